@@ -1,0 +1,13 @@
+"""MI355X-native (gfx950 / CDNA4) hot path of the AMR volume renderer.
+
+A from-scratch implementation of the one data-parallel path of BenWibking/amrVolumeRenderer:
+VolumePainter's ray march over AMR bricks, the depth-sorted / float / ubyte over-blend and the
+DirectSend sort-last compositor, as hand-written HIP kernels behind a C ABI
+(include/avr_hip.h, built to amrvolumerenderer_amd/libavr_hip.so).  See DESIGN.md.
+"""
+from . import _capi  # noqa: F401
+from .types import (AmrBox, CameraParameters, ColorMapControlPoint, ScalarTransform,  # noqa: F401
+                    VolumeBounds, make_params)
+
+__all__ = ["AmrBox", "CameraParameters", "ColorMapControlPoint", "ScalarTransform",
+           "VolumeBounds", "make_params"]

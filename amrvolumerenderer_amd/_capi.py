@@ -1,0 +1,155 @@
+"""ctypes binding of the C ABI (include/avr_hip.h) implemented by libavr_hip.so.
+
+The library is built in-tree by ``amrvolumerenderer_amd.build.build()`` (hipcc, gfx950).  There
+is no fallback: if the shared object is missing or a HIP device is absent, the compute entry
+points raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libavr_hip.so")
+
+AVR_OK = 0
+AVR_ERR_INVALID_ARGUMENT = -1
+AVR_ERR_RUNTIME = -2
+AVR_ERR_NO_DEVICE = -3
+AVR_ERR_OUT_OF_MEMORY = -4
+
+
+class AvrError(RuntimeError):
+    """std::runtime_error of the reference API (HIP failures included)."""
+
+
+class AvrNoDevice(AvrError):
+    pass
+
+
+class Box(C.Structure):
+    _fields_ = [
+        ("min_corner", C.c_double * 3),
+        ("max_corner", C.c_double * 3),
+        ("dims", C.c_int32 * 3),
+        ("level", C.c_int32),
+        ("cells", C.c_void_p),
+        ("jstride", C.c_int64),
+        ("kstride", C.c_int64),
+    ]
+
+
+class ScalarTransform(C.Structure):
+    _fields_ = [
+        ("log_scale_input", C.c_int32),
+        ("normalize_to_unit_range", C.c_int32),
+        ("positive_floor", C.c_double),
+        ("normalization_min", C.c_double),
+        ("inverse_normalization_span", C.c_double),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("eye", C.c_double * 3),
+        ("look_at", C.c_double * 3),
+        ("up", C.c_double * 3),
+        ("fov_y_degrees", C.c_float),
+        ("near_plane", C.c_float),
+        ("far_plane", C.c_float),
+    ]
+
+
+class ColormapPoint(C.Structure):
+    _fields_ = [("value", C.c_float), ("red", C.c_float), ("green", C.c_float),
+                ("blue", C.c_float), ("alpha", C.c_float)]
+
+
+class PaintParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("scalar_range", C.c_float * 2),
+        ("box_transparency", C.c_float),
+        ("reference_sample_distance", C.c_float),
+        ("bounds_min", C.c_double * 3),
+        ("bounds_max", C.c_double * 3),
+        ("colormap", C.POINTER(ColormapPoint)),
+        ("colormap_count", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/avr_hip.h declares.
+_vp = C.c_void_p
+_i64 = C.c_int64
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+SIGNATURES = {
+    "avr_last_error": (C.c_char_p, []),
+    "avr_abi_version": (C.c_int, []),
+    "avr_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "avr_context_destroy": (None, [_vp]),
+    "avr_context_set_stream": (C.c_int, [_vp, _vp]),
+    "avr_context_synchronize": (C.c_int, [_vp]),
+    "avr_build_color_table": (C.c_int, [C.c_float, C.c_float, _fp, C.POINTER(ColormapPoint),
+                                         C.c_int, _fp]),
+    "avr_box_sampling": (C.c_int, [C.POINTER(Box), C.POINTER(PaintParams), _fp, _fp, _fp]),
+    "avr_box_depth_hint": (C.c_int, [C.POINTER(Box), C.POINTER(Camera), _fp]),
+    "avr_reference_sample_distance": (C.c_int, [C.POINTER(Box), C.c_int, C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_double), _fp]),
+    "avr_layer_order": (C.c_int, [_fp, _ip, _ip, C.c_int, _ip, _ip, C.POINTER(C.c_int)]),
+    "avr_piece_range": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
+    "avr_paint_box": (C.c_int, [_vp, C.POINTER(Box), C.POINTER(ScalarTransform),
+                                 C.POINTER(PaintParams), C.POINTER(Camera), _vp, _vp]),
+    "avr_scene_create": (C.c_int, [_vp, C.POINTER(Box), C.c_int, C.POINTER(ScalarTransform),
+                                    C.POINTER(_vp)]),
+    "avr_scene_destroy": (None, [_vp]),
+    "avr_render_runs": (C.c_int, [_vp, _vp, C.POINTER(PaintParams), C.POINTER(Camera), _ip,
+                                   C.c_int, _ip, C.c_int, C.c_int, _vp, _vp]),
+    "avr_blend_depthsort_f32x5": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
+    "avr_blend_rgba_f32x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
+    "avr_blend_rgba_u8x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
+    "avr_blend_regions": (C.c_int, [_vp, C.c_int, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "avr_encode_rgba_u8": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "avr_decode_rgba_u8": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "avr_fold_runs_depthsort": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, _i64]),
+    "avr_downsample_depthsort": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "avr_quantize_rgb8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AvrError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().avr_last_error().decode("utf-8", "replace")
+
+
+def check(status: int) -> None:
+    """Maps a status code to the exception the reference API raises for it."""
+    if status == AVR_OK:
+        return
+    message = last_error()
+    if status == AVR_ERR_INVALID_ARGUMENT:
+        raise ValueError(message)          # std::invalid_argument
+    if status == AVR_ERR_NO_DEVICE:
+        raise AvrNoDevice(message)
+    if status == AVR_ERR_OUT_OF_MEMORY:
+        raise MemoryError(message)
+    raise AvrError(message)                # std::runtime_error

@@ -1,0 +1,462 @@
+// C ABI of the MI355X volume-rendering path (include/avr_hip.h).  Thin: validates, runs the
+// host prologue (avr_host.cpp), stages the per-frame descriptors and launches the kernels
+// (avr_kernels.hip) on the context's stream.  No CPU compute fallback exists behind it.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <exception>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "avr_internal.h"
+
+namespace avr {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void set_error(const std::string& message) { g_last_error = message; }
+
+namespace {
+
+class HipFailure : public std::runtime_error {
+ public:
+  using std::runtime_error::runtime_error;
+};
+
+void hip_check(hipError_t err, const char* what) {
+  if (err != hipSuccess) {
+    throw HipFailure(std::string(what) + ": " + hipGetErrorString(err));
+  }
+}
+
+// A grow-only device buffer with a pinned host mirror for asynchronous uploads.
+class StagedBuffer {
+ public:
+  ~StagedBuffer() { release(); }
+  void release() {
+    if (dev_ != nullptr) (void)hipFree(dev_);
+    if (host_ != nullptr) (void)hipHostFree(host_);
+    dev_ = nullptr;
+    host_ = nullptr;
+    capacity_ = 0;
+  }
+  void reserve(size_t bytes) {
+    if (bytes <= capacity_) return;
+    release();
+    size_t cap = 4096;
+    while (cap < bytes) cap *= 2;
+    hip_check(hipMalloc(&dev_, cap), "hipMalloc(staging)");
+    hip_check(hipHostMalloc(&host_, cap, hipHostMallocDefault), "hipHostMalloc(staging)");
+    capacity_ = cap;
+  }
+  void* host() const { return host_; }
+  void* dev() const { return dev_; }
+
+ private:
+  void* dev_ = nullptr;
+  void* host_ = nullptr;
+  size_t capacity_ = 0;
+};
+
+}  // namespace
+}  // namespace avr
+
+struct avr_context {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t staged = nullptr;   // recorded after the last upload that read the pinned mirrors
+  bool staged_pending = false;
+  avr::StagedBuffer boxes, tables, order, run_end, slices;
+
+  void wait_staging() {
+    if (staged_pending) {
+      avr::hip_check(hipEventSynchronize(staged), "hipEventSynchronize(staging)");
+      staged_pending = false;
+    }
+  }
+  void mark_staging() {
+    avr::hip_check(hipEventRecord(staged, stream), "hipEventRecord(staging)");
+    staged_pending = true;
+  }
+  void upload(avr::StagedBuffer& buffer, const void* src, size_t bytes) {
+    if (bytes == 0) return;
+    buffer.reserve(bytes);
+    std::memcpy(buffer.host(), src, bytes);
+    avr::hip_check(hipMemcpyAsync(buffer.dev(), buffer.host(), bytes, hipMemcpyHostToDevice, stream),
+                   "hipMemcpyAsync(staging)");
+  }
+};
+
+struct avr_scene {
+  avr_context* ctx = nullptr;
+  std::vector<avr_box> boxes;
+  avr_scalar_transform transform{};
+};
+
+namespace {
+
+// Runs `body`, mapping exceptions to status codes (no exception crosses the ABI).
+template <typename F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::invalid_argument& e) {
+    avr::set_error(e.what());
+    return AVR_ERR_INVALID_ARGUMENT;
+  } catch (const std::bad_alloc&) {
+    avr::set_error("out of host memory");
+    return AVR_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    avr::set_error(e.what());
+    return AVR_ERR_RUNTIME;
+  } catch (...) {
+    avr::set_error("unknown failure");
+    return AVR_ERR_RUNTIME;
+  }
+}
+
+void require(bool condition, const char* message) {
+  if (!condition) throw std::invalid_argument(message);
+}
+
+void bind_device(avr_context* ctx) {
+  require(ctx != nullptr, "null context");
+  avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+}
+
+int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
+           const avr_scalar_transform& transform, const avr_paint_params& params,
+           const avr_camera& camera, const int32_t* box_order, int n_order,
+           const int32_t* run_end, int n_runs, int n_pieces, float* out_layers,
+           uint64_t* samples_out) {
+  require(out_layers != nullptr, "null output image");
+  require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
+  require(n_runs == 0 || (run_end != nullptr), "null run_end");
+  require(n_order == 0 || (box_order != nullptr), "null box_order");
+  int previous = 0;
+  for (int r = 0; r < n_runs; ++r) {
+    require(run_end[r] >= previous && run_end[r] <= n_order, "run_end must be non-decreasing");
+    previous = run_end[r];
+  }
+  require(n_runs == 0 || run_end[n_runs - 1] == n_order, "runs must cover box_order");
+  for (int i = 0; i < n_order; ++i) {
+    require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
+  }
+
+  avr::FramePlan plan;
+  avr::plan_frame(boxes, n_boxes, transform, params, camera, &plan);
+  if (n_runs == 0) return AVR_OK;
+  require(plan.n_tables <= avr::kMaxLdsTables,
+          "too many distinct sampling levels for the LDS transfer-function cache");
+
+  ctx->wait_staging();
+  ctx->upload(ctx->boxes, plan.boxes.data(), plan.boxes.size() * sizeof(avr::BoxDev));
+  ctx->upload(ctx->tables, plan.tables.data(), plan.tables.size() * sizeof(float));
+  ctx->upload(ctx->order, box_order, static_cast<size_t>(n_order) * sizeof(int32_t));
+  ctx->upload(ctx->run_end, run_end, static_cast<size_t>(n_runs) * sizeof(int32_t));
+  ctx->mark_staging();
+
+  avr::RenderLaunch launch;
+  launch.consts = plan.consts;
+  launch.boxes_dev = static_cast<const avr::BoxDev*>(ctx->boxes.dev());
+  launch.tables_dev = static_cast<const float*>(ctx->tables.dev());
+  launch.n_tables = plan.n_tables;
+  launch.order_dev = static_cast<const int32_t*>(ctx->order.dev());
+  launch.run_end_dev = static_cast<const int32_t*>(ctx->run_end.dev());
+  launch.n_order = n_order;
+  launch.n_runs = n_runs;
+  launch.n_pieces = n_pieces;
+  launch.out_layers = out_layers;
+  launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
+  return avr::launch_render_runs(launch, ctx->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* avr_last_error(void) { return avr::g_last_error.c_str(); }
+
+int avr_abi_version(void) { return 1; }
+
+int avr_context_create(int device_id, avr_context** out_ctx) {
+  return guarded([&]() -> int {
+    require(out_ctx != nullptr, "null out_ctx");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+      avr::set_error("no HIP device available (this library has no CPU fallback)");
+      return AVR_ERR_NO_DEVICE;
+    }
+    require(device_id >= 0 && device_id < count, "device_id out of range");
+    avr::hip_check(hipSetDevice(device_id), "hipSetDevice");
+    auto* ctx = new avr_context();
+    ctx->device = device_id;
+    try {
+      avr::hip_check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
+                     "hipStreamCreate");
+      avr::hip_check(hipEventCreateWithFlags(&ctx->staged, hipEventDisableTiming),
+                     "hipEventCreate");
+    } catch (...) {
+      delete ctx;
+      throw;
+    }
+    ctx->stream = ctx->own_stream;
+    *out_ctx = ctx;
+    return AVR_OK;
+  });
+}
+
+void avr_context_destroy(avr_context* ctx) {
+  if (ctx == nullptr) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->own_stream != nullptr) (void)hipStreamSynchronize(ctx->own_stream);
+  ctx->boxes.release();
+  ctx->tables.release();
+  ctx->order.release();
+  ctx->run_end.release();
+  ctx->slices.release();
+  if (ctx->staged != nullptr) (void)hipEventDestroy(ctx->staged);
+  if (ctx->own_stream != nullptr) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int avr_context_set_stream(avr_context* ctx, void* hip_stream) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    ctx->wait_staging();
+    ctx->stream = (hip_stream != nullptr) ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return AVR_OK;
+  });
+}
+
+int avr_context_synchronize(avr_context* ctx) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    avr::hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return AVR_OK;
+  });
+}
+
+int avr_build_color_table(float alpha_scale, float normalization_factor,
+                          const float scalar_range[2], const avr_colormap_point* colormap,
+                          int colormap_count, float out_table_host[1024]) {
+  return guarded([&]() -> int {
+    require(scalar_range != nullptr && out_table_host != nullptr, "null argument");
+    require(colormap_count >= 0 && (colormap_count == 0 || colormap != nullptr),
+            "invalid color map");
+    avr::build_color_table(alpha_scale, normalization_factor, scalar_range, colormap,
+                           colormap_count, out_table_host);
+    return AVR_OK;
+  });
+}
+
+int avr_box_sampling(const avr_box* box, const avr_paint_params* params, float* sample_distance,
+                     float* normalization_factor, float* alpha_scale) {
+  return guarded([&]() -> int {
+    require(box != nullptr && params != nullptr && sample_distance != nullptr &&
+                normalization_factor != nullptr && alpha_scale != nullptr,
+            "null argument");
+    avr::box_sampling(*box, *params, sample_distance, normalization_factor, alpha_scale);
+    return AVR_OK;
+  });
+}
+
+int avr_box_depth_hint(const avr_box* box, const avr_camera* camera, float* out_hint) {
+  return guarded([&]() -> int {
+    require(box != nullptr && camera != nullptr && out_hint != nullptr, "null argument");
+    *out_hint = avr::box_depth_hint(*box, *camera);
+    return AVR_OK;
+  });
+}
+
+int avr_reference_sample_distance(const avr_box* boxes, int n_boxes, const double bounds_min[3],
+                                  const double bounds_max[3], float* out_distance) {
+  return guarded([&]() -> int {
+    require(n_boxes >= 0 && (n_boxes == 0 || boxes != nullptr), "invalid box list");
+    require(bounds_min != nullptr && bounds_max != nullptr && out_distance != nullptr,
+            "null argument");
+    *out_distance = avr::reference_sample_distance(boxes, n_boxes, bounds_min, bounds_max);
+    return AVR_OK;
+  });
+}
+
+int avr_layer_order(const float* hints, const int32_t* owner, const int32_t* local_index,
+                    int n_layers, int32_t* order_out, int32_t* run_end_out, int* n_runs_out) {
+  return guarded([&]() -> int {
+    require(n_layers >= 0 && n_runs_out != nullptr, "invalid argument");
+    if (n_layers == 0) {
+      *n_runs_out = 0;
+      return AVR_OK;
+    }
+    require(hints != nullptr && owner != nullptr && local_index != nullptr &&
+                order_out != nullptr && run_end_out != nullptr,
+            "null argument");
+    *n_runs_out = avr::layer_order(hints, owner, local_index, n_layers, order_out, run_end_out);
+    return AVR_OK;
+  });
+}
+
+int avr_piece_range(int64_t image_size, int piece_index, int num_pieces, int64_t* begin,
+                    int64_t* end) {
+  return guarded([&]() -> int {
+    require(begin != nullptr && end != nullptr, "null argument");
+    require(num_pieces >= 1 && piece_index >= 0 && piece_index < num_pieces && image_size >= 0,
+            "invalid piece");
+    const int64_t piece_size = image_size / num_pieces;
+    *begin = piece_size * piece_index;
+    *end = (piece_index < num_pieces - 1) ? (*begin + piece_size) : image_size;
+    return AVR_OK;
+  });
+}
+
+int avr_paint_box(avr_context* ctx, const avr_box* box, const avr_scalar_transform* transform,
+                  const avr_paint_params* params, const avr_camera* camera, float* out_rgbad,
+                  uint64_t* samples_out) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(box != nullptr && transform != nullptr && params != nullptr && camera != nullptr,
+            "null argument");
+    const int32_t order[1] = {0};
+    const int32_t run_end[1] = {1};
+    return render(ctx, box, 1, *transform, *params, *camera, order, 1, run_end, 1, 1, out_rgbad,
+                  samples_out);
+  });
+}
+
+int avr_scene_create(avr_context* ctx, const avr_box* boxes, int n_boxes,
+                     const avr_scalar_transform* transform, avr_scene** out_scene) {
+  return guarded([&]() -> int {
+    require(ctx != nullptr && out_scene != nullptr && transform != nullptr, "null argument");
+    require(n_boxes >= 0 && (n_boxes == 0 || boxes != nullptr), "invalid box list");
+    auto* scene = new avr_scene();
+    scene->ctx = ctx;
+    scene->boxes.assign(boxes, boxes + n_boxes);
+    scene->transform = *transform;
+    *out_scene = scene;
+    return AVR_OK;
+  });
+}
+
+void avr_scene_destroy(avr_scene* scene) { delete scene; }
+
+int avr_render_runs(avr_context* ctx, const avr_scene* scene, const avr_paint_params* params,
+                    const avr_camera* camera, const int32_t* box_order, int n_order,
+                    const int32_t* run_end, int n_runs, int n_pieces, float* out_layers,
+                    uint64_t* samples_out) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(scene != nullptr && params != nullptr && camera != nullptr, "null argument");
+    return render(ctx, scene->boxes.data(), static_cast<int>(scene->boxes.size()),
+                  scene->transform, *params, *camera, box_order, n_order, run_end, n_runs, n_pieces,
+                  out_layers, samples_out);
+  });
+}
+
+static int blend_common(avr_context* ctx, int kind, const void* top, const void* bottom, void* out,
+                        int64_t n_pixels) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(n_pixels >= 0, "negative pixel count");
+    if (n_pixels == 0) return AVR_OK;
+    require(top != nullptr && bottom != nullptr && out != nullptr, "null image");
+    return avr::launch_blend(kind, top, bottom, out, n_pixels, ctx->stream);
+  });
+}
+
+int avr_blend_depthsort_f32x5(avr_context* ctx, const float* top, const float* bottom, float* out,
+                              int64_t n_pixels) {
+  return blend_common(ctx, 0, top, bottom, out, n_pixels);
+}
+
+int avr_blend_rgba_f32x4(avr_context* ctx, const float* top, const float* bottom, float* out,
+                         int64_t n_pixels) {
+  return blend_common(ctx, 1, top, bottom, out, n_pixels);
+}
+
+int avr_blend_rgba_u8x4(avr_context* ctx, const uint32_t* top, const uint32_t* bottom,
+                        uint32_t* out, int64_t n_pixels) {
+  return blend_common(ctx, 2, top, bottom, out, n_pixels);
+}
+
+int avr_blend_regions(avr_context* ctx, int kind, const void* top, int64_t tb, int64_t te,
+                      const void* bottom, int64_t bb, int64_t be, void* out) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(kind >= 0 && kind <= 2, "unknown image kind");
+    require(tb <= te && bb <= be, "invalid region");
+    // the reference asserts the regions touch or overlap (ImageColorOnly.hpp:129-130)
+    require(tb <= be && bb <= te, "regions neither overlap nor touch");
+    const int64_t n = (te > be ? te : be) - (tb < bb ? tb : bb);
+    if (n == 0) return AVR_OK;
+    require(out != nullptr && (te == tb || top != nullptr) && (be == bb || bottom != nullptr),
+            "null image");
+    return avr::launch_blend_regions(kind, top, tb, te, bottom, bb, be, out, ctx->stream);
+  });
+}
+
+int avr_encode_rgba_u8(avr_context* ctx, const float* rgba, uint32_t* out, int64_t n_pixels) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(n_pixels >= 0, "negative pixel count");
+    if (n_pixels == 0) return AVR_OK;
+    require(rgba != nullptr && out != nullptr, "null image");
+    return avr::launch_encode_u8(rgba, out, n_pixels, ctx->stream);
+  });
+}
+
+int avr_decode_rgba_u8(avr_context* ctx, const uint32_t* in, float* rgba, int64_t n_pixels) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(n_pixels >= 0, "negative pixel count");
+    if (n_pixels == 0) return AVR_OK;
+    require(rgba != nullptr && in != nullptr, "null image");
+    return avr::launch_decode_u8(in, rgba, n_pixels, ctx->stream);
+  });
+}
+
+int avr_fold_runs_depthsort(avr_context* ctx, const float* const* slices_host, int n_slices,
+                            float* out, int64_t n_pixels) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(n_slices >= 0 && n_pixels >= 0, "invalid argument");
+    if (n_pixels == 0) return AVR_OK;
+    require(out != nullptr && (n_slices == 0 || slices_host != nullptr), "null argument");
+    for (int s = 0; s < n_slices; ++s) require(slices_host[s] != nullptr, "null slice");
+    ctx->wait_staging();
+    ctx->upload(ctx->slices, slices_host, static_cast<size_t>(n_slices) * sizeof(float*));
+    ctx->mark_staging();
+    return avr::launch_fold_runs(static_cast<const float* const*>(ctx->slices.dev()), n_slices, out,
+                                 n_pixels, ctx->stream);
+  });
+}
+
+int avr_downsample_depthsort(avr_context* ctx, const float* src, int target_w, int target_h,
+                             int block, float* dst) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    // downsampleImage throws for sqrtAA <= 1 (VolumeRenderer.cpp:483-487)
+    require(block > 1, "downsample expects a block size > 1");
+    require(target_w >= 0 && target_h >= 0, "invalid target size");
+    if (target_w == 0 || target_h == 0) return AVR_OK;
+    require(src != nullptr && dst != nullptr, "null image");
+    return avr::launch_downsample(src, target_w, target_h, block, dst, ctx->stream);
+  });
+}
+
+int avr_quantize_rgb8(avr_context* ctx, const float* src, int w, int h, int stride, uint8_t* dst) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(w >= 0 && h >= 0 && stride >= 3, "invalid image description");
+    if (w == 0 || h == 0) return AVR_OK;
+    require(src != nullptr && dst != nullptr, "null image");
+    return avr::launch_quantize(src, w, h, stride, dst, ctx->stream);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,628 @@
+// Host prologue of the MI355X volume-rendering path: everything VolumePainter::paint and
+// renderSingleTrial compute on the host per frame / per box before the device loop runs.
+// The transfer-function table is built here (host libm, 256 entries per sampling level) so
+// that pow/tan never run on the GPU and the table bits match the reference's host build
+// ("Hard parts").
+//
+// Reference: Common/VolumePainter.cpp:107-125 (computeScaledAlpha), :127-200 (table nodes),
+// :202-320 (CIELAB), :331-440 (colour / opacity mapping), :442-516 (buildColorTable),
+// :571-733 (paint prologue); VolumeRenderer/VolumeRenderer.cpp:541-553 (depth hint),
+// :1138-1190 (reference sample distance); DirectSend/Base/DirectSendBase.cpp:363-410 (order).
+#include "avr_internal.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <stdexcept>
+
+namespace avr {
+
+namespace {
+
+constexpr float kSoftClipTolerance = 1e-5f;
+constexpr float kPi = 3.14159265358979323846f;
+
+struct Rgba {
+  float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f;
+};
+
+struct ColorStop {
+  float value = 0.0f;
+  float r = 0.0f, g = 0.0f, b = 0.0f;
+};
+
+struct OpacityStop {
+  float value = 0.0f;
+  float alpha = 0.0f;
+  float midpoint = 0.5f;
+  float sharpness = 0.0f;
+};
+
+// The reference's ColorTableSpec (VolumePainter.cpp:65-73).
+class TransferFunction {
+ public:
+  bool lab = false;
+  bool clamp_ends = true;
+  Rgba nan_color{0.5f, 0.0f, 0.0f, 1.0f};
+  Rgba below{0.0f, 0.0f, 0.0f, 1.0f};
+  Rgba above{0.0f, 0.0f, 0.0f, 1.0f};
+  std::vector<ColorStop> colors;
+  std::vector<OpacityStop> opacity;
+
+  // insertColorNode / insertOpacityNode: sorted by value, an equal value replaces (:127-151).
+  void add(const ColorStop& stop) {
+    auto it = std::lower_bound(colors.begin(), colors.end(), stop.value,
+                               [](const ColorStop& s, float v) { return s.value < v; });
+    if (it != colors.end() && it->value == stop.value) {
+      *it = stop;
+    } else {
+      colors.insert(it, stop);
+    }
+  }
+  void add(const OpacityStop& stop) {
+    auto it = std::lower_bound(opacity.begin(), opacity.end(), stop.value,
+                               [](const OpacityStop& s, float v) { return s.value < v; });
+    if (it != opacity.end() && it->value == stop.value) {
+      *it = stop;
+    } else {
+      opacity.insert(it, stop);
+    }
+  }
+
+  // rescaleTableToRange (:153-200)
+  void rescale(float range_min, float range_max) {
+    bool seen = false;
+    float lo = 0.0f, hi = 0.0f;
+    auto visit = [&](float v) {
+      if (!seen) {
+        lo = hi = v;
+        seen = true;
+        return;
+      }
+      lo = std::min(lo, v);
+      hi = std::max(hi, v);
+    };
+    for (const auto& s : colors) visit(s.value);
+    for (const auto& s : opacity) visit(s.value);
+    if (!seen) lo = hi = 0.0f;
+    const float old_span = hi - lo;
+    const float new_span = range_max - range_min;
+    if (!(old_span > 0.0f) || !(new_span > 0.0f)) return;
+    for (auto& s : colors) {
+      const float t = (s.value - lo) / old_span;
+      s.value = range_min + new_span * t;
+    }
+    for (auto& s : opacity) {
+      const float t = (s.value - lo) / old_span;
+      s.value = range_min + new_span * t;
+    }
+  }
+
+  Rgba color_at(float value) const;     // mapColorValue (:331-379)
+  float opacity_at(float value) const;  // mapOpacityValue (:381-440)
+};
+
+float srgb_to_linear(float c) {
+  return (c > 0.04045f) ? std::pow((c + 0.055f) / 1.055f, 2.4f) : c / 12.92f;
+}
+float linear_to_srgb(float c) {
+  constexpr float inv_gamma = 1.0f / 2.4f;
+  return (c > 0.0031308f) ? 1.055f * std::pow(c, inv_gamma) - 0.055f : 12.92f * c;
+}
+float lab_f(float t) {
+  constexpr float third = 1.0f / 3.0f;
+  constexpr float offset = 16.0f / 116.0f;
+  return (t > 0.008856f) ? std::pow(t, third) : (7.787f * t) + offset;
+}
+float lab_f_inverse(float t) {
+  constexpr float offset = 16.0f / 116.0f;
+  return (std::pow(t, 3.0f) > 0.008856f) ? std::pow(t, 3.0f) : (t - offset) / 7.787f;
+}
+
+// rgbToLab (:202-256): sRGB -> XYZ (D65 constants as written in the reference) -> CIELAB.
+Rgba to_lab(const Rgba& rgb) {
+  const float r = srgb_to_linear(rgb.r);
+  const float g = srgb_to_linear(rgb.g);
+  const float b = srgb_to_linear(rgb.b);
+  const float x = r * 0.4124f + g * 0.3576f + b * 0.1805f;
+  const float y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+  const float z = r * 0.0193f + g * 0.1192f + b * 0.9505f;
+  const float fx = lab_f(x / 0.9505f);
+  const float fy = lab_f(y / 1.0f);
+  const float fz = lab_f(z / 1.089f);
+  Rgba lab;
+  lab.r = (116.0f * fy) - 16.0f;
+  lab.g = 500.0f * (fx - fy);
+  lab.b = 200.0f * (fy - fz);
+  lab.a = rgb.a;
+  return lab;
+}
+
+// labToRgb (:258-320), including the max-normalisation and the >= 0 clamp.
+Rgba from_lab(const Rgba& lab) {
+  float y = (lab.r + 16.0f) / 116.0f;
+  float x = lab.g / 500.0f + y;
+  float z = y - lab.b / 200.0f;
+  x = lab_f_inverse(x);
+  y = lab_f_inverse(y);
+  z = lab_f_inverse(z);
+  x *= 0.9505f;
+  y *= 1.0f;
+  z *= 1.089f;
+  float r = x * 3.2406f + y * -1.5372f + z * -0.4986f;
+  float g = x * -0.9689f + y * 1.8758f + z * 0.0415f;
+  float b = x * 0.0557f + y * -0.2040f + z * 1.0570f;
+  r = linear_to_srgb(r);
+  g = linear_to_srgb(g);
+  b = linear_to_srgb(b);
+  const float peak = std::max(r, std::max(g, b));
+  if (peak > 1.0f) {
+    r /= peak;
+    g /= peak;
+    b /= peak;
+  }
+  Rgba rgb;
+  rgb.r = std::max(r, 0.0f);
+  rgb.g = std::max(g, 0.0f);
+  rgb.b = std::max(b, 0.0f);
+  rgb.a = lab.a;
+  return rgb;
+}
+
+Rgba mix(const Rgba& l, const Rgba& r, float t) {  // lerpColor (:322-329)
+  return {l.r + (r.r - l.r) * t, l.g + (r.g - l.g) * t, l.b + (r.b - l.b) * t,
+          l.a + (r.a - l.a) * t};
+}
+
+Rgba TransferFunction::color_at(float value) const {
+  if (!std::isfinite(value)) return nan_color;
+  if (colors.empty()) return below;
+  const ColorStop& first = colors.front();
+  const ColorStop& last = colors.back();
+  if (value < first.value) return clamp_ends ? Rgba{first.r, first.g, first.b, 1.0f} : below;
+  if (value > last.value) return clamp_ends ? Rgba{last.r, last.g, last.b, 1.0f} : above;
+  if (value == first.value) return {first.r, first.g, first.b, 1.0f};
+  if (value == last.value) return {last.r, last.g, last.b, 1.0f};
+  for (std::size_t i = 1; i < colors.size(); ++i) {
+    const ColorStop& hi = colors[i];
+    if (hi.value >= value) {
+      const ColorStop& lo = colors[i - 1];
+      const float span = hi.value - lo.value;
+      const float t = (span > 0.0f) ? (value - lo.value) / span : 0.0f;
+      const Rgba a{lo.r, lo.g, lo.b, 1.0f};
+      const Rgba b{hi.r, hi.g, hi.b, 1.0f};
+      if (lab) return from_lab(mix(to_lab(a), to_lab(b), t));
+      return mix(a, b, t);
+    }
+  }
+  return {last.r, last.g, last.b, 1.0f};
+}
+
+float TransferFunction::opacity_at(float value) const {
+  if (!std::isfinite(value)) return 1.0f;
+  if (opacity.empty()) return 1.0f;
+  const OpacityStop& first = opacity.front();
+  const OpacityStop& last = opacity.back();
+  if (value <= first.value) return first.alpha;
+  if (value >= last.value) return last.alpha;
+  for (std::size_t i = 1; i < opacity.size(); ++i) {
+    const OpacityStop& hi = opacity[i];
+    if (!(hi.value >= value)) continue;
+    const OpacityStop& lo = opacity[i - 1];
+    const float span = hi.value - lo.value;
+    float w = (span > 0.0f) ? (value - lo.value) / span : 0.0f;
+    if (w < lo.midpoint) {
+      w = 0.5f * w / lo.midpoint;
+    } else {
+      w = 0.5f + 0.5f * (w - lo.midpoint) / (1.0f - lo.midpoint);
+    }
+    if (lo.sharpness == 1.0f) return (w < 0.5f) ? lo.alpha : hi.alpha;
+    if (lo.sharpness == 0.0f) return lo.alpha + (hi.alpha - lo.alpha) * w;
+    if (w < 0.5f) {
+      w = 0.5f * std::pow(w * 2.0f, 1.0f + 10.0f * lo.sharpness);
+    } else if (w > 0.5f) {
+      w = 1.0f - 0.5f * std::pow((1.0f - w) * 2.0f, 1.0f + 10.0f * lo.sharpness);
+    }
+    const float w2 = w * w;
+    const float w3 = w2 * w;
+    const float h1 = 2.0f * w3 - 3.0f * w2 + 1.0f;
+    const float h2 = -2.0f * w3 + 3.0f * w2;
+    const float h3 = w3 - 2.0f * w2 + w;
+    const float h4 = w3 - w2;
+    const float slope = hi.alpha - lo.alpha;
+    const float tangent = (1.0f - lo.sharpness) * slope;
+    float result = h1 * lo.alpha + h2 * hi.alpha + h3 * tangent + h4 * tangent;
+    result = std::max(result, std::min(lo.alpha, hi.alpha));
+    result = std::min(result, std::max(lo.alpha, hi.alpha));
+    return result;
+  }
+  return last.alpha;
+}
+
+// computeScaledAlpha (:107-125): opacity correction for the box's step length.
+float step_corrected_alpha(float base_alpha, float alpha_scale, float normalization_factor) {
+  const float scaled = std::clamp(base_alpha * alpha_scale, 0.0f, 1.0f);
+  if (normalization_factor <= 0.0f || scaled <= 0.0f) return 0.0f;
+  if (scaled >= 1.0f) return 1.0f;
+  const double transmittance =
+      std::pow(1.0 - static_cast<double>(scaled), static_cast<double>(normalization_factor));
+  float alpha = static_cast<float>(1.0 - transmittance);
+  if (!std::isfinite(alpha)) alpha = scaled;
+  return std::clamp(alpha, 0.0f, 1.0f);
+}
+
+struct Vec3d {
+  double x = 0.0, y = 0.0, z = 0.0;
+};
+Vec3d sub(const Vec3d& a, const Vec3d& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+double dot(const Vec3d& a, const Vec3d& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+double norm(const Vec3d& a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+Vec3d cross(const Vec3d& a, const Vec3d& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+Vec3d from(const double v[3]) { return {v[0], v[1], v[2]}; }
+
+// camera::safeNormalize (Common/CameraUtils.hpp:17-23)
+Vec3d normalized_or_default(const Vec3d& v) {
+  const double len = norm(v);
+  if (len > 0.0 && std::isfinite(len)) return {v.x / len, v.y / len, v.z / len};
+  return {0.0, 0.0, -1.0};
+}
+
+struct CameraBasis {
+  Vec3d forward, right, up;
+};
+
+// VolumePainter.cpp:631-639
+CameraBasis camera_basis(const avr_camera& camera) {
+  CameraBasis basis;
+  basis.forward = normalized_or_default(sub(from(camera.look_at), from(camera.eye)));
+  Vec3d right = cross(basis.forward, from(camera.up));
+  const double right_len = norm(right);
+  if (right_len > 0.0 && std::isfinite(right_len)) {
+    right = {right.x / right_len, right.y / right_len, right.z / right_len};
+  } else {
+    right = {1.0, 0.0, 0.0};
+  }
+  basis.right = right;
+  basis.up = cross(right, basis.forward);
+  return basis;
+}
+
+bool is_power_of_two(float v) {
+  if (!(v > 0.0f) || !std::isfinite(v)) return false;
+  int exponent = 0;
+  return std::frexp(v, &exponent) == 0.5f;
+}
+
+// Conservative screen rectangle of a box: every pixel whose forward ray can intersect the box
+// lies inside.  Pixels outside produce the empty layer pixel (0,0,0,0,+inf) in the reference
+// (slab miss, or an intersection interval entirely behind the eye: VolumePainter.cpp:802-837),
+// which is an exact identity of the depth-sort blend, so skipping them does not change bits.
+void screen_rect(const avr_box& box, const avr_camera& camera, const CameraBasis& basis,
+                 const FrameConsts& fc, int32_t rect[4]) {
+  const Vec3d eye = from(camera.eye);
+  double lo_x = std::numeric_limits<double>::infinity(), hi_x = -lo_x;
+  double lo_y = lo_x, hi_y = -lo_x;
+  bool full = false;
+  const double tan_y = static_cast<double>(fc.tan_half_fov);
+  const double tan_x = tan_y * static_cast<double>(fc.aspect);
+  // Corners are tested after the float cast the kernel applies (VolumePainter.cpp:658-665).
+  for (int corner = 0; corner < 8 && !full; ++corner) {
+    const Vec3d p{
+        static_cast<double>(static_cast<float>((corner & 1) ? box.max_corner[0] : box.min_corner[0])),
+        static_cast<double>(static_cast<float>((corner & 2) ? box.max_corner[1] : box.min_corner[1])),
+        static_cast<double>(static_cast<float>((corner & 4) ? box.max_corner[2] : box.min_corner[2]))};
+    const Vec3d v = sub(p, eye);
+    const double depth = dot(v, basis.forward);
+    if (!(depth > 1e-6) || !std::isfinite(depth)) {
+      full = true;
+      break;
+    }
+    const double ndc_x = dot(v, basis.right) / (depth * tan_x);
+    const double ndc_y = dot(v, basis.up) / (depth * tan_y);
+    const double px = (ndc_x + 1.0) * 0.5 * fc.width - 0.5;
+    const double py = (ndc_y + 1.0) * 0.5 * fc.height - 0.5;
+    if (!std::isfinite(px) || !std::isfinite(py)) {
+      full = true;
+      break;
+    }
+    lo_x = std::min(lo_x, px);
+    hi_x = std::max(hi_x, px);
+    lo_y = std::min(lo_y, py);
+    hi_y = std::max(hi_y, py);
+  }
+  if (full) {
+    rect[0] = 0;
+    rect[1] = 0;
+    rect[2] = fc.width - 1;
+    rect[3] = fc.height - 1;
+    return;
+  }
+  constexpr double margin = 2.0;  // pixels; float rounding of the ray setup is << 1 pixel
+  const double x0 = std::floor(lo_x - margin), x1 = std::ceil(hi_x + margin);
+  const double y0 = std::floor(lo_y - margin), y1 = std::ceil(hi_y + margin);
+  if (x1 < 0.0 || y1 < 0.0 || x0 > fc.width - 1.0 || y0 > fc.height - 1.0) {
+    rect[0] = 0;
+    rect[1] = 0;
+    rect[2] = -1;
+    rect[3] = -1;
+    return;
+  }
+  rect[0] = static_cast<int32_t>(std::max(x0, 0.0));
+  rect[1] = static_cast<int32_t>(std::max(y0, 0.0));
+  rect[2] = static_cast<int32_t>(std::min(x1, fc.width - 1.0));
+  rect[3] = static_cast<int32_t>(std::min(y1, fc.height - 1.0));
+}
+
+}  // namespace
+
+void build_color_table(float alpha_scale, float normalization_factor, const float scalar_range[2],
+                       const avr_colormap_point* colormap, int colormap_count, float* out_table) {
+  TransferFunction tf;
+  tf.clamp_ends = true;
+  const float range_min = scalar_range[0];
+  const float range_max = scalar_range[1];
+  const float range_span = range_max - range_min;
+
+  if (colormap != nullptr && colormap_count > 0) {
+    tf.lab = true;
+    tf.nan_color = {1.0f, 0.0f, 0.0f, 1.0f};
+    for (int i = 0; i < colormap_count; ++i) {
+      const avr_colormap_point& pt = colormap[i];
+      tf.add(ColorStop{pt.value, std::clamp(pt.red, 0.0f, 1.0f), std::clamp(pt.green, 0.0f, 1.0f),
+                       std::clamp(pt.blue, 0.0f, 1.0f)});
+      tf.add(OpacityStop{pt.value,
+                         step_corrected_alpha(pt.alpha, alpha_scale, normalization_factor), 0.5f,
+                         0.0f});
+    }
+  } else {
+    tf.lab = false;
+    tf.nan_color = {0.25f, 0.0f, 0.0f, 1.0f};
+    // default "jet" colour stops and opacity ramp (:471-487)
+    static const std::array<ColorStop, 7> kJet = {{
+        {0.0f, 0.0f, 0.0f, 0.5625f},
+        {0.111111f, 0.0f, 0.0f, 1.0f},
+        {0.3650795f, 0.0f, 1.0f, 1.0f},
+        {0.4920635f, 0.5f, 1.0f, 0.5f},
+        {0.6190475f, 1.0f, 1.0f, 0.0f},
+        {0.873016f, 1.0f, 0.0f, 0.0f},
+        {1.0f, 0.5f, 0.0f, 0.0f},
+    }};
+    for (const ColorStop& stop : kJet) tf.add(stop);
+    static const std::array<float, 6> kRampAt = {0.0f, 0.15f, 0.35f, 0.6f, 0.85f, 1.0f};
+    static const std::array<float, 6> kRampAlpha = {0.05f, 0.15f, 0.22f, 0.3f, 0.38f, 0.5f};
+    for (std::size_t i = 0; i < kRampAt.size(); ++i) {
+      tf.add(OpacityStop{kRampAt[i] * range_span + range_min,
+                         step_corrected_alpha(kRampAlpha[i], alpha_scale, normalization_factor),
+                         0.5f, 0.0f});
+    }
+    tf.rescale(range_min, range_max);
+  }
+
+  for (int i = 0; i < kTableSize; ++i) {
+    const float t = static_cast<float>(i) / static_cast<float>(kTableSize - 1);
+    const float value = range_min + range_span * t;
+    Rgba entry = tf.color_at(value);
+    entry.a = tf.opacity_at(value);
+    out_table[i * 4 + 0] = entry.r;
+    out_table[i * 4 + 1] = entry.g;
+    out_table[i * 4 + 2] = entry.b;
+    out_table[i * 4 + 3] = entry.a;
+  }
+}
+
+void box_sampling(const avr_box& box, const avr_paint_params& params, float* sample_distance,
+                  float* normalization_factor, float* alpha_scale) {
+  double spacing[3] = {0.0, 0.0, 0.0};
+  for (int axis = 0; axis < 3; ++axis) {
+    if (box.dims[axis] > 0) {
+      spacing[axis] =
+          (box.max_corner[axis] - box.min_corner[axis]) / static_cast<double>(box.dims[axis]);
+    }
+  }
+  float min_spacing = std::numeric_limits<float>::max();
+  for (int axis = 0; axis < 3; ++axis) {
+    const float value = static_cast<float>(spacing[axis]);
+    if (value > 0.0f && value < min_spacing && std::isfinite(value)) min_spacing = value;
+  }
+  if (!(min_spacing > 0.0f && std::isfinite(min_spacing))) {
+    const float fallback = static_cast<float>(std::min({params.bounds_max[0] - params.bounds_min[0],
+                                                        params.bounds_max[1] - params.bounds_min[1],
+                                                        params.bounds_max[2] - params.bounds_min[2]}));
+    min_spacing = std::max(1e-4f, fallback * 0.01f);
+  }
+  const float step = std::max(min_spacing * 0.5f, 1e-5f);
+  float reference = params.reference_sample_distance;
+  if (!(reference > 0.0f && std::isfinite(reference))) reference = step;
+  float factor = step / reference;
+  if (!std::isfinite(factor)) factor = 1.0f;
+  factor = std::max(factor, 0.0f);
+  *sample_distance = step;
+  *normalization_factor = factor;
+  *alpha_scale = std::clamp(1.0f - params.box_transparency, 0.0f, 1.0f);
+}
+
+float box_depth_hint(const avr_box& box, const avr_camera& camera) {
+  const Vec3d eye = from(camera.eye);
+  const Vec3d view = normalized_or_default(sub(from(camera.look_at), eye));
+  float nearest = std::numeric_limits<float>::infinity();
+  for (int corner = 0; corner < 8; ++corner) {
+    const Vec3d p{(corner & 1) ? box.max_corner[0] : box.min_corner[0],
+                  (corner & 2) ? box.max_corner[1] : box.min_corner[1],
+                  (corner & 4) ? box.max_corner[2] : box.min_corner[2]};
+    nearest = std::min(nearest, static_cast<float>(dot(sub(p, eye), view)));
+  }
+  return nearest;
+}
+
+float reference_sample_distance(const avr_box* boxes, int n_boxes, const double bounds_min[3],
+                                const double bounds_max[3]) {
+  float coarsest = 0.0f;
+  for (int b = 0; b < n_boxes; ++b) {
+    double spacing[3] = {0.0, 0.0, 0.0};
+    for (int axis = 0; axis < 3; ++axis) {
+      if (boxes[b].dims[axis] > 0) {
+        // the reference divides the double span by float(dim) here (VolumeRenderer.cpp:1143-1151)
+        spacing[axis] = (boxes[b].max_corner[axis] - boxes[b].min_corner[axis]) /
+                        static_cast<float>(boxes[b].dims[axis]);
+      }
+    }
+    float min_spacing = std::numeric_limits<float>::max();
+    for (int axis = 0; axis < 3; ++axis) {
+      if (spacing[axis] > 0.0f && spacing[axis] < min_spacing && std::isfinite(spacing[axis])) {
+        min_spacing = static_cast<float>(spacing[axis]);
+      }
+    }
+    if (min_spacing > 0.0f && std::isfinite(min_spacing)) coarsest = std::max(coarsest, min_spacing);
+  }
+  if (!(coarsest > 0.0f && std::isfinite(coarsest))) {
+    float fallback = std::numeric_limits<float>::max();
+    for (int axis = 0; axis < 3; ++axis) {
+      const float length = static_cast<float>(bounds_max[axis] - bounds_min[axis]);
+      if (length > 0.0f && std::isfinite(length)) fallback = std::min(fallback, length);
+    }
+    if (!(fallback > 0.0f && std::isfinite(fallback))) fallback = 1.0f;
+    coarsest = std::max(1e-4f, fallback * 0.01f);
+  }
+  return std::max(coarsest * 0.5f, 1e-5f);
+}
+
+int layer_order(const float* hints, const int32_t* owner, const int32_t* local_index, int n_layers,
+                int32_t* order_out, int32_t* run_end_out) {
+  std::vector<int32_t> ids(static_cast<std::size_t>(std::max(n_layers, 0)));
+  for (int i = 0; i < n_layers; ++i) ids[static_cast<std::size_t>(i)] = i;
+  // (depth, owningRank, localIndex) is a strict total order over distinct layers
+  // (DirectSendBase.cpp:378-388), so the sort result does not depend on the algorithm.
+  std::sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b) {
+    if (hints[a] == hints[b]) {
+      if (owner[a] == owner[b]) return local_index[a] < local_index[b];
+      return owner[a] < owner[b];
+    }
+    return hints[a] < hints[b];
+  });
+  int runs = 0;
+  int i = 0;
+  while (i < n_layers) {
+    const int32_t run_owner = owner[ids[static_cast<std::size_t>(i)]];
+    while (i < n_layers && owner[ids[static_cast<std::size_t>(i)]] == run_owner) ++i;
+    run_end_out[runs++] = i;
+  }
+  for (int k = 0; k < n_layers; ++k) order_out[k] = ids[static_cast<std::size_t>(k)];
+  return runs;
+}
+
+void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
+                const avr_paint_params& params, const avr_camera& camera, FramePlan* plan) {
+  if (params.width <= 0 || params.height <= 0) {
+    throw std::invalid_argument("image width and height must be positive");
+  }
+  if (n_boxes < 0 || (n_boxes > 0 && boxes == nullptr)) {
+    throw std::invalid_argument("invalid box list");
+  }
+  if (static_cast<int64_t>(params.width) * params.height > (int64_t{1} << 31) - 1) {
+    throw std::invalid_argument("image has more than 2^31-1 pixels");
+  }
+
+  FrameConsts& fc = plan->consts;
+  std::memset(&fc, 0, sizeof(fc));
+  fc.width = params.width;
+  fc.height = params.height;
+  fc.aspect = static_cast<float>(params.width) / static_cast<float>(std::max(params.height, 1));
+  fc.tan_half_fov = std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f);
+  fc.inv_width = 1.0f / static_cast<float>(params.width);
+  fc.inv_height = 1.0f / static_cast<float>(params.height);
+
+  const CameraBasis basis = camera_basis(camera);
+  fc.fwd[0] = static_cast<float>(basis.forward.x);
+  fc.fwd[1] = static_cast<float>(basis.forward.y);
+  fc.fwd[2] = static_cast<float>(basis.forward.z);
+  fc.right[0] = static_cast<float>(basis.right.x);
+  fc.right[1] = static_cast<float>(basis.right.y);
+  fc.right[2] = static_cast<float>(basis.right.z);
+  fc.up[0] = static_cast<float>(basis.up.x);
+  fc.up[1] = static_cast<float>(basis.up.y);
+  fc.up[2] = static_cast<float>(basis.up.z);
+  for (int axis = 0; axis < 3; ++axis) fc.eye[axis] = static_cast<float>(camera.eye[axis]);
+
+  // scalar range -> table index mapping and soft clip (VolumePainter.cpp:717-724)
+  fc.range_min = params.scalar_range[0];
+  const float range_max = params.scalar_range[1];
+  fc.inverse_range = 1.0f;
+  if (range_max != fc.range_min) fc.inverse_range = 1.0f / (range_max - fc.range_min);
+  fc.clip_start = std::clamp(params.scalar_range[1], 0.0f, 1.0f);
+  fc.apply_clip = (1.0f > fc.clip_start + kSoftClipTolerance) ? 1 : 0;
+
+  fc.log_scale = transform.log_scale_input ? 1 : 0;
+  fc.normalize = transform.normalize_to_unit_range ? 1 : 0;
+  fc.positive_floor = transform.positive_floor;
+  fc.norm_min = transform.normalization_min;
+  fc.inv_norm_span = transform.inverse_normalization_span;
+
+  plan->boxes.assign(static_cast<std::size_t>(n_boxes), BoxDev{});
+  plan->tables.clear();
+  plan->n_tables = 0;
+  std::map<uint32_t, int> table_of_factor;  // normalization factor bits -> table slot
+
+  for (int b = 0; b < n_boxes; ++b) {
+    const avr_box& box = boxes[b];
+    BoxDev& dev = plan->boxes[static_cast<std::size_t>(b)];
+    std::memset(&dev, 0, sizeof(dev));
+
+    float step = 0.0f, factor = 0.0f, alpha_scale = 0.0f;
+    box_sampling(box, params, &step, &factor, &alpha_scale);
+    uint32_t factor_bits = 0;
+    std::memcpy(&factor_bits, &factor, sizeof(factor_bits));
+    auto found = table_of_factor.find(factor_bits);
+    if (found == table_of_factor.end()) {
+      const int slot = plan->n_tables++;
+      plan->tables.resize(static_cast<std::size_t>(plan->n_tables) * kTableSize * 4);
+      build_color_table(alpha_scale, factor, params.scalar_range, params.colormap,
+                        params.colormap_count,
+                        plan->tables.data() + static_cast<std::size_t>(slot) * kTableSize * 4);
+      found = table_of_factor.emplace(factor_bits, slot).first;
+    }
+    dev.lut = found->second;
+
+    for (int axis = 0; axis < 3; ++axis) {
+      dev.minc[axis] = static_cast<float>(box.min_corner[axis]);
+      dev.maxc[axis] = static_cast<float>(box.max_corner[axis]);
+    }
+    dev.nx = box.dims[0];
+    dev.ny = box.dims[1];
+    dev.nz = box.dims[2];
+    dev.sample_dist = step;
+    dev.cells = box.cells;
+    dev.jstride = box.jstride;
+    dev.kstride = box.kstride;
+
+    if (dev.nx <= 0 || dev.ny <= 0 || dev.nz <= 0) {
+      // the reference clears the layer (VolumePainter.cpp:670-673): never hit
+      dev.rect[0] = dev.rect[1] = 0;
+      dev.rect[2] = dev.rect[3] = -1;
+      dev.dx = dev.dy = dev.dz = 1.0f;
+      dev.inv_dx = dev.inv_dy = dev.inv_dz = 1.0f;
+      continue;
+    }
+    if (box.cells == nullptr) throw std::invalid_argument("box has no cell data");
+
+    dev.dx = (dev.maxc[0] - dev.minc[0]) / static_cast<float>(dev.nx);
+    dev.dy = (dev.maxc[1] - dev.minc[1]) / static_cast<float>(dev.ny);
+    dev.dz = (dev.maxc[2] - dev.minc[2]) / static_cast<float>(dev.nz);
+    dev.inv_dx = 1.0f / dev.dx;
+    dev.inv_dy = 1.0f / dev.dy;
+    dev.inv_dz = 1.0f / dev.dz;
+    dev.pow2_spacing =
+        (is_power_of_two(dev.dx) && is_power_of_two(dev.dy) && is_power_of_two(dev.dz)) ? 1 : 0;
+    const float ex = dev.maxc[0] - dev.minc[0];
+    const float ey = dev.maxc[1] - dev.minc[1];
+    const float ez = dev.maxc[2] - dev.minc[2];
+    dev.mesh_eps = std::sqrt(ex * ex + ey * ey + ez * ez) * 0.0001f;
+    screen_rect(box, camera, basis, fc, dev.rect);
+  }
+}
+
+}  // namespace avr

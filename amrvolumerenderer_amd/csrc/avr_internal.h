@@ -1,0 +1,96 @@
+// Internal types shared by the host prologue (avr_host.cpp), the kernels (avr_kernels.hip)
+// and the C ABI (avr_capi.cpp).  Not part of the public boundary (include/avr_hip.h).
+#ifndef AVR_INTERNAL_H
+#define AVR_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/avr_hip.h"
+
+namespace avr {
+
+constexpr int kTableSize = 256;  // kColorTableSize, Common/VolumePainter.cpp:35
+constexpr int kMaxLdsTables = 16;  // transfer-function tables staged in LDS per launch (4 KiB each)
+
+// Per-box constants of VolumePainter::paint's host prologue (Common/VolumePainter.cpp:571-692),
+// laid out for wave-uniform scalar loads (one 128-byte record per box).
+struct alignas(16) BoxDev {
+  float minc[3];
+  float maxc[3];
+  float dx, dy, dz;       // (maxCornerF - minCornerF) / float(n)   (:678-686)
+  float mesh_eps;         // 1e-4 * |diag|                          (:688-692)
+  float sample_dist;      // max(0.5 * minSpacing, 1e-5)            (:600)
+  int32_t nx, ny, nz;
+  int32_t lut;            // index of this box's transfer-function table
+  int32_t rect[4];        // conservative screen rectangle x0,y0,x1,y1 (inclusive); x1 < x0 = off-screen
+  const double* cells;    // values(validBox.smallEnd(), component)
+  int64_t jstride;
+  int64_t kstride;
+  float inv_dx, inv_dy, inv_dz;  // 1/dx.. (IEEE), exact-multiply fast path when dx is a power of two
+  int32_t pow2_spacing;   // 1 when dx, dy, dz are all powers of two (division == multiplication)
+};
+static_assert(sizeof(BoxDev) == 128, "BoxDev must stay one 128-byte record");
+
+// Frame constants (camera basis, scalar mapping); passed to kernels by value (kernarg -> SGPRs).
+struct FrameConsts {
+  int32_t width, height;
+  float aspect, tan_half_fov, inv_width, inv_height;
+  float fwd[3], right[3], up[3], eye[3];
+  float range_min, inverse_range, clip_start;
+  int32_t apply_clip;
+  int32_t log_scale, normalize;
+  double positive_floor, norm_min, inv_norm_span;
+};
+
+// Host results for one frame over a list of boxes.
+struct FramePlan {
+  FrameConsts consts;
+  std::vector<BoxDev> boxes;        // same order as the input boxes
+  std::vector<float> tables;        // n_tables * 1024 floats
+  int n_tables = 0;
+};
+
+// ---- host prologue (avr_host.cpp) ---------------------------------------------------------
+void build_color_table(float alpha_scale, float normalization_factor, const float scalar_range[2],
+                       const avr_colormap_point* colormap, int colormap_count, float* out_table);
+void box_sampling(const avr_box& box, const avr_paint_params& params, float* sample_distance,
+                  float* normalization_factor, float* alpha_scale);
+float box_depth_hint(const avr_box& box, const avr_camera& camera);
+float reference_sample_distance(const avr_box* boxes, int n_boxes, const double bounds_min[3],
+                                const double bounds_max[3]);
+int layer_order(const float* hints, const int32_t* owner, const int32_t* local_index, int n_layers,
+                int32_t* order_out, int32_t* run_end_out);
+// Fills plan for the given boxes; throws std::invalid_argument / std::runtime_error.
+void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
+                const avr_paint_params& params, const avr_camera& camera, FramePlan* plan);
+
+// ---- kernel launchers (avr_kernels.hip); all asynchronous on `stream` (hipStream_t) ---------
+struct RenderLaunch {
+  FrameConsts consts;
+  const BoxDev* boxes_dev;      // scene descriptors for this frame
+  const float* tables_dev;      // n_tables * 1024 floats
+  int n_tables;
+  const int32_t* order_dev;     // box indices in global layer order
+  const int32_t* run_end_dev;   // one-past-last position per run
+  int n_order, n_runs, n_pieces;
+  float* out_layers;
+  unsigned long long* samples_out;  // may be null
+};
+int launch_render_runs(const RenderLaunch& launch, void* stream);
+int launch_blend(int kind, const void* top, const void* bottom, void* out, int64_t n, void* stream);
+int launch_blend_regions(int kind, const void* top, int64_t tb, int64_t te, const void* bottom,
+                         int64_t bb, int64_t be, void* out, void* stream);
+int launch_encode_u8(const float* rgba, uint32_t* out, int64_t n, void* stream);
+int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream);
+int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,
+                     void* stream);
+int launch_downsample(const float* src, int tw, int th, int block, float* dst, void* stream);
+int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream);
+
+void set_error(const std::string& message);
+
+}  // namespace avr
+
+#endif

@@ -1,0 +1,719 @@
+// HIP kernels of the MI355X (gfx950 / CDNA4) volume-rendering hot path.
+//
+// Built with -ffp-contract=off: every float operation below is a single IEEE binary32
+// operation in source order, which is what the reference's CPU build executes
+// ("no FMA contraction").  Division and sqrt are the correctly rounded
+// forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+//
+// Kernels:
+//   render_runs_kernel  one thread per pixel; marches the rank's boxes in global layer order,
+//                       folds each same-owner run with the depth-sort blend in registers and
+//                       writes one layer per run in DirectSend "send layout".
+//                       (VolumePainter.cpp:735-955 + VolumeRenderer.cpp:1201-1219 +
+//                        DirectSendBase.cpp:413-426)
+//   blend_*             Features::blend of the three image types (element-wise)
+//   fold_runs_kernel    receiver-side left fold over runs (DirectSendBase.cpp:400-446)
+//   downsample / quantize / encode / decode   frame tail
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "avr_internal.h"
+
+namespace avr {
+
+namespace {
+
+constexpr int kTile = 16;            // workgroup = 16x16 pixels = 4 waves of 8x8
+constexpr int kBlockThreads = 256;
+constexpr int kSuperTileTiles = 64;  // tiles per Morton super-tile handed to one XCD (128x128 px)
+constexpr int kXcds = 8;
+
+#define AVR_INF __builtin_huge_valf()
+
+struct Layer5 {
+  float r, g, b, a, d;
+};
+
+// Morton decode of the even bits.
+__device__ __forceinline__ unsigned compact_bits(unsigned v) {
+  v &= 0x55555555u;
+  v = (v | (v >> 1)) & 0x33333333u;
+  v = (v | (v >> 2)) & 0x0f0f0f0fu;
+  v = (v | (v >> 4)) & 0x00ff00ffu;
+  v = (v | (v >> 8)) & 0x0000ffffu;
+  return v;
+}
+
+// applyScalarTransform (Common/VolumeTypes.hpp:33-67), double arithmetic.
+__device__ __forceinline__ float apply_scalar_transform(double raw, const FrameConsts& fc) {
+  double v = __builtin_isfinite(raw) ? raw : 0.0;
+  if (fc.log_scale) {
+    if (!(v > 0.0)) {
+      v = fc.positive_floor;
+    } else if (v < fc.positive_floor) {
+      v = fc.positive_floor;
+    }
+    v = log(v);
+  }
+  if (fc.normalize) {
+    v = (v - fc.norm_min) * fc.inv_norm_span;
+    if (v < 0.0) {
+      v = 0.0;
+    } else if (v > 1.0) {
+      v = 1.0;
+    }
+  }
+  return static_cast<float>(v);
+}
+
+// saturateSoftTail (Common/VolumePainter.cpp:75-105) with rolloffEnd = 1.
+__device__ __forceinline__ float saturate_soft_tail(float value, float clip_start) {
+  const float clamped_end = (clip_start < 1.0f) ? 1.0f : clip_start;
+  float cv = value;
+  if (cv < 0.0f) {
+    cv = 0.0f;
+  } else if (cv > clamped_end) {
+    cv = clamped_end;
+  }
+  if (!(clamped_end > clip_start + 1e-5f)) return cv;
+  if (!(cv > clip_start)) return cv;
+  if (!(cv < clamped_end)) return clamped_end;
+  const float n = (cv - clip_start) / (clamped_end - clip_start);
+  const float smooth = n + n * n - n * n * n;
+  return clip_start + (clamped_end - clip_start) * smooth;
+}
+
+// Features::blend of ImageRGBAFloatColorDepthSort (ImageRGBAFloatColorDepthSort.hpp:13-27).
+__device__ __forceinline__ Layer5 blend_depthsort(const Layer5& top, const Layer5& bottom) {
+  const bool top_is_front = top.d <= bottom.d;
+  const Layer5 front = top_is_front ? top : bottom;
+  const Layer5 back = top_is_front ? bottom : top;
+  const float t = 1.0f - front.a;
+  Layer5 out;
+  out.r = front.r + back.r * t;
+  out.g = front.g + back.g * t;
+  out.b = front.b + back.b * t;
+  out.a = front.a + back.a * t;
+  out.d = (bottom.d < top.d) ? bottom.d : top.d;  // std::min(topDepth, bottomDepth)
+  return out;
+}
+
+struct Ray {
+  float ox, oy, oz;
+  float dx, dy, dz;
+};
+
+// Ray of pixel (px, py): VolumePainter.cpp:741-766.
+__device__ __forceinline__ Ray make_ray(int px, int py, const FrameConsts& fc) {
+  const float ndc_x = (static_cast<float>(px) + 0.5f) * fc.inv_width * 2.0f - 1.0f;
+  const float ndc_y = (static_cast<float>(py) + 0.5f) * fc.inv_height * 2.0f - 1.0f;
+  const float plane_x = ndc_x * fc.tan_half_fov * fc.aspect;
+  const float plane_y = ndc_y * fc.tan_half_fov;
+  Ray ray;
+  ray.dx = fc.fwd[0] + plane_x * fc.right[0] + plane_y * fc.up[0];
+  ray.dy = fc.fwd[1] + plane_x * fc.right[1] + plane_y * fc.up[1];
+  ray.dz = fc.fwd[2] + plane_x * fc.right[2] + plane_y * fc.up[2];
+  const float len_sq = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+  // host amrex::Math::rsqrt(x) is 1/sqrt(x): length = 1 / (1 / sqrt)
+  const float len = (len_sq > 0.0f) ? (1.0f / (1.0f / sqrtf(len_sq))) : 0.0f;
+  if (len > 0.0f) {
+    const float inv = 1.0f / len;
+    ray.dx *= inv;
+    ray.dy *= inv;
+    ray.dz *= inv;
+  }
+  ray.ox = fc.eye[0];
+  ray.oy = fc.eye[1];
+  ray.oz = fc.eye[2];
+  return ray;
+}
+
+// One axis of the slab test (updateBounds, VolumePainter.cpp:775-796).  inv_dir = 1/direction
+// is the same value for every box, so it is computed once per pixel.
+__device__ __forceinline__ void slab_axis(float origin, float direction, float inv_dir,
+                                          float min_val, float max_val, float& tmin,
+                                          float& tmax) {
+  if (fabsf(direction) < 1e-8f) {
+    if (origin < min_val || origin > max_val) {
+      tmin = AVR_INF;
+      tmax = -AVR_INF;
+    }
+    return;
+  }
+  float t1 = (min_val - origin) * inv_dir;
+  float t2 = (max_val - origin) * inv_dir;
+  if (t1 > t2) {
+    const float tmp = t1;
+    t1 = t2;
+    t2 = tmp;
+  }
+  tmin = (tmin > t1) ? tmin : t1;
+  tmax = (tmax < t2) ? tmax : t2;
+}
+
+// The march of one ray through one box (VolumePainter.cpp:811-921 + host epilogue :939-955).
+// Returns the layer pixel the reference would store for this box.
+template <bool STATS>
+__device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts& fc,
+                                            const float4* __restrict__ table, const Ray& ray,
+                                            float tmin, float tmax, unsigned& fetches) {
+  const float min_x = box.minc[0], min_y = box.minc[1], min_z = box.minc[2];
+  const float max_x = box.maxc[0], max_y = box.maxc[1], max_z = box.maxc[2];
+  const float step = box.sample_dist;
+  const double* __restrict__ cells = box.cells;
+  const int64_t jstride = box.jstride;
+  const int64_t kstride = box.kstride;
+  const int nx = box.nx, ny = box.ny, nz = box.nz;
+
+  float distance = tmin + box.mesh_eps;
+  if (distance < 0.0f) distance = box.mesh_eps;
+
+  float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
+
+  float pos_x = ray.ox + ray.dx * distance;
+  float pos_y = ray.oy + ray.dy * distance;
+  float pos_z = ray.oz + ray.dz * distance;
+
+  // The reference's skip loop (:830-835) and the "continue" branch of the main loop (:838-844)
+  // do the same thing -- advance without sampling while the position is outside -- so one loop
+  // with an inside test reproduces both.
+  while (distance < tmax && acc_a < 1.0f) {
+    const bool inside = !(pos_x < min_x || pos_x > max_x || pos_y < min_y || pos_y > max_y ||
+                          pos_z < min_z || pos_z > max_z);
+    if (inside) {
+      const float fx = (pos_x - min_x) / box.dx;
+      const float fy = (pos_y - min_y) / box.dy;
+      const float fz = (pos_z - min_z) / box.dz;
+      int i = static_cast<int>(floorf(fx));
+      int j = static_cast<int>(floorf(fy));
+      int k = static_cast<int>(floorf(fz));
+      i = (i < 0) ? 0 : ((i >= nx) ? nx - 1 : i);
+      j = (j < 0) ? 0 : ((j >= ny) ? ny - 1 : j);
+      k = (k < 0) ? 0 : ((k >= nz) ? nz - 1 : k);
+
+      const double raw = cells[static_cast<int64_t>(i) + static_cast<int64_t>(j) * jstride +
+                               static_cast<int64_t>(k) * kstride];
+      if (STATS) ++fetches;
+      float scalar = apply_scalar_transform(raw, fc);
+      if (fc.apply_clip) scalar = saturate_soft_tail(scalar, fc.clip_start);
+      float normalized = (scalar - fc.range_min) * fc.inverse_range;
+      normalized = (normalized < 0.0f) ? 0.0f : normalized;
+      normalized = (normalized > 1.0f) ? 1.0f : normalized;
+      int idx = static_cast<int>(normalized * 255.0f);
+      idx = (idx < 0) ? 0 : idx;
+      idx = (idx > kTableSize - 1) ? (kTableSize - 1) : idx;
+      const float4 sample = table[idx];
+      const float alpha = sample.w * (1.0f - acc_a);
+      acc_r += sample.x * alpha;
+      acc_g += sample.y * alpha;
+      acc_b += sample.z * alpha;
+      acc_a += alpha;
+    }
+    distance += step;
+    pos_x = ray.ox + ray.dx * distance;
+    pos_y = ray.oy + ray.dy * distance;
+    pos_z = ray.oz + ray.dz * distance;
+  }
+
+  // device-side clamp (:902-905) then the host epilogue's std::clamp to [0,1] (:944-947)
+  acc_r = (acc_r > 1.0f) ? 1.0f : acc_r;
+  acc_g = (acc_g > 1.0f) ? 1.0f : acc_g;
+  acc_b = (acc_b > 1.0f) ? 1.0f : acc_b;
+  acc_a = (acc_a > 1.0f) ? 1.0f : acc_a;
+  Layer5 out;
+  out.r = (acc_r < 0.0f) ? 0.0f : acc_r;
+  out.g = (acc_g < 0.0f) ? 0.0f : acc_g;
+  out.b = (acc_b < 0.0f) ? 0.0f : acc_b;
+  out.a = (acc_a < 0.0f) ? 0.0f : acc_a;
+
+  float depth = AVR_INF;
+  if (acc_a > 0.0f) {  // entry depth along the view axis (:912-920)
+    const float ex = ray.ox + ray.dx * tmin;
+    const float ey = ray.oy + ray.dy * tmin;
+    const float ez = ray.oz + ray.dz * tmin;
+    depth = (ex - fc.eye[0]) * fc.fwd[0] + (ey - fc.eye[1]) * fc.fwd[1] +
+            (ez - fc.eye[2]) * fc.fwd[2];
+  }
+  if (!__builtin_isfinite(depth) || out.a <= 0.0f) depth = AVR_INF;  // (:950-952)
+  out.d = depth;
+  return out;
+}
+
+// Address of pixel p of run r in send layout (see avr_render_runs in include/avr_hip.h).
+__device__ __forceinline__ int64_t send_offset(int64_t p, int run, int n_runs, int64_t n_pixels,
+                                               int n_pieces) {
+  if (n_pieces <= 1) return (static_cast<int64_t>(run) * n_pixels + p) * 5;
+  const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
+  int64_t piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
+  if (piece > n_pieces - 1) piece = n_pieces - 1;
+  const int64_t begin = piece * piece_size;
+  const int64_t len = (piece < n_pieces - 1) ? piece_size : (n_pixels - begin);
+  return (static_cast<int64_t>(n_runs) * begin + static_cast<int64_t>(run) * len + (p - begin)) * 5;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
+    const FrameConsts fc, const BoxDev* __restrict__ boxes, const float* __restrict__ tables,
+    const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
+    const int n_runs, const int n_pieces, const int tiles_x, const int tiles_y,
+    const unsigned padded_tiles, float* __restrict__ out, unsigned long long* samples_out) {
+  extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
+
+  // ---- stage the transfer-function tables in LDS (one per AMR sampling level) -------------
+  {
+    const float4* src = reinterpret_cast<const float4*>(tables);
+    const int total = n_tables * kTableSize;
+    for (int e = threadIdx.x; e < total; e += kBlockThreads) lds_tables[e] = src[e];
+  }
+  __syncthreads();
+
+  // ---- XCD-aware tile assignment ------------------------------------------------------------
+  // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Hand every XCD
+  // whole Morton-ordered super-tiles so that the workgroups resident on one XCD at a time cover
+  // a compact patch of the screen and re-use the same bricks from that XCD's L2.
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b % kXcds;
+  const unsigned within = b / kXcds;
+  const unsigned seq =
+      ((within / kSuperTileTiles) * kXcds + xcd) * kSuperTileTiles + (within % kSuperTileTiles);
+  if (seq >= padded_tiles) return;
+  const int tile_x = static_cast<int>(compact_bits(seq));
+  const int tile_y = static_cast<int>(compact_bits(seq >> 1));
+  if (tile_x >= tiles_x || tile_y >= tiles_y) return;
+
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+  const int lane = static_cast<int>(threadIdx.x) & 63;
+  const int wave_x0 = tile_x * kTile + (wave & 1) * 8;  // wave-uniform 8x8 sub-tile
+  const int wave_y0 = tile_y * kTile + (wave >> 1) * 8;
+  const int px = wave_x0 + (lane & 7);
+  const int py = wave_y0 + (lane >> 3);
+  const bool live = (px < fc.width) && (py < fc.height);
+  const int64_t n_pixels = static_cast<int64_t>(fc.width) * fc.height;
+  const int64_t p = static_cast<int64_t>(py) * fc.width + px;
+
+  const Ray ray = make_ray(px, py, fc);
+  const float inv_dx = 1.0f / ray.dx;  // as updateBounds computes it per box (:786)
+  const float inv_dy = 1.0f / ray.dy;
+  const float inv_dz = 1.0f / ray.dz;
+
+  unsigned fetches = 0;
+  int position = 0;
+  for (int run = 0; run < n_runs; ++run) {
+    const int end = run_end[run];
+    Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};  // cleared layer pixel: exact blend identity
+    for (; position < end; ++position) {
+      const BoxDev& box = boxes[order[position]];
+      // wave-uniform cull against the box's conservative screen rectangle
+      if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + 7 || box.rect[3] < wave_y0 ||
+          box.rect[1] > wave_y0 + 7) {
+        continue;
+      }
+      float tmin = -AVR_INF;
+      float tmax = AVR_INF;
+      slab_axis(ray.ox, ray.dx, inv_dx, box.minc[0], box.maxc[0], tmin, tmax);
+      slab_axis(ray.oy, ray.dy, inv_dy, box.minc[1], box.maxc[1], tmin, tmax);
+      slab_axis(ray.oz, ray.dz, inv_dz, box.minc[2], box.maxc[2], tmin, tmax);
+      bool hit = live && (tmax >= tmin);
+      if (hit && acc.a == 1.0f) {
+        // The run accumulator is opaque: if it is also in front of this box's entry point the
+        // blend returns the accumulator unchanged (front + back * (1 - 1)), whatever the box
+        // holds, so the march is skipped without changing bits.
+        const float ex = ray.ox + ray.dx * tmin;
+        const float ey = ray.oy + ray.dy * tmin;
+        const float ez = ray.oz + ray.dz * tmin;
+        const float entry_depth = (ex - fc.eye[0]) * fc.fwd[0] + (ey - fc.eye[1]) * fc.fwd[1] +
+                                  (ez - fc.eye[2]) * fc.fwd[2];
+        if (acc.d <= entry_depth) hit = false;
+      }
+      if (!__builtin_amdgcn_ballot_w64(hit)) continue;  // whole wave missed or terminated
+      if (hit) {
+        const Layer5 layer = march_box<STATS>(box, fc, lds_tables + box.lut * kTableSize, ray,
+                                              tmin, tmax, fetches);
+        acc = blend_depthsort(acc, layer);
+      }
+    }
+    if (live) {
+      float* dst = out + send_offset(p, run, n_runs, n_pixels, n_pieces);
+      dst[0] = acc.r;
+      dst[1] = acc.g;
+      dst[2] = acc.b;
+      dst[3] = acc.a;
+      dst[4] = acc.d;
+    }
+  }
+
+  if (STATS && samples_out != nullptr) {
+    unsigned long long total = fetches;
+    for (int offset = 32; offset > 0; offset >>= 1) {
+      total += __shfl_down(total, offset, 64);
+    }
+    if (lane == 0 && total != 0) atomicAdd(samples_out, total);
+  }
+}
+
+// ---- element-wise image algebra ------------------------------------------------------------
+
+__global__ void blend_depthsort_kernel(const float* __restrict__ top,
+                                       const float* __restrict__ bottom, float* __restrict__ out,
+                                       int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
+       p += stride) {
+    const float* t = top + p * 5;
+    const float* b = bottom + p * 5;
+    const Layer5 tl = {t[0], t[1], t[2], t[3], t[4]};
+    const Layer5 bl = {b[0], b[1], b[2], b[3], b[4]};
+    const Layer5 o = blend_depthsort(tl, bl);
+    float* d = out + p * 5;
+    d[0] = o.r;
+    d[1] = o.g;
+    d[2] = o.b;
+    d[3] = o.a;
+    d[4] = o.d;
+  }
+}
+
+// ImageRGBAFloatColorOnlyFeatures::blend (ImageRGBAFloatColorOnly.hpp:19-26)
+__device__ __forceinline__ float4 blend_rgba_f32(const float4 top, const float4 bottom) {
+  const float t = 1.0f - top.w;
+  float4 o;
+  o.x = top.x + bottom.x * t;
+  o.y = top.y + bottom.y * t;
+  o.z = top.z + bottom.z * t;
+  o.w = top.w + bottom.w * t;
+  return o;
+}
+
+__global__ void blend_rgba_f32_kernel(const float4* __restrict__ top,
+                                      const float4* __restrict__ bottom, float4* __restrict__ out,
+                                      int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
+       p += stride) {
+    out[p] = blend_rgba_f32(top[p], bottom[p]);
+  }
+}
+
+// ImageRGBAUByteColorOnlyFeatures::blend (ImageRGBAUByteColorOnly.hpp:19-34): the bottom
+// component is scaled in float, truncated to uint8, and the uint8 sum wraps (no saturation).
+__device__ __forceinline__ uint32_t blend_rgba_u8(uint32_t top, uint32_t bottom) {
+  const float bottom_scale = 1.0f - static_cast<float>(top >> 24) / 255.0f;
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t tc = (top >> (8 * c)) & 0xffu;
+    const uint32_t bc = (bottom >> (8 * c)) & 0xffu;
+    const uint32_t scaled =
+        static_cast<uint32_t>(static_cast<int>(static_cast<float>(bc) * bottom_scale)) & 0xffu;
+    out |= ((tc + scaled) & 0xffu) << (8 * c);
+  }
+  return out;
+}
+
+__global__ void blend_rgba_u8_kernel(const uint32_t* __restrict__ top,
+                                     const uint32_t* __restrict__ bottom,
+                                     uint32_t* __restrict__ out, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
+       p += stride) {
+    out[p] = blend_rgba_u8(top[p], bottom[p]);
+  }
+}
+
+// ImageColorOnly<F>::blend with regions (Common/ImageColorOnly.hpp:119-199).  One thread per
+// output pixel q in [min(tb,bb), max(te,be)): copy where only one image covers q, blend where
+// both do.  KIND: 0 depth-sort, 1 float, 2 ubyte.
+template <int KIND>
+__global__ void blend_regions_kernel(const void* __restrict__ top_v, int64_t tb, int64_t te,
+                                     const void* __restrict__ bottom_v, int64_t bb, int64_t be,
+                                     void* __restrict__ out_v) {
+  const int64_t ob = (tb < bb) ? tb : bb;
+  const int64_t oe = (te > be) ? te : be;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t q = ob + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < oe;
+       q += stride) {
+    const bool in_top = (q >= tb) && (q < te);
+    const bool in_bottom = (q >= bb) && (q < be);
+    if (KIND == 0) {
+      const float* t = static_cast<const float*>(top_v) + (q - tb) * 5;
+      const float* b = static_cast<const float*>(bottom_v) + (q - bb) * 5;
+      float* d = static_cast<float*>(out_v) + (q - ob) * 5;
+      Layer5 o;
+      if (in_top && in_bottom) {
+        const Layer5 tl = {t[0], t[1], t[2], t[3], t[4]};
+        const Layer5 bl = {b[0], b[1], b[2], b[3], b[4]};
+        o = blend_depthsort(tl, bl);
+      } else if (in_top) {
+        o = {t[0], t[1], t[2], t[3], t[4]};
+      } else if (in_bottom) {
+        o = {b[0], b[1], b[2], b[3], b[4]};
+      } else {
+        continue;
+      }
+      d[0] = o.r;
+      d[1] = o.g;
+      d[2] = o.b;
+      d[3] = o.a;
+      d[4] = o.d;
+    } else if (KIND == 1) {
+      const float4* t = static_cast<const float4*>(top_v) + (q - tb);
+      const float4* b = static_cast<const float4*>(bottom_v) + (q - bb);
+      float4* d = static_cast<float4*>(out_v) + (q - ob);
+      if (in_top && in_bottom) {
+        *d = blend_rgba_f32(*t, *b);
+      } else if (in_top) {
+        *d = *t;
+      } else if (in_bottom) {
+        *d = *b;
+      }
+    } else {
+      const uint32_t* t = static_cast<const uint32_t*>(top_v) + (q - tb);
+      const uint32_t* b = static_cast<const uint32_t*>(bottom_v) + (q - bb);
+      uint32_t* d = static_cast<uint32_t*>(out_v) + (q - ob);
+      if (in_top && in_bottom) {
+        *d = blend_rgba_u8(*t, *b);
+      } else if (in_top) {
+        *d = *t;
+      } else if (in_bottom) {
+        *d = *b;
+      }
+    }
+  }
+}
+
+// Color::GetComponentAsByte (Common/Color.hpp:86-90)
+__device__ __forceinline__ uint32_t component_as_byte(float c) {
+  const int tv = static_cast<int>(c * 256.f);
+  return static_cast<uint32_t>((tv < 0) ? 0 : (tv > 255) ? 255 : tv);
+}
+
+__global__ void encode_u8_kernel(const float4* __restrict__ rgba, uint32_t* __restrict__ out,
+                                 int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
+       p += stride) {
+    const float4 c = rgba[p];
+    out[p] = component_as_byte(c.x) | (component_as_byte(c.y) << 8) |
+             (component_as_byte(c.z) << 16) | (component_as_byte(c.w) << 24);
+  }
+}
+
+// Color::SetComponentFromByte (Common/Color.hpp:69-77)
+__global__ void decode_u8_kernel(const uint32_t* __restrict__ in, float4* __restrict__ rgba,
+                                 int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
+       p += stride) {
+    const uint32_t e = in[p];
+    float4 c;
+    c.x = static_cast<float>(e & 0xffu) / 255.f;
+    c.y = static_cast<float>((e >> 8) & 0xffu) / 255.f;
+    c.z = static_cast<float>((e >> 16) & 0xffu) / 255.f;
+    c.w = static_cast<float>(e >> 24) / 255.f;
+    rgba[p] = c;
+  }
+}
+
+// Receiver-side fold over runs in global order (DirectSendBase.cpp:441-445): the first run's
+// slice is taken as is, every further slice is blended underneath.
+__global__ void fold_runs_kernel(const float* const* __restrict__ slices, int n_slices,
+                                 float* __restrict__ out, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
+       p += stride) {
+    Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};
+    for (int s = 0; s < n_slices; ++s) {
+      const float* src = slices[s] + p * 5;
+      const Layer5 layer = {src[0], src[1], src[2], src[3], src[4]};
+      acc = (s == 0) ? layer : blend_depthsort(acc, layer);
+    }
+    float* d = out + p * 5;
+    d[0] = acc.r;
+    d[1] = acc.g;
+    d[2] = acc.b;
+    d[3] = acc.a;
+    d[4] = acc.d;
+  }
+}
+
+// downsampleImage (VolumeRenderer.cpp:479-528): sums in dy-major, dx-minor order.
+__global__ void downsample_kernel(const float* __restrict__ src, int tw, int th, int block,
+                                  float* __restrict__ dst) {
+  const int64_t n = static_cast<int64_t>(tw) * th;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int src_w = tw * block;
+  const float inv_samples = 1.0f / static_cast<float>(block * block);
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
+       q += stride) {
+    const int x = static_cast<int>(q % tw);
+    const int y = static_cast<int>(q / tw);
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f, sa = 0.0f;
+    for (int dy = 0; dy < block; ++dy) {
+      const float* row = src + (static_cast<int64_t>(y * block + dy) * src_w + x * block) * 5;
+      for (int dx = 0; dx < block; ++dx) {
+        sr += row[dx * 5 + 0];
+        sg += row[dx * 5 + 1];
+        sb += row[dx * 5 + 2];
+        sa += row[dx * 5 + 3];
+      }
+    }
+    float* d = dst + q * 5;
+    d[0] = sr * inv_samples;
+    d[1] = sg * inv_samples;
+    d[2] = sb * inv_samples;
+    d[3] = sa * inv_samples;
+    d[4] = AVR_INF;
+  }
+}
+
+// SavePPM pixel bytes (SavePPM.cpp:17-36): RGB8, output rows top-down.
+__global__ void quantize_kernel(const float* __restrict__ src, int w, int h, int stride_f,
+                                uint8_t* __restrict__ dst) {
+  const int64_t n = static_cast<int64_t>(w) * h;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
+       q += stride) {
+    const int x = static_cast<int>(q % w);
+    const int out_row = static_cast<int>(q / w);
+    const int y = h - 1 - out_row;
+    const float* s = src + (static_cast<int64_t>(y) * w + x) * stride_f;
+    uint8_t* d = dst + q * 3;
+    d[0] = static_cast<uint8_t>(component_as_byte(s[0]));
+    d[1] = static_cast<uint8_t>(component_as_byte(s[1]));
+    d[2] = static_cast<uint8_t>(component_as_byte(s[2]));
+  }
+}
+
+int grid_for(int64_t n, int block) {
+  int64_t blocks = (n + block - 1) / block;
+  const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride the rest
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return static_cast<int>(blocks);
+}
+
+int check_launch(const char* what) {
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_error(std::string(what) + ": " + hipGetErrorString(err));
+    return AVR_ERR_RUNTIME;
+  }
+  return AVR_OK;
+}
+
+unsigned next_pow2(unsigned v) {
+  unsigned p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+int launch_render_runs(const RenderLaunch& L, void* stream_v) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int tiles_x = (L.consts.width + kTile - 1) / kTile;
+  const int tiles_y = (L.consts.height + kTile - 1) / kTile;
+  const unsigned side = next_pow2(static_cast<unsigned>(tiles_x > tiles_y ? tiles_x : tiles_y));
+  unsigned padded = side * side;  // Morton range covering the tile grid
+  // round up to whole (super-tile x XCD) groups so every sequence number has a block
+  const unsigned group = kSuperTileTiles * kXcds;
+  const unsigned blocks = ((padded + group - 1) / group) * group;
+  const size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
+  if (L.samples_out != nullptr) {
+    hipLaunchKernelGGL(render_runs_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
+                       stream, L.consts, L.boxes_dev, L.tables_dev, L.n_tables, L.order_dev,
+                       L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded, L.out_layers,
+                       L.samples_out);
+  } else {
+    hipLaunchKernelGGL(render_runs_kernel<false>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
+                       stream, L.consts, L.boxes_dev, L.tables_dev, L.n_tables, L.order_dev,
+                       L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded, L.out_layers,
+                       L.samples_out);
+  }
+  return check_launch("render_runs_kernel");
+}
+
+int launch_blend(int kind, const void* top, const void* bottom, void* out, int64_t n,
+                 void* stream_v) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (n <= 0) return AVR_OK;
+  const int grid = grid_for(n, 256);
+  if (kind == 0) {
+    hipLaunchKernelGGL(blend_depthsort_kernel, dim3(grid), dim3(256), 0, stream,
+                       static_cast<const float*>(top), static_cast<const float*>(bottom),
+                       static_cast<float*>(out), n);
+  } else if (kind == 1) {
+    hipLaunchKernelGGL(blend_rgba_f32_kernel, dim3(grid), dim3(256), 0, stream,
+                       static_cast<const float4*>(top), static_cast<const float4*>(bottom),
+                       static_cast<float4*>(out), n);
+  } else {
+    hipLaunchKernelGGL(blend_rgba_u8_kernel, dim3(grid), dim3(256), 0, stream,
+                       static_cast<const uint32_t*>(top), static_cast<const uint32_t*>(bottom),
+                       static_cast<uint32_t*>(out), n);
+  }
+  return check_launch("blend kernel");
+}
+
+int launch_blend_regions(int kind, const void* top, int64_t tb, int64_t te, const void* bottom,
+                         int64_t bb, int64_t be, void* out, void* stream_v) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const int64_t ob = tb < bb ? tb : bb;
+  const int64_t oe = te > be ? te : be;
+  const int64_t n = oe - ob;
+  if (n <= 0) return AVR_OK;
+  const int grid = grid_for(n, 256);
+  if (kind == 0) {
+    hipLaunchKernelGGL(blend_regions_kernel<0>, dim3(grid), dim3(256), 0, stream, top, tb, te,
+                       bottom, bb, be, out);
+  } else if (kind == 1) {
+    hipLaunchKernelGGL(blend_regions_kernel<1>, dim3(grid), dim3(256), 0, stream, top, tb, te,
+                       bottom, bb, be, out);
+  } else {
+    hipLaunchKernelGGL(blend_regions_kernel<2>, dim3(grid), dim3(256), 0, stream, top, tb, te,
+                       bottom, bb, be, out);
+  }
+  return check_launch("blend_regions_kernel");
+}
+
+int launch_encode_u8(const float* rgba, uint32_t* out, int64_t n, void* stream_v) {
+  if (n <= 0) return AVR_OK;
+  hipLaunchKernelGGL(encode_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_v), reinterpret_cast<const float4*>(rgba), out,
+                     n);
+  return check_launch("encode_u8_kernel");
+}
+
+int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream_v) {
+  if (n <= 0) return AVR_OK;
+  hipLaunchKernelGGL(decode_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_v), in, reinterpret_cast<float4*>(rgba), n);
+  return check_launch("decode_u8_kernel");
+}
+
+int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,
+                     void* stream_v) {
+  if (n <= 0) return AVR_OK;
+  hipLaunchKernelGGL(fold_runs_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_v), slices_dev, n_slices, out, n);
+  return check_launch("fold_runs_kernel");
+}
+
+int launch_downsample(const float* src, int tw, int th, int block, float* dst, void* stream_v) {
+  const int64_t n = static_cast<int64_t>(tw) * th;
+  if (n <= 0) return AVR_OK;
+  hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_v), src, tw, th, block, dst);
+  return check_launch("downsample_kernel");
+}
+
+int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream_v) {
+  const int64_t n = static_cast<int64_t>(w) * h;
+  if (n <= 0) return AVR_OK;
+  hipLaunchKernelGGL(quantize_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_v), src, w, h, stride, dst);
+  return check_launch("quantize_kernel");
+}
+
+}  // namespace avr

@@ -1,0 +1,326 @@
+"""Context (one per rank = per GPU) and thin tensor-level wrappers over the C ABI.
+
+PyTorch is plumbing here: it owns device memory (HBM tensors) and the HIP stream; every
+computation goes through libavr_hip.so.  Host-only helpers (colour table, sampling constants,
+depth hints, layer order, piece ranges) work without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+from .types import AmrBox, CameraParameters, ScalarTransform
+
+INF = float("inf")
+
+
+# ---------------------------------------------------------------------------------------------
+# host-only helpers
+# ---------------------------------------------------------------------------------------------
+
+def build_color_table(alpha_scale: float, normalization_factor: float,
+                      scalar_range=(0.0, 1.0), color_map=None) -> np.ndarray:
+    """buildColorTable (Common/VolumePainter.cpp:442-516) -> [256, 4] float32."""
+    from .types import colormap_to_c
+    out = np.empty(1024, dtype=np.float32)
+    rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))
+    arr, n = colormap_to_c(color_map)
+    _capi.check(_capi.lib().avr_build_color_table(
+        float(alpha_scale), float(normalization_factor), rng,
+        C.cast(arr, C.POINTER(_capi.ColormapPoint)) if n else None, n,
+        out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out.reshape(256, 4)
+
+
+def box_sampling(box: AmrBox, params: _capi.PaintParams) -> Tuple[float, float, float]:
+    """(sampleDistance, normalizationFactor, alphaScale), VolumePainter.cpp:571-613."""
+    sd, nf, als = C.c_float(), C.c_float(), C.c_float()
+    cbox = box.to_c()
+    _capi.check(_capi.lib().avr_box_sampling(C.byref(cbox), C.byref(params), C.byref(sd),
+                                             C.byref(nf), C.byref(als)))
+    return sd.value, nf.value, als.value
+
+
+def box_depth_hint(box: AmrBox, camera: CameraParameters) -> float:
+    """computeBoxDepthHint (VolumeRenderer/VolumeRenderer.cpp:541-553)."""
+    out = C.c_float()
+    cbox, ccam = box.to_c(), camera.to_c()
+    _capi.check(_capi.lib().avr_box_depth_hint(C.byref(cbox), C.byref(ccam), C.byref(out)))
+    return out.value
+
+
+def reference_sample_distance(boxes: Sequence[AmrBox], bounds_min, bounds_max) -> float:
+    """VolumeRenderer/VolumeRenderer.cpp:1138-1190 over the given boxes."""
+    arr = (_capi.Box * max(len(boxes), 1))(*[b.to_c() for b in boxes])
+    bmin = (C.c_double * 3)(*map(float, bounds_min))
+    bmax = (C.c_double * 3)(*map(float, bounds_max))
+    out = C.c_float()
+    _capi.check(_capi.lib().avr_reference_sample_distance(arr, len(boxes), bmin, bmax,
+                                                          C.byref(out)))
+    return out.value
+
+
+def layer_order(hints, owner, local_index) -> Tuple[np.ndarray, np.ndarray]:
+    """Global layer order and run ends (DirectSend/Base/DirectSendBase.cpp:363-410)."""
+    hints = np.ascontiguousarray(hints, dtype=np.float32)
+    owner = np.ascontiguousarray(owner, dtype=np.int32)
+    local_index = np.ascontiguousarray(local_index, dtype=np.int32)
+    n = int(hints.size)
+    order = np.empty(max(n, 1), dtype=np.int32)
+    run_end = np.empty(max(n, 1), dtype=np.int32)
+    n_runs = C.c_int()
+    ip = C.POINTER(C.c_int32)
+    _capi.check(_capi.lib().avr_layer_order(
+        hints.ctypes.data_as(C.POINTER(C.c_float)), owner.ctypes.data_as(ip),
+        local_index.ctypes.data_as(ip), n, order.ctypes.data_as(ip), run_end.ctypes.data_as(ip),
+        C.byref(n_runs)))
+    return order[:n].copy(), run_end[:n_runs.value].copy()
+
+
+def piece_range(image_size: int, piece_index: int, num_pieces: int) -> Tuple[int, int]:
+    """getPieceRange (DirectSend/Base/DirectSendBase.cpp:59-74)."""
+    b, e = C.c_int64(), C.c_int64()
+    _capi.check(_capi.lib().avr_piece_range(int(image_size), int(piece_index), int(num_pieces),
+                                            C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+# ---------------------------------------------------------------------------------------------
+# device context
+# ---------------------------------------------------------------------------------------------
+
+class Context:
+    """One rendering context per rank (= per GPU).  Owns a HIP stream (a torch stream, so
+    torch allocations / collectives can be ordered against the kernels)."""
+
+    def __init__(self, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise _capi.AvrNoDevice("no HIP device visible to PyTorch; the renderer has no CPU "
+                                    "fallback")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_context_create(self.device_index, C.byref(handle)))
+        self._handle = handle
+        self.stream = torch.cuda.Stream(device=self.device)
+        _capi.check(_capi.lib().avr_context_set_stream(self._handle,
+                                                       C.c_void_p(self.stream.cuda_stream)))
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _capi.lib().avr_context_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- stream ordering -----------------------------------------------------------------------
+    def join(self) -> None:
+        """Make the context stream wait for work already queued on torch's current stream."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def publish(self) -> None:
+        """Make torch's current stream wait for the context stream."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def synchronize(self) -> None:
+        _capi.check(_capi.lib().avr_context_synchronize(self._handle))
+
+    # -- helpers ----------------------------------------------------------------------------
+    def _check_tensor(self, t: torch.Tensor, dtype, what: str) -> None:
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise ValueError(f"{what} must be a tensor on {self.device}")
+        if t.dtype != dtype or not t.is_contiguous():
+            raise ValueError(f"{what} must be a contiguous {dtype} tensor")
+
+    def empty(self, *shape, dtype=torch.float32) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # -- painter ----------------------------------------------------------------------------
+    def paint_box(self, box: AmrBox, transform: ScalarTransform, params: _capi.PaintParams,
+                  camera: CameraParameters, out: Optional[torch.Tensor] = None,
+                  samples: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_paint_box: one box -> [H, W, 5] depth-sort layer."""
+        if out is None:
+            out = self.empty(params.height, params.width, 5)
+        self._check_tensor(out, torch.float32, "out")
+        if out.numel() != params.width * params.height * 5:
+            raise ValueError("out has the wrong size")
+        if samples is not None:
+            self._check_tensor(samples, torch.int64, "samples")
+        cbox, ctr, ccam = box.to_c(), transform.to_c(), camera.to_c()
+        self.join()
+        _capi.check(_capi.lib().avr_paint_box(
+            self._handle, C.byref(cbox), C.byref(ctr), C.byref(params), C.byref(ccam),
+            C.c_void_p(out.data_ptr()),
+            C.c_void_p(samples.data_ptr()) if samples is not None else None))
+        self.publish()
+        return out
+
+    def create_scene(self, boxes: Sequence[AmrBox], transform: ScalarTransform) -> "Scene":
+        return Scene(self, boxes, transform)
+
+    # -- image algebra -------------------------------------------------------------------------
+    _BLEND = {"depthsort": ("avr_blend_depthsort_f32x5", torch.float32, 5),
+              "rgba_f32": ("avr_blend_rgba_f32x4", torch.float32, 4),
+              "rgba_u8": ("avr_blend_rgba_u8x4", torch.int32, 1)}
+    _KIND = {"depthsort": 0, "rgba_f32": 1, "rgba_u8": 2}
+
+    def blend(self, kind: str, top: torch.Tensor, bottom: torch.Tensor,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        name, dtype, vec = self._BLEND[kind]
+        self._check_tensor(top, dtype, "top")
+        self._check_tensor(bottom, dtype, "bottom")
+        if top.numel() != bottom.numel():
+            raise ValueError("top and bottom differ in size")
+        if out is None:
+            out = torch.empty_like(top)
+        self._check_tensor(out, dtype, "out")
+        self.join()
+        _capi.check(getattr(_capi.lib(), name)(
+            self._handle, C.c_void_p(top.data_ptr()), C.c_void_p(bottom.data_ptr()),
+            C.c_void_p(out.data_ptr()), top.numel() // vec))
+        self.publish()
+        return out
+
+    def blend_regions(self, kind: str, top: torch.Tensor, tb: int, te: int, bottom: torch.Tensor,
+                      bb: int, be: int) -> Tuple[torch.Tensor, int, int]:
+        _, dtype, vec = self._BLEND[kind]
+        self._check_tensor(top, dtype, "top")
+        self._check_tensor(bottom, dtype, "bottom")
+        if top.numel() != (te - tb) * vec or bottom.numel() != (be - bb) * vec:
+            raise ValueError("buffer sizes do not match the regions")
+        ob, oe = min(tb, bb), max(te, be)
+        out = self.empty((oe - ob) * vec, dtype=dtype)
+        self.join()
+        _capi.check(_capi.lib().avr_blend_regions(
+            self._handle, self._KIND[kind], C.c_void_p(top.data_ptr()), tb, te,
+            C.c_void_p(bottom.data_ptr()), bb, be, C.c_void_p(out.data_ptr())))
+        self.publish()
+        return out, ob, oe
+
+    def encode_rgba_u8(self, rgba: torch.Tensor) -> torch.Tensor:
+        self._check_tensor(rgba, torch.float32, "rgba")
+        out = self.empty(rgba.numel() // 4, dtype=torch.int32)
+        self.join()
+        _capi.check(_capi.lib().avr_encode_rgba_u8(self._handle, C.c_void_p(rgba.data_ptr()),
+                                                   C.c_void_p(out.data_ptr()), out.numel()))
+        self.publish()
+        return out
+
+    def decode_rgba_u8(self, encoded: torch.Tensor) -> torch.Tensor:
+        self._check_tensor(encoded, torch.int32, "encoded")
+        out = self.empty(encoded.numel(), 4)
+        self.join()
+        _capi.check(_capi.lib().avr_decode_rgba_u8(self._handle, C.c_void_p(encoded.data_ptr()),
+                                                   C.c_void_p(out.data_ptr()), encoded.numel()))
+        self.publish()
+        return out
+
+    def fold_runs(self, slices: Sequence[torch.Tensor], n_pixels: int,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_fold_runs_depthsort: left fold of run slices (each n_pixels x 5) in order."""
+        for s in slices:
+            self._check_tensor(s, torch.float32, "slice")
+            if s.numel() != n_pixels * 5:
+                raise ValueError("slice has the wrong size")
+        if out is None:
+            out = self.empty(n_pixels, 5)
+        self._check_tensor(out, torch.float32, "out")
+        ptrs = (C.c_void_p * max(len(slices), 1))(*[s.data_ptr() for s in slices])
+        self.join()
+        _capi.check(_capi.lib().avr_fold_runs_depthsort(self._handle, ptrs, len(slices),
+                                                        C.c_void_p(out.data_ptr()), n_pixels))
+        self.publish()
+        return out
+
+    def downsample(self, src: torch.Tensor, target_w: int, target_h: int, block: int
+                   ) -> torch.Tensor:
+        self._check_tensor(src, torch.float32, "src")
+        if src.numel() != target_w * block * target_h * block * 5:
+            raise ValueError("src has the wrong size")
+        out = self.empty(target_h, target_w, 5)
+        self.join()
+        _capi.check(_capi.lib().avr_downsample_depthsort(
+            self._handle, C.c_void_p(src.data_ptr()), target_w, target_h, block,
+            C.c_void_p(out.data_ptr())))
+        self.publish()
+        return out
+
+    def quantize_rgb8(self, src: torch.Tensor, w: int, h: int) -> torch.Tensor:
+        self._check_tensor(src, torch.float32, "src")
+        stride = src.numel() // (w * h)
+        out = self.empty(h, w, 3, dtype=torch.uint8)
+        self.join()
+        _capi.check(_capi.lib().avr_quantize_rgb8(self._handle, C.c_void_p(src.data_ptr()), w, h,
+                                                  stride, C.c_void_p(out.data_ptr())))
+        self.publish()
+        return out
+
+
+class Scene:
+    """The rank's local boxes + scalar transform (avr_scene).  Keeps the cell tensors alive."""
+
+    def __init__(self, ctx: Context, boxes: Sequence[AmrBox], transform: ScalarTransform):
+        self.ctx = ctx
+        self.boxes = list(boxes)
+        self.transform = transform
+        for b in self.boxes:
+            if b.values is None or b.values.device != ctx.device:
+                raise ValueError("scene boxes need cell data on the context's device")
+        arr = (_capi.Box * max(len(self.boxes), 1))(*[b.to_c() for b in self.boxes])
+        ctr = transform.to_c()
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_scene_create(ctx._handle, arr, len(self.boxes), C.byref(ctr),
+                                                 C.byref(handle)))
+        self._handle = handle
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _capi.lib().avr_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_runs(self, params: _capi.PaintParams, camera: CameraParameters,
+                    box_order: Sequence[int], run_end: Sequence[int], n_pieces: int = 1,
+                    out: Optional[torch.Tensor] = None,
+                    samples: Optional[torch.Tensor] = None, sync_streams: bool = True
+                    ) -> torch.Tensor:
+        """avr_render_runs: fused paint + owner-side run fold; returns the send-layout buffer
+        (n_runs * H * W * 5 floats)."""
+        ctx = self.ctx
+        order = np.ascontiguousarray(box_order, dtype=np.int32)
+        ends = np.ascontiguousarray(run_end, dtype=np.int32)
+        n_runs = int(ends.size)
+        n_px = int(params.width) * int(params.height)
+        if out is None:
+            out = ctx.empty(max(n_runs, 1) * n_px * 5)
+        ctx._check_tensor(out, torch.float32, "out")
+        if out.numel() < n_runs * n_px * 5:
+            raise ValueError("out is too small")
+        if samples is not None:
+            ctx._check_tensor(samples, torch.int64, "samples")
+        ccam = camera.to_c()
+        ip = C.POINTER(C.c_int32)
+        if sync_streams:
+            ctx.join()
+        _capi.check(_capi.lib().avr_render_runs(
+            ctx._handle, self._handle, C.byref(params), C.byref(ccam),
+            order.ctypes.data_as(ip), int(order.size), ends.ctypes.data_as(ip), n_runs,
+            int(n_pieces), C.c_void_p(out.data_ptr()),
+            C.c_void_p(samples.data_ptr()) if samples is not None else None))
+        if sync_streams:
+            ctx.publish()
+        return out

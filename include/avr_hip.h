@@ -1,0 +1,217 @@
+/*
+ * avr_hip.h -- C ABI of the MI355X (gfx950) volume-rendering hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, no exceptions.
+ * Every entry point cites the reference interface (file:line under the amrVolumeRenderer tree)
+ * it replaces.  All image/cell pointers are DEVICE pointers (HBM) unless a parameter says
+ * "host".  Every function returns 0 on success or a negative avr_status; the message of the
+ * last failure on the calling thread is available from avr_last_error().
+ *
+ * There is no CPU fallback behind this ABI: without a HIP device every compute entry point
+ * fails with AVR_ERR_NO_DEVICE.
+ *
+ * Pixel layouts (same as the reference's image buffers):
+ *   depth-sort image : 5 floats / pixel  (premultiplied r, g, b, a, depth)   -- ImageRGBAFloatColorDepthSort
+ *   float image      : 4 floats / pixel  (premultiplied r, g, b, a)          -- ImageRGBAFloatColorOnly
+ *   ubyte image      : 1 uint32 / pixel  (bytes r, g, b, a in memory order)  -- ImageRGBAUByteColorOnly
+ * Pixel index p = y * width + x, image origin bottom-left (Common/VolumePainter.cpp:738-739).
+ */
+#ifndef AVR_HIP_H
+#define AVR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  AVR_OK = 0,
+  AVR_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference API */
+  AVR_ERR_RUNTIME = -2,          /* std::runtime_error (HIP failure, bad image type, ...) */
+  AVR_ERR_NO_DEVICE = -3,
+  AVR_ERR_OUT_OF_MEMORY = -4
+} avr_status;
+
+typedef struct avr_context avr_context;
+typedef struct avr_scene avr_scene;
+
+/* volume::AmrBox (Common/VolumeTypes.hpp:69-76).  `cells` = address of
+ * values(validBox.smallEnd(), component): x fastest, then jstride, kstride (amrex::Array4). */
+typedef struct {
+  double min_corner[3];
+  double max_corner[3];
+  int32_t dims[3];
+  int32_t level;        /* informational (AMR level); not read by the kernels */
+  const double *cells;  /* device pointer */
+  int64_t jstride;
+  int64_t kstride;
+} avr_box;
+
+/* volume::ScalarTransform (Common/VolumeTypes.hpp:21-31): the fields the path reads. */
+typedef struct {
+  int32_t log_scale_input;
+  int32_t normalize_to_unit_range;
+  double positive_floor;
+  double normalization_min;
+  double inverse_normalization_span;
+} avr_scalar_transform;
+
+/* volume::CameraParameters (Common/VolumeTypes.hpp:83-90). */
+typedef struct {
+  double eye[3];
+  double look_at[3];
+  double up[3];
+  float fov_y_degrees;
+  float near_plane;
+  float far_plane;
+} avr_camera;
+
+/* volume::ColorMapControlPoint (Common/VolumeTypes.hpp:92-98). */
+typedef struct {
+  float value, red, green, blue, alpha;
+} avr_colormap_point;
+
+/* The scalar arguments of VolumePainter::paint (Common/VolumePainter.hpp:19-31):
+ * image size, scalarRange, boxTransparency, referenceSampleDistance, bounds, colorMap.
+ * (rank, numProcs, antialiasing are unused by the reference: VolumePainter.cpp:561-562.) */
+typedef struct {
+  int32_t width;
+  int32_t height;
+  float scalar_range[2];
+  float box_transparency;
+  float reference_sample_distance;
+  double bounds_min[3];
+  double bounds_max[3];
+  const avr_colormap_point *colormap; /* host pointer; NULL/0 = default jet map */
+  int32_t colormap_count;
+} avr_paint_params;
+
+/* ---- library / context ------------------------------------------------------------------ */
+
+/* Message of the last failure on this thread ("" if none). */
+const char *avr_last_error(void);
+
+/* ABI version of this header (bumped on incompatible change). */
+int avr_abi_version(void);
+
+/* Creates a context bound to HIP device `device_id` with its own stream.  Replaces the
+ * function-local static VolumePainter / DirectSendBase instances of
+ * VolumeRenderer/VolumeRenderer.cpp:909-927 (one context per rank = per GPU). */
+int avr_context_create(int device_id, avr_context **out_ctx);
+void avr_context_destroy(avr_context *ctx);
+
+/* Use an externally owned HIP stream (hipStream_t passed as void*; NULL = the context's own).
+ * All launches of the context go to this stream; nothing in this ABI synchronises the stream
+ * except avr_context_synchronize and the *_host readbacks. */
+int avr_context_set_stream(avr_context *ctx, void *hip_stream);
+int avr_context_synchronize(avr_context *ctx);
+
+/* ---- host-side per-frame quantities (no device work) ------------------------------------- */
+
+/* buildColorTable (Common/VolumePainter.cpp:442-516): 256 RGBA entries to host memory. */
+int avr_build_color_table(float alpha_scale, float normalization_factor,
+                          const float scalar_range[2], const avr_colormap_point *colormap,
+                          int colormap_count, float out_table_host[1024]);
+
+/* sampleDistance / normalizationFactor / alphaScale of one box (VolumePainter.cpp:571-613). */
+int avr_box_sampling(const avr_box *box, const avr_paint_params *params, float *sample_distance,
+                     float *normalization_factor, float *alpha_scale);
+
+/* computeBoxDepthHint (VolumeRenderer/VolumeRenderer.cpp:541-553). */
+int avr_box_depth_hint(const avr_box *box, const avr_camera *camera, float *out_hint);
+
+/* referenceSampleDistance of renderSingleTrial (VolumeRenderer/VolumeRenderer.cpp:1138-1190)
+ * over the boxes given (the caller reduces with MAX over ranks when boxes are distributed:
+ * pass the already-reduced coarsest spacing through avr_paint_params instead). */
+int avr_reference_sample_distance(const avr_box *boxes, int n_boxes, const double bounds_min[3],
+                                  const double bounds_max[3], float *out_distance);
+
+/* Global layer order of DirectSendBase::composeLayered (DirectSend/Base/DirectSendBase.cpp:
+ * 363-410): sorts layers by (hint, owner, local_index); order_out[n] = layer ids,
+ * run_end_out[r] = one-past-last position of run r (maximal same-owner stretch); *n_runs_out. */
+int avr_layer_order(const float *hints, const int32_t *owner, const int32_t *local_index,
+                    int n_layers, int32_t *order_out, int32_t *run_end_out, int *n_runs_out);
+
+/* getPieceRange (DirectSend/Base/DirectSendBase.cpp:59-74). */
+int avr_piece_range(int64_t image_size, int piece_index, int num_pieces, int64_t *begin,
+                    int64_t *end);
+
+/* ---- painter ----------------------------------------------------------------------------- */
+
+/* VolumePainter::paint (Common/VolumePainter.hpp:19-31, .cpp:548-961) for ONE box: writes
+ * width*height depth-sort pixels to out_rgbad (device).  If samples_out (device, 1 x uint64)
+ * is non-NULL the number of executed cell fetches is ADDED to it. */
+int avr_paint_box(avr_context *ctx, const avr_box *box, const avr_scalar_transform *transform,
+                  const avr_paint_params *params, const avr_camera *camera, float *out_rgbad,
+                  uint64_t *samples_out);
+
+/* A scene = the rank's local boxes (geometry.localBoxes, VolumeRenderer.cpp:1201) with one
+ * scalar transform (geometry.scalarTransform).  Descriptors are copied to the device; cell
+ * data stays where `cells` points. */
+int avr_scene_create(avr_context *ctx, const avr_box *boxes, int n_boxes,
+                     const avr_scalar_transform *transform, avr_scene **out_scene);
+void avr_scene_destroy(avr_scene *scene);
+
+/* Fused replacement of the per-box loop + owner-side run fold
+ * (VolumeRenderer.cpp:1201-1219 + DirectSendBase.cpp:413-426): paints the local boxes
+ * box_order[0..n) (indices into the scene, already in global layer order) and folds each run
+ * (run_end[r] = one-past-last position of run r in box_order) with the depth-sort blend, in
+ * order.  Run r's layer is written for ALL pixels in "send layout": the image is cut in
+ * n_pieces DirectSend pieces (avr_piece_range) and
+ *     out[ piece_offset(k) + (r * piece_len(k) + (p - piece_begin(k))) * 5 .. +5 ]
+ * with piece_offset(k) = 5 * n_runs * piece_begin(k); for n_pieces == 1 this is simply
+ * out[r][p][5].  The result is bit-identical to painting every box into its own layer and
+ * blending (empty pixels are an exact identity of the blend).
+ * samples_out as in avr_paint_box. */
+int avr_render_runs(avr_context *ctx, const avr_scene *scene, const avr_paint_params *params,
+                    const avr_camera *camera, const int32_t *box_order, int n_order,
+                    const int32_t *run_end, int n_runs, int n_pieces, float *out_layers,
+                    uint64_t *samples_out);
+
+/* ---- image algebra ----------------------------------------------------------------------- */
+
+/* Features::blend over n pixels, out = blend(top, bottom); out may alias top or bottom.
+ * ImageRGBAFloatColorDepthSort.hpp:13-27 / ImageRGBAFloatColorOnly.hpp:19-26 /
+ * ImageRGBAUByteColorOnly.hpp:19-34 (uint8 wrap-around preserved). */
+int avr_blend_depthsort_f32x5(avr_context *ctx, const float *top, const float *bottom,
+                              float *out, int64_t n_pixels);
+int avr_blend_rgba_f32x4(avr_context *ctx, const float *top, const float *bottom, float *out,
+                         int64_t n_pixels);
+int avr_blend_rgba_u8x4(avr_context *ctx, const uint32_t *top, const uint32_t *bottom,
+                        uint32_t *out, int64_t n_pixels);
+
+/* ImageColorOnly<F>::blend with pixel regions (Common/ImageColorOnly.hpp:119-199): top covers
+ * [tb,te), bottom [bb,be), out covers [min(tb,bb), max(te,be)); the regions must touch or
+ * overlap.  kind: 0 depth-sort, 1 float, 2 ubyte.  out must not alias the inputs. */
+int avr_blend_regions(avr_context *ctx, int kind, const void *top, int64_t tb, int64_t te,
+                      const void *bottom, int64_t bb, int64_t be, void *out);
+
+/* Color::GetComponentAsByte / SetComponentFromByte over n RGBA pixels
+ * (Common/Color.hpp:66-91, ImageRGBAUByteColorOnly.cpp:16-39). */
+int avr_encode_rgba_u8(avr_context *ctx, const float *rgba, uint32_t *out, int64_t n_pixels);
+int avr_decode_rgba_u8(avr_context *ctx, const uint32_t *in, float *rgba, int64_t n_pixels);
+
+/* Receiver-side fold of DirectSendBase::composeLayered (DirectSendBase.cpp:400-446) for one
+ * piece of n_pixels pixels: slices[r] (device pointers, host array) are the piece's pixels of
+ * global run r in global order; out = fold_left(blend, slices).  n_slices == 0 writes the
+ * cleared layer (0,0,0,0,+inf) (DirectSendBase.cpp:450-455). */
+int avr_fold_runs_depthsort(avr_context *ctx, const float *const *slices_host, int n_slices,
+                            float *out, int64_t n_pixels);
+
+/* ---- frame tail --------------------------------------------------------------------------- */
+
+/* downsampleImage (VolumeRenderer/VolumeRenderer.cpp:479-528): block x block box mean of a
+ * (target_w*block) x (target_h*block) depth-sort image; depth := +inf. */
+int avr_downsample_depthsort(avr_context *ctx, const float *src, int target_w, int target_h,
+                             int block, float *dst);
+
+/* SavePPM/SavePNG pixel bytes (Common/SavePPM.cpp:17-36, Common/Color.hpp:86-90): RGB8 from an
+ * image of `stride` floats per pixel, rows written top-down (y = h-1 .. 0). dst = w*h*3 bytes. */
+int avr_quantize_rgb8(avr_context *ctx, const float *src, int w, int h, int stride,
+                      uint8_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVR_HIP_H */
