@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on BASELINE.json's metric: Mray-samples/s (+ frames/s) for a
+2048^2 render of the 512^3-base 3-level AMR scene (config-4 of SURVEY.md 8d), translucent
+transfer function (box_transparency 0.97: full traversal, the throughput regime).
+
+  python bench.py --gpus N --steps K --warmup W
+(for N > 1 launched by torch.distributed.run, one rank per GPU over RCCL).
+
+A "step" is one frame: fused paint + run fold -> DirectSend exchange -> fold -> gather ->
+8-bit conversion, with all cell data already resident in HBM.  Strong scaling: the frame is
+fixed, boxes are partitioned over ranks (Morton chunks).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="config4",
+                    choices=["config1", "config2", "config3", "config4", "config5", "tiny"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--field", default="smooth", choices=["smooth", "noise", "radial"])
+    ap.add_argument("--transparency", type=float, default=0.97)
+    ap.add_argument("--ownership", default="morton", choices=["morton", "round_robin", "block"])
+    ap.add_argument("--antialiasing", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target CPU time of the bounded cpu_baseline sample")
+    ap.add_argument("--orbit", type=int, default=0, help="average over this many orbit views")
+    return ap.parse_args()
+
+
+CONFIG_IMAGE = {"config1": (256, 256), "config2": (1024, 1024), "config3": (2048, 2048),
+                "config4": (2048, 2048), "config5": (4096, 4096), "tiny": (256, 256)}
+
+
+def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
+    """Times the oracle (the CPU restatement of VolumePainter::paint, oracle/avr_oracle.c) on
+    a bounded stratified sample of this scene's boxes at the full image size, on the host
+    cores of this box.  Reported beside the GPU number; never the thing measured or shipped."""
+    import numpy as np
+    from oracle import oracle as O
+    threads = min(os.cpu_count() or 1, 16)
+    params, _ = renderer.make_params(rparams)
+    ocam = O.make_camera(camera.eye, camera.look_at, camera.up, camera.fov_y_degrees,
+                         camera.near_plane, camera.far_plane)
+    tr = spec.transform
+    otr = O.make_transform(tr.log_scale_input, tr.normalize_to_unit_range, tr.positive_floor,
+                           tr.normalization_min, tr.inverse_normalization_span)
+    op = O.make_params(params.width, params.height, spec.scalar_range, rparams.box_transparency,
+                       renderer.reference_sample_distance, spec.bounds.min_corner,
+                       spec.bounds.max_corner)
+    n = len(local_boxes)
+    # stratified: boxes spread evenly over the level-major list; stop at the time budget
+    picks = [int(i * n / 16) for i in range(16)] if n >= 16 else list(range(n))
+    total_samples, total_time, used = 0, 0.0, 0
+    for i in picks:
+        box = local_boxes[i]
+        cells = box.values.cpu().numpy()
+        ob = O.make_box(cells, box.min_corner, box.max_corner)
+        t0 = time.perf_counter()
+        _, ns = O.paint_box(ob, otr, op, ocam, threads=threads)
+        total_time += time.perf_counter() - t0
+        total_samples += ns
+        used += 1
+        if total_time >= seconds:
+            break
+    return {
+        "value": round(total_samples / max(total_time, 1e-9) / 1e6, 3),
+        "unit": "Mray-samples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle VolumePainter::paint of {used} of {n} boxes (stratified over the "
+                  f"level-major box list) at {params.width}x{params.height}, same camera and "
+                  f"transfer function, {total_samples} samples in {total_time:.1f} s, "
+                  f"OpenMP over image rows",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
+
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    from amrvolumerenderer_amd import build as avr_build
+    if rank == 0:
+        avr_build.build()
+    if world > 1:
+        dist.barrier()
+    from amrvolumerenderer_amd import runtime, scenes
+    from amrvolumerenderer_amd.renderer import (FrameRenderer, RenderParameters,
+                                                build_scene_on_device)
+
+    if args.config == "tiny":
+        spec = scenes.make_amr_scene(64, 2, 16, args.field, "tiny_amr2_64")
+    else:
+        spec = getattr(scenes, args.config)(args.field)
+    scenes.assign_owners(spec, world, args.ownership)
+    width, height = CONFIG_IMAGE[args.config]
+    width = args.width or width
+    height = args.height or height
+
+    ctx = runtime.Context(local_rank)
+    all_boxes, local_boxes = build_scene_on_device(ctx, spec, rank)
+    torch.cuda.synchronize()
+    renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
+                             spec.scalar_range, rank, world, group)
+    rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
+                               antialiasing=args.antialiasing)
+    cameras = ([scenes.orbit_camera(v, args.orbit) for v in range(args.orbit)]
+               if args.orbit > 0 else [scenes.default_camera()])
+
+    # ---- untimed: sample count of one frame per camera (device-side counter, stats build) ----
+    samples_dev = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    frame_samples = []
+    for cam in cameras:
+        samples_dev.zero_()
+        renderer.render(rparams, cam, samples=samples_dev)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        s = samples_dev.clone()
+        if world > 1:
+            dist.all_reduce(s, group=group)
+        frame_samples.append(int(s.item()))
+    local_runs = renderer.last_plan.n_local_runs
+    total_runs = len(renderer.last_plan.run_owner)
+
+    def step(i):
+        return renderer.render(rparams, cameras[i % len(cameras)])
+
+    for i in range(args.warmup):
+        step(i)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+    # ---- timed region: EXACTLY `steps` frames ----------------------------------------------
+    # the paint kernel's own duration is taken with HIP events on the stream it is launched on
+    params, _ = renderer.make_params(rparams)
+    kernel_events = []
+    orig_paint = renderer.paint
+
+    def timed_paint(plan, p, cam, samples=None, sync_streams=True):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(ctx.stream)
+        out = orig_paint(plan, p, cam, samples, sync_streams)
+        e1.record(ctx.stream)
+        kernel_events.append((e0, e1))
+        return out
+
+    renderer.paint = timed_paint
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    renderer.paint = orig_paint
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    elapsed = float(t.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+
+    samples_total = sum(frame_samples[i % len(cameras)] for i in range(args.steps))
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = samples_total / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (render_runs_kernel), this rank's launch ------------
+    # algorithmic bytes per launch = 8 B per executed cell fetch (one amrex::Real) + 20 B per
+    # emitted layer pixel; samples of THIS rank's launch:
+    samples_dev.zero_()
+    renderer.render(rparams, cameras[0], samples=samples_dev)
+    ctx.synchronize()
+    my_samples = int(samples_dev.item())
+    n_pixels = params.width * params.height
+    algo_bytes = 8.0 * my_samples + 20.0 * n_pixels * max(local_runs, 1)
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "render_runs_kernel",
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(algo_bytes),
+        "samples_this_rank": my_samples,
+        "compulsory_bytes": int(sum(b.values.numel() for b in local_boxes) * 8
+                                + 20 * n_pixels * max(local_runs, 1)),
+    }
+
+    out = {
+        "metric": "Mray-samples/s (2048^2 render of 512^3-base 3-level AMR)",
+        "value": round(value, 3), "unit": "Mray-samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "frames_per_s": round(1e3 / ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 march / f64 cell fetch+transform", "data": "synthetic",
+        "config": {
+            "workload": f"{spec.name}: {len(spec.boxes)} boxes of {spec.box_cells}^3 "
+                        f"({spec.total_cells * 8 / 1e9:.2f} GB f64), {spec.levels} AMR levels, "
+                        f"field={spec.field}, {width}x{height}, antialiasing={args.antialiasing}, "
+                        f"box_transparency={args.transparency}, default jet map, "
+                        f"{len(cameras)} view(s)",
+            "ownership": args.ownership, "runs_total": total_runs,
+            "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,
+        },
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec, local_boxes, renderer, rparams, cameras[0],
+                                           args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
