@@ -596,8 +596,6 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
     dev.nz = box.dims[2];
     dev.sample_dist = step;
     dev.cells = box.cells;
-    dev.jstride = box.jstride;
-    dev.kstride = box.kstride;
 
     if (dev.nx <= 0 || dev.ny <= 0 || dev.nz <= 0) {
       // the reference clears the layer (VolumePainter.cpp:670-673): never hit
@@ -605,9 +603,19 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
       dev.rect[2] = dev.rect[3] = -1;
       dev.dx = dev.dy = dev.dz = 1.0f;
       dev.inv_dx = dev.inv_dy = dev.inv_dz = 1.0f;
+      dev.index_mode = kExactDivide;
       continue;
     }
     if (box.cells == nullptr) throw std::invalid_argument("box has no cell data");
+    // 32-bit element offsets on the device: the addressed span must stay below 2^28 elements
+    const int64_t span = static_cast<int64_t>(dev.nx - 1) +
+                         static_cast<int64_t>(dev.ny - 1) * box.jstride +
+                         static_cast<int64_t>(dev.nz - 1) * box.kstride;
+    if (box.jstride < 0 || box.kstride < 0 || span >= (int64_t{1} << 28)) {
+      throw std::invalid_argument("box spans more than 2^28 cells (or has negative strides)");
+    }
+    dev.jstride = static_cast<int32_t>(box.jstride);
+    dev.kstride = static_cast<int32_t>(box.kstride);
 
     dev.dx = (dev.maxc[0] - dev.minc[0]) / static_cast<float>(dev.nx);
     dev.dy = (dev.maxc[1] - dev.minc[1]) / static_cast<float>(dev.ny);
@@ -615,8 +623,21 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
     dev.inv_dx = 1.0f / dev.dx;
     dev.inv_dy = 1.0f / dev.dy;
     dev.inv_dz = 1.0f / dev.dz;
-    dev.pow2_spacing =
-        (is_power_of_two(dev.dx) && is_power_of_two(dev.dy) && is_power_of_two(dev.dz)) ? 1 : 0;
+    const bool regular = (dev.dx > 0.0f && dev.dy > 0.0f && dev.dz > 0.0f) &&
+                         std::isfinite(dev.dx) && std::isfinite(dev.dy) && std::isfinite(dev.dz) &&
+                         std::isfinite(dev.inv_dx) && std::isfinite(dev.inv_dy) &&
+                         std::isfinite(dev.inv_dz);
+    if (!regular) {
+      dev.index_mode = kExactDivide;
+    } else if (is_power_of_two(dev.dx) && is_power_of_two(dev.dy) && is_power_of_two(dev.dz)) {
+      dev.index_mode = kPow2Multiply;
+    } else {
+      dev.index_mode = kReciprocal;
+    }
+    // |q - RN(f/dx)| < 2^-22 * q and q <= n * (1 + 2^-22) for an inside sample; 2^-20 * n
+    // leaves a 4x margin (derivation in DESIGN.md, "Exact index without the divide")
+    const int longest = std::max(dev.nx, std::max(dev.ny, dev.nz));
+    dev.near_tol = std::ldexp(static_cast<float>(std::max(longest, 1)), -20);
     const float ex = dev.maxc[0] - dev.minc[0];
     const float ey = dev.maxc[1] - dev.minc[1];
     const float ez = dev.maxc[2] - dev.minc[2];

@@ -14,6 +14,16 @@ namespace avr {
 constexpr int kTableSize = 256;  // kColorTableSize, Common/VolumePainter.cpp:35
 constexpr int kMaxLdsTables = 16;  // transfer-function tables staged in LDS per launch (4 KiB each)
 
+// Cell index = floor((pos - min) / dx) with an IEEE divide in the reference
+// (Common/VolumePainter.cpp:846-852).  The same integer is obtained cheaper when provable:
+enum IndexMode : int32_t {
+  kPow2Multiply = 0,  // dx is a power of two: (pos - min) * (1/dx) IS the correctly rounded quotient
+  kReciprocal = 1,    // q = (pos - min) * RN(1/dx) is within 2^-22 * q of the rounded quotient, so
+                      // floor(q) is the reference's index unless q is within near_tol of an
+                      // integer; those samples take the exact divide
+  kExactDivide = 2,   // degenerate spacing (dx <= 0 or not finite): always the exact divide
+};
+
 // Per-box constants of VolumePainter::paint's host prologue (Common/VolumePainter.cpp:571-692),
 // laid out for wave-uniform scalar loads (one 128-byte record per box).
 struct alignas(16) BoxDev {
@@ -25,11 +35,13 @@ struct alignas(16) BoxDev {
   int32_t nx, ny, nz;
   int32_t lut;            // index of this box's transfer-function table
   int32_t rect[4];        // conservative screen rectangle x0,y0,x1,y1 (inclusive); x1 < x0 = off-screen
+  int32_t index_mode;     // how (pos - min) / dx is evaluated, see IndexMode
   const double* cells;    // values(validBox.smallEnd(), component)
-  int64_t jstride;
-  int64_t kstride;
-  float inv_dx, inv_dy, inv_dz;  // 1/dx.. (IEEE), exact-multiply fast path when dx is a power of two
-  int32_t pow2_spacing;   // 1 when dx, dy, dz are all powers of two (division == multiplication)
+  int32_t jstride;        // element strides (Array4); the box spans < 2^28 elements
+  int32_t kstride;
+  float inv_dx, inv_dy, inv_dz;  // RN(1 / dx)
+  float near_tol;         // kReciprocal: |q - rint(q)| <= near_tol sends the sample to the exact divide
+  int32_t pad_[3];
 };
 static_assert(sizeof(BoxDev) == 128, "BoxDev must stay one 128-byte record");
 

@@ -153,19 +153,86 @@ __device__ __forceinline__ void slab_axis(float origin, float direction, float i
   tmax = (tmax < t2) ? tmax : t2;
 }
 
+// Cell indices of an inside sample: the reference's clamp(int(floor((pos - min) / d)), 0, n - 1)
+// per axis (VolumePainter.cpp:846-867), as the linear element offset i + j*jstride + k*kstride.
+// `fx` = pos - min >= 0 for an inside sample, so truncation equals floor and only the upper
+// clamp can bind on the multiply paths; the exact-divide path restates the reference literally.
+template <int MODE>
+__device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, float fx, float fy, float fz) {
+  int i = 0, j = 0, k = 0;
+  bool exact = (MODE == kExactDivide);
+  if (MODE != kExactDivide) {
+    const float qx = fx * box.inv_dx;
+    const float qy = fy * box.inv_dy;
+    const float qz = fz * box.inv_dz;
+    i = static_cast<int>(qx);
+    j = static_cast<int>(qy);
+    k = static_cast<int>(qz);
+    i = (i > box.nx - 1) ? box.nx - 1 : i;
+    j = (j > box.ny - 1) ? box.ny - 1 : j;
+    k = (k > box.nz - 1) ? box.nz - 1 : k;
+    if (MODE == kReciprocal) {
+      // q is within 2^-22 * q of the correctly rounded quotient; the floors can differ only
+      // when q sits this close to an integer ("Exact index without the divide")
+      const float ex = fabsf(qx - rintf(qx));
+      const float ey = fabsf(qy - rintf(qy));
+      const float ez = fabsf(qz - rintf(qz));
+      exact = fminf(fminf(ex, ey), ez) <= box.near_tol;
+    }
+  }
+  if (exact) {
+    int ei = static_cast<int>(floorf(fx / box.dx));
+    int ej = static_cast<int>(floorf(fy / box.dy));
+    int ek = static_cast<int>(floorf(fz / box.dz));
+    ei = (ei < 0) ? 0 : ((ei >= box.nx) ? box.nx - 1 : ei);
+    ej = (ej < 0) ? 0 : ((ej >= box.ny) ? box.ny - 1 : ej);
+    ek = (ek < 0) ? 0 : ((ek >= box.nz) ? box.nz - 1 : ek);
+    i = ei;
+    j = ej;
+    k = ek;
+  }
+  return static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * static_cast<uint32_t>(box.jstride) +
+         static_cast<uint32_t>(k) * static_cast<uint32_t>(box.kstride);
+}
+
+typedef const double __attribute__((address_space(1))) * GlobalCells;
+
+// Transfer-function table index of one cell value.
+//   SIMPLE = the standard API path: no log scaling, normalise on, no soft
+//   clip, scalarRange {0,1}.  There scalar = float(clamp_d((v - min) * inv, 0, 1)) and
+//   normalized = (scalar - 0) * 1 = scalar; clamping after the float cast gives the same value
+//   (rounding is monotone and 0, 1 are exact; only the sign of a zero can differ, which cannot
+//   change int(scalar * 255)), and int(scalar * 255) is already in [0, 255].
+template <bool SIMPLE>
+__device__ __forceinline__ int table_index(double raw, const FrameConsts& fc) {
+  if (SIMPLE) {
+    double v = __builtin_isfinite(raw) ? raw : 0.0;
+    v = (v - fc.norm_min) * fc.inv_norm_span;
+    const float scalar = __builtin_amdgcn_fmed3f(static_cast<float>(v), 0.0f, 1.0f);
+    return static_cast<int>(scalar * 255.0f);
+  }
+  float scalar = apply_scalar_transform(raw, fc);
+  if (fc.apply_clip) scalar = saturate_soft_tail(scalar, fc.clip_start);
+  float normalized = (scalar - fc.range_min) * fc.inverse_range;
+  normalized = (normalized < 0.0f) ? 0.0f : normalized;
+  normalized = (normalized > 1.0f) ? 1.0f : normalized;
+  int idx = static_cast<int>(normalized * 255.0f);
+  idx = (idx < 0) ? 0 : idx;
+  idx = (idx > kTableSize - 1) ? (kTableSize - 1) : idx;
+  return idx;
+}
+
 // The march of one ray through one box (VolumePainter.cpp:811-921 + host epilogue :939-955).
 // Returns the layer pixel the reference would store for this box.
-template <bool STATS>
+template <bool STATS, bool SIMPLE, int MODE>
 __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts& fc,
                                             const float4* __restrict__ table, const Ray& ray,
                                             float tmin, float tmax, unsigned& fetches) {
   const float min_x = box.minc[0], min_y = box.minc[1], min_z = box.minc[2];
   const float max_x = box.maxc[0], max_y = box.maxc[1], max_z = box.maxc[2];
   const float step = box.sample_dist;
-  const double* __restrict__ cells = box.cells;
-  const int64_t jstride = box.jstride;
-  const int64_t kstride = box.kstride;
-  const int nx = box.nx, ny = box.ny, nz = box.nz;
+  const char __attribute__((address_space(1)))* cells =
+      (const char __attribute__((address_space(1)))*)box.cells;
 
   float distance = tmin + box.mesh_eps;
   if (distance < 0.0f) distance = box.mesh_eps;
@@ -183,27 +250,11 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     const bool inside = !(pos_x < min_x || pos_x > max_x || pos_y < min_y || pos_y > max_y ||
                           pos_z < min_z || pos_z > max_z);
     if (inside) {
-      const float fx = (pos_x - min_x) / box.dx;
-      const float fy = (pos_y - min_y) / box.dy;
-      const float fz = (pos_z - min_z) / box.dz;
-      int i = static_cast<int>(floorf(fx));
-      int j = static_cast<int>(floorf(fy));
-      int k = static_cast<int>(floorf(fz));
-      i = (i < 0) ? 0 : ((i >= nx) ? nx - 1 : i);
-      j = (j < 0) ? 0 : ((j >= ny) ? ny - 1 : j);
-      k = (k < 0) ? 0 : ((k >= nz) ? nz - 1 : k);
-
-      const double raw = cells[static_cast<int64_t>(i) + static_cast<int64_t>(j) * jstride +
-                               static_cast<int64_t>(k) * kstride];
+      const uint32_t offset =
+          cell_offset<MODE>(box, pos_x - min_x, pos_y - min_y, pos_z - min_z);
+      const double raw = *(GlobalCells)(cells + (static_cast<uint64_t>(offset) << 3));
       if (STATS) ++fetches;
-      float scalar = apply_scalar_transform(raw, fc);
-      if (fc.apply_clip) scalar = saturate_soft_tail(scalar, fc.clip_start);
-      float normalized = (scalar - fc.range_min) * fc.inverse_range;
-      normalized = (normalized < 0.0f) ? 0.0f : normalized;
-      normalized = (normalized > 1.0f) ? 1.0f : normalized;
-      int idx = static_cast<int>(normalized * 255.0f);
-      idx = (idx < 0) ? 0 : idx;
-      idx = (idx > kTableSize - 1) ? (kTableSize - 1) : idx;
+      const int idx = table_index<SIMPLE>(raw, fc);
       const float4 sample = table[idx];
       const float alpha = sample.w * (1.0f - acc_a);
       acc_r += sample.x * alpha;
@@ -253,7 +304,7 @@ __device__ __forceinline__ int64_t send_offset(int64_t p, int run, int n_runs, i
   return (static_cast<int64_t>(n_runs) * begin + static_cast<int64_t>(run) * len + (p - begin)) * 5;
 }
 
-template <bool STATS>
+template <bool STATS, bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
@@ -329,8 +380,15 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
       }
       if (!__builtin_amdgcn_ballot_w64(hit)) continue;  // whole wave missed or terminated
       if (hit) {
-        const Layer5 layer = march_box<STATS>(box, fc, lds_tables + box.lut * kTableSize, ray,
-                                              tmin, tmax, fetches);
+        const float4* table = lds_tables + box.lut * kTableSize;
+        Layer5 layer;
+        if (box.index_mode == kPow2Multiply) {  // wave-uniform
+          layer = march_box<STATS, SIMPLE, kPow2Multiply>(box, fc, table, ray, tmin, tmax, fetches);
+        } else if (box.index_mode == kReciprocal) {
+          layer = march_box<STATS, SIMPLE, kReciprocal>(box, fc, table, ray, tmin, tmax, fetches);
+        } else {
+          layer = march_box<STATS, SIMPLE, kExactDivide>(box, fc, table, ray, tmin, tmax, fetches);
+        }
         acc = blend_depthsort(acc, layer);
       }
     }
@@ -621,17 +679,26 @@ int launch_render_runs(const RenderLaunch& L, void* stream_v) {
   const unsigned group = kSuperTileTiles * kXcds;
   const unsigned blocks = ((padded + group - 1) / group) * group;
   const size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
-  if (L.samples_out != nullptr) {
-    hipLaunchKernelGGL(render_runs_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
-                       stream, L.consts, L.boxes_dev, L.tables_dev, L.n_tables, L.order_dev,
-                       L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded, L.out_layers,
-                       L.samples_out);
+  const FrameConsts& fc = L.consts;
+  // the standard API path (normalise on, scalarRange {0,1}, no log, no soft clip)
+  const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
+                      fc.inverse_range == 1.0f;
+  const bool stats = L.samples_out != nullptr;
+#define AVR_LAUNCH(STATS, SIMPLE)                                                                \
+  hipLaunchKernelGGL((render_runs_kernel<STATS, SIMPLE>), dim3(blocks), dim3(kBlockThreads),     \
+                     lds_bytes, stream, L.consts, L.boxes_dev, L.tables_dev, L.n_tables,         \
+                     L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded, \
+                     L.out_layers, L.samples_out)
+  if (stats && simple) {
+    AVR_LAUNCH(true, true);
+  } else if (stats) {
+    AVR_LAUNCH(true, false);
+  } else if (simple) {
+    AVR_LAUNCH(false, true);
   } else {
-    hipLaunchKernelGGL(render_runs_kernel<false>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
-                       stream, L.consts, L.boxes_dev, L.tables_dev, L.n_tables, L.order_dev,
-                       L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded, L.out_layers,
-                       L.samples_out);
+    AVR_LAUNCH(false, false);
   }
+#undef AVR_LAUNCH
   return check_launch("render_runs_kernel");
 }
 
