@@ -71,7 +71,9 @@ struct avr_context {
   hipStream_t stream = nullptr;
   hipEvent_t staged = nullptr;   // recorded after the last upload that read the pinned mirrors
   bool staged_pending = false;
-  avr::StagedBuffer boxes, tables, order, run_end, slices;
+  avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin;
+  void* classified = nullptr;      // grow-only buffer of the frame's classified volume
+  size_t classified_capacity = 0;
 
   void wait_staging() {
     if (staged_pending) {
@@ -159,7 +161,18 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
   ctx->upload(ctx->tables, plan.tables.data(), plan.tables.size() * sizeof(float));
   ctx->upload(ctx->order, box_order, static_cast<size_t>(n_order) * sizeof(int32_t));
   ctx->upload(ctx->run_end, run_end, static_cast<size_t>(n_runs) * sizeof(int32_t));
+  ctx->upload(ctx->tile_begin, plan.classify_tile_begin.data(),
+              plan.classify_tile_begin.size() * sizeof(uint32_t));
   ctx->mark_staging();
+  if (plan.classified_bytes > ctx->classified_capacity) {
+    // grow-only; a frame of the same scene never reallocates
+    avr::hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (ctx->classified != nullptr) (void)hipFree(ctx->classified);
+    ctx->classified = nullptr;
+    ctx->classified_capacity = 0;
+    avr::hip_check(hipMalloc(&ctx->classified, plan.classified_bytes), "hipMalloc(classified)");
+    ctx->classified_capacity = plan.classified_bytes;
+  }
 
   avr::RenderLaunch launch;
   launch.consts = plan.consts;
@@ -173,6 +186,10 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
   launch.n_pieces = n_pieces;
   launch.out_layers = out_layers;
   launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
+  launch.classified = static_cast<uint8_t*>(ctx->classified);
+  launch.tile_begin_dev = static_cast<const uint32_t*>(ctx->tile_begin.dev());
+  launch.n_boxes = n_boxes;
+  launch.n_classify_tiles = plan.classify_tile_begin.back();
   return avr::launch_render_runs(launch, ctx->stream);
 }
 
@@ -221,6 +238,8 @@ void avr_context_destroy(avr_context* ctx) {
   ctx->order.release();
   ctx->run_end.release();
   ctx->slices.release();
+  ctx->tile_begin.release();
+  if (ctx->classified != nullptr) (void)hipFree(ctx->classified);
   if (ctx->staged != nullptr) (void)hipEventDestroy(ctx->staged);
   if (ctx->own_stream != nullptr) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -565,12 +565,17 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
   plan->boxes.assign(static_cast<std::size_t>(n_boxes), BoxDev{});
   plan->tables.clear();
   plan->n_tables = 0;
+  plan->classify_tile_begin.assign(static_cast<std::size_t>(n_boxes) + 1, 0u);
+  plan->classified_bytes = 0;
   std::map<uint32_t, int> table_of_factor;  // normalization factor bits -> table slot
 
   for (int b = 0; b < n_boxes; ++b) {
     const avr_box& box = boxes[b];
     BoxDev& dev = plan->boxes[static_cast<std::size_t>(b)];
     std::memset(&dev, 0, sizeof(dev));
+    dev.cls_offset = plan->classified_bytes;
+    plan->classify_tile_begin[static_cast<std::size_t>(b) + 1] =
+        plan->classify_tile_begin[static_cast<std::size_t>(b)];
 
     float step = 0.0f, factor = 0.0f, alpha_scale = 0.0f;
     box_sampling(box, params, &step, &factor, &alpha_scale);
@@ -616,6 +621,17 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
     }
     dev.jstride = static_cast<int32_t>(box.jstride);
     dev.kstride = static_cast<int32_t>(box.kstride);
+    {
+      const uint64_t bricks_x = static_cast<uint64_t>((dev.nx + kBrickX - 1) / kBrickX);
+      const uint64_t bricks_y = static_cast<uint64_t>((dev.ny + kBrickY - 1) / kBrickY);
+      const uint64_t bricks_z = static_cast<uint64_t>((dev.nz + kBrickZ - 1) / kBrickZ);
+      const uint64_t chunks = static_cast<uint64_t>((dev.nx + kClassifyChunk - 1) / kClassifyChunk);
+      const uint64_t tiles = bricks_y * bricks_z * chunks;
+      const uint64_t total_tiles = plan->classify_tile_begin[static_cast<std::size_t>(b)] + tiles;
+      if (total_tiles >= (uint64_t{1} << 31)) throw std::invalid_argument("scene has too many cells");
+      plan->classify_tile_begin[static_cast<std::size_t>(b) + 1] = static_cast<uint32_t>(total_tiles);
+      plan->classified_bytes += bricks_x * bricks_y * bricks_z * kBrickBytes;
+    }
 
     dev.dx = (dev.maxc[0] - dev.minc[0]) / static_cast<float>(dev.nx);
     dev.dy = (dev.maxc[1] - dev.minc[1]) / static_cast<float>(dev.ny);

@@ -41,7 +41,8 @@ struct alignas(16) BoxDev {
   int32_t kstride;
   float inv_dx, inv_dy, inv_dz;  // RN(1 / dx)
   float near_tol;         // kReciprocal: |q - rint(q)| <= near_tol sends the sample to the exact divide
-  int32_t pad_[3];
+  int32_t pad_;
+  uint64_t cls_offset;    // byte offset of this box's classified bricklets in the frame's buffer
 };
 static_assert(sizeof(BoxDev) == 128, "BoxDev must stay one 128-byte record");
 
@@ -56,12 +57,19 @@ struct FrameConsts {
   double positive_floor, norm_min, inv_norm_span;
 };
 
+// Classified volume: every cell's transfer-function table index (uint8) in 128-byte bricklets
+// of 8 x 4 x 4 cells (x fastest inside a bricklet; bricklets x-fastest inside the box).
+constexpr int kBrickX = 8, kBrickY = 4, kBrickZ = 4, kBrickBytes = 128;
+constexpr int kClassifyChunk = 128;  // cells of one x-row handled by one classify workgroup
+
 // Host results for one frame over a list of boxes.
 struct FramePlan {
   FrameConsts consts;
   std::vector<BoxDev> boxes;        // same order as the input boxes
   std::vector<float> tables;        // n_tables * 1024 floats
   int n_tables = 0;
+  std::vector<uint32_t> classify_tile_begin;  // n_boxes + 1: prefix sum of classify workgroups
+  uint64_t classified_bytes = 0;              // size of the frame's classified buffer
 };
 
 // ---- host prologue (avr_host.cpp) ---------------------------------------------------------
@@ -89,7 +97,12 @@ struct RenderLaunch {
   int n_order, n_runs, n_pieces;
   float* out_layers;
   unsigned long long* samples_out;  // may be null
+  uint8_t* classified;              // frame's classified buffer (FramePlan::classified_bytes)
+  const uint32_t* tile_begin_dev;   // n_boxes + 1 prefix of classify workgroups
+  int n_boxes;
+  uint32_t n_classify_tiles;
 };
+// classify pass (cells -> table indices) followed by the march, both on `stream`
 int launch_render_runs(const RenderLaunch& launch, void* stream);
 int launch_blend(int kind, const void* top, const void* bottom, void* out, int64_t n, void* stream);
 int launch_blend_regions(int kind, const void* top, int64_t tb, int64_t te, const void* bottom,

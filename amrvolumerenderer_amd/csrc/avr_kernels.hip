@@ -153,12 +153,26 @@ __device__ __forceinline__ void slab_axis(float origin, float direction, float i
   tmax = (tmax < t2) ? tmax : t2;
 }
 
+// Byte offset of cell (i, j, k) inside a box's classified volume: 128-byte bricklets of
+// 8 x 4 x 4 cells, so that the cells a bundle of neighbouring rays touches over several steps
+// share cache lines in all three directions (an x-fastest row would only help along x).
+__device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, int bricks_x,
+                                                    int bricks_y) {
+  const uint32_t brick = (static_cast<uint32_t>(k >> 2) * static_cast<uint32_t>(bricks_y) +
+                          static_cast<uint32_t>(j >> 2)) * static_cast<uint32_t>(bricks_x) +
+                         static_cast<uint32_t>(i >> 3);
+  const uint32_t within = (static_cast<uint32_t>(k & 3) << 5) | (static_cast<uint32_t>(j & 3) << 3) |
+                          static_cast<uint32_t>(i & 7);
+  return (brick << 7) | within;
+}
+
 // Cell indices of an inside sample: the reference's clamp(int(floor((pos - min) / d)), 0, n - 1)
-// per axis (VolumePainter.cpp:846-867), as the linear element offset i + j*jstride + k*kstride.
-// `fx` = pos - min >= 0 for an inside sample, so truncation equals floor and only the upper
-// clamp can bind on the multiply paths; the exact-divide path restates the reference literally.
+// per axis (VolumePainter.cpp:846-867).  `fx` = pos - min >= 0 for an inside sample, so
+// truncation equals floor and only the upper clamp can bind on the multiply paths; the
+// exact-divide path restates the reference literally.
 template <int MODE>
-__device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, float fx, float fy, float fz) {
+__device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, int bricks_x, int bricks_y,
+                                                float fx, float fy, float fz) {
   int i = 0, j = 0, k = 0;
   bool exact = (MODE == kExactDivide);
   if (MODE != kExactDivide) {
@@ -191,8 +205,7 @@ __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, float fx, flo
     j = ej;
     k = ek;
   }
-  return static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * static_cast<uint32_t>(box.jstride) +
-         static_cast<uint32_t>(k) * static_cast<uint32_t>(box.kstride);
+  return bricklet_offset(i, j, k, bricks_x, bricks_y);
 }
 
 typedef const double __attribute__((address_space(1))) * GlobalCells;
@@ -224,15 +237,18 @@ __device__ __forceinline__ int table_index(double raw, const FrameConsts& fc) {
 
 // The march of one ray through one box (VolumePainter.cpp:811-921 + host epilogue :939-955).
 // Returns the layer pixel the reference would store for this box.
-template <bool STATS, bool SIMPLE, int MODE>
+template <bool STATS, int MODE>
 __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts& fc,
+                                            const uint8_t* __restrict__ classified,
                                             const float4* __restrict__ table, const Ray& ray,
                                             float tmin, float tmax, unsigned& fetches) {
   const float min_x = box.minc[0], min_y = box.minc[1], min_z = box.minc[2];
   const float max_x = box.maxc[0], max_y = box.maxc[1], max_z = box.maxc[2];
   const float step = box.sample_dist;
-  const char __attribute__((address_space(1)))* cells =
-      (const char __attribute__((address_space(1)))*)box.cells;
+  const uint8_t __attribute__((address_space(1)))* cells =
+      (const uint8_t __attribute__((address_space(1)))*)(classified + box.cls_offset);
+  const int bricks_x = (box.nx + kBrickX - 1) >> 3;
+  const int bricks_y = (box.ny + kBrickY - 1) >> 2;
 
   float distance = tmin + box.mesh_eps;
   if (distance < 0.0f) distance = box.mesh_eps;
@@ -250,11 +266,12 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     const bool inside = !(pos_x < min_x || pos_x > max_x || pos_y < min_y || pos_y > max_y ||
                           pos_z < min_z || pos_z > max_z);
     if (inside) {
-      const uint32_t offset =
-          cell_offset<MODE>(box, pos_x - min_x, pos_y - min_y, pos_z - min_z);
-      const double raw = *(GlobalCells)(cells + (static_cast<uint64_t>(offset) << 3));
+      const uint32_t offset = cell_offset<MODE>(box, bricks_x, bricks_y, pos_x - min_x,
+                                                pos_y - min_y, pos_z - min_z);
+      // the cell's transfer-function table index, computed from the f64 cell value by the
+      // classify pass of this frame (same arithmetic as VolumePainter.cpp:870-883)
+      const int idx = cells[offset];
       if (STATS) ++fetches;
-      const int idx = table_index<SIMPLE>(raw, fc);
       const float4 sample = table[idx];
       const float alpha = sample.w * (1.0f - acc_a);
       acc_r += sample.x * alpha;
@@ -304,9 +321,10 @@ __device__ __forceinline__ int64_t send_offset(int64_t p, int run, int n_runs, i
   return (static_cast<int64_t>(n_runs) * begin + static_cast<int64_t>(run) * len + (p - begin)) * 5;
 }
 
-template <bool STATS, bool SIMPLE>
+template <bool STATS>
 __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
-    const FrameConsts fc, const BoxDev* __restrict__ boxes, const float* __restrict__ tables,
+    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+    const uint8_t* __restrict__ classified, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
     const int n_runs, const int n_pieces, const int tiles_x, const int tiles_y,
     const unsigned padded_tiles, float* __restrict__ out, unsigned long long* samples_out) {
@@ -383,11 +401,14 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
         const float4* table = lds_tables + box.lut * kTableSize;
         Layer5 layer;
         if (box.index_mode == kPow2Multiply) {  // wave-uniform
-          layer = march_box<STATS, SIMPLE, kPow2Multiply>(box, fc, table, ray, tmin, tmax, fetches);
+          layer = march_box<STATS, kPow2Multiply>(box, fc, classified, table, ray, tmin, tmax,
+                                                  fetches);
         } else if (box.index_mode == kReciprocal) {
-          layer = march_box<STATS, SIMPLE, kReciprocal>(box, fc, table, ray, tmin, tmax, fetches);
+          layer = march_box<STATS, kReciprocal>(box, fc, classified, table, ray, tmin, tmax,
+                                                fetches);
         } else {
-          layer = march_box<STATS, SIMPLE, kExactDivide>(box, fc, table, ray, tmin, tmax, fetches);
+          layer = march_box<STATS, kExactDivide>(box, fc, classified, table, ray, tmin, tmax,
+                                                 fetches);
         }
         acc = blend_depthsort(acc, layer);
       }
@@ -408,6 +429,82 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
       total += __shfl_down(total, offset, 64);
     }
     if (lane == 0 && total != 0) atomicAdd(samples_out, total);
+  }
+}
+
+// ---- classify pass ---------------------------------------------------------------------------
+// Streams every f64 cell of the frame's boxes once (coalesced rows, the HBM-bound part of the
+// frame) and stores its transfer-function table index -- the value VolumePainter.cpp:870-883
+// derives per SAMPLE is a pure function of the cell, so it is derived once per CELL here -- as
+// one byte in 8 x 4 x 4 bricklets.  One workgroup = 4 k-planes x 4 j-rows x 128 cells of x:
+// 16 rows of 1 KiB in, 16 complete bricklets (2 KiB, contiguous) out through LDS.
+template <bool SIMPLE>
+__global__ __launch_bounds__(kBlockThreads) void classify_kernel(
+    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+    const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified) {
+  __shared__ uint32_t staged[16 * kBrickBytes / 4];  // 16 bricklets
+
+  // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
+  const uint32_t tile = blockIdx.x;
+  int lo = 0, hi = n_boxes;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_begin[mid] <= tile) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const BoxDev& box = boxes[lo];
+  const int nx = box.nx, ny = box.ny, nz = box.nz;
+  const int bricks_x = (nx + kBrickX - 1) >> 3;
+  const int bricks_y = (ny + kBrickY - 1) >> 2;
+  const int chunks = (nx + kClassifyChunk - 1) / kClassifyChunk;
+  uint32_t local = tile - tile_begin[lo];
+  const int chunk = static_cast<int>(local % static_cast<uint32_t>(chunks));
+  local /= static_cast<uint32_t>(chunks);
+  const int bj = static_cast<int>(local % static_cast<uint32_t>(bricks_y));
+  const int bk = static_cast<int>(local / static_cast<uint32_t>(bricks_y));
+
+  const double __attribute__((address_space(1)))* cells =
+      (const double __attribute__((address_space(1)))*)box.cells;
+  const int t = static_cast<int>(threadIdx.x);
+  const int xi = t & 127;              // cell inside the 128-cell chunk
+  const int i = chunk * kClassifyChunk + xi;
+#pragma unroll
+  for (int pass = 0; pass < 8; ++pass) {
+    const int row = pass * 2 + (t >> 7);  // 0..15 = kk * 4 + jj
+    const int j = bj * kBrickY + (row & 3);
+    const int k = bk * kBrickZ + (row >> 2);
+    uint32_t idx = 0;
+    if (i < nx && j < ny && k < nz) {
+      const double raw = cells[static_cast<uint32_t>(i) +
+                               static_cast<uint32_t>(j) * static_cast<uint32_t>(box.jstride) +
+                               static_cast<uint32_t>(k) * static_cast<uint32_t>(box.kstride)];
+      idx = static_cast<uint32_t>(table_index<SIMPLE>(raw, fc));
+    }
+    // pack the bytes of 4 neighbouring lanes (cells i..i+3 of one row) into one dword
+    uint32_t packed = idx << (8 * (t & 3));
+    packed |= static_cast<uint32_t>(
+        __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0xB1, 0xF, 0xF, false));
+    packed |= static_cast<uint32_t>(
+        __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0x4E, 0xF, 0xF, false));
+    if ((t & 3) == 0) {
+      // bricklet (xi >> 3) of the chunk, row `row`, bytes (xi & 7) .. +3
+      staged[(xi >> 3) * (kBrickBytes / 4) + row * 2 + ((xi & 7) >> 2)] = packed;
+    }
+  }
+  __syncthreads();
+  // 16 complete bricklets, contiguous in the box's classified volume
+  const int first_brick_x = chunk * (kClassifyChunk / kBrickX);
+  const int bricks_here = (bricks_x - first_brick_x < 16) ? (bricks_x - first_brick_x) : 16;
+  const uint64_t out_base =
+      box.cls_offset + ((static_cast<uint64_t>(bk) * static_cast<uint64_t>(bricks_y) +
+                         static_cast<uint64_t>(bj)) * static_cast<uint64_t>(bricks_x) +
+                        static_cast<uint64_t>(first_brick_x)) * kBrickBytes;
+  if (t * 8 < bricks_here * kBrickBytes) {
+    const uint2 v = reinterpret_cast<const uint2*>(staged)[t];
+    *reinterpret_cast<uint2*>(classified + out_base + static_cast<uint64_t>(t) * 8) = v;
   }
 }
 
@@ -683,22 +780,28 @@ int launch_render_runs(const RenderLaunch& L, void* stream_v) {
   // the standard API path (normalise on, scalarRange {0,1}, no log, no soft clip)
   const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
                       fc.inverse_range == 1.0f;
-  const bool stats = L.samples_out != nullptr;
-#define AVR_LAUNCH(STATS, SIMPLE)                                                                \
-  hipLaunchKernelGGL((render_runs_kernel<STATS, SIMPLE>), dim3(blocks), dim3(kBlockThreads),     \
-                     lds_bytes, stream, L.consts, L.boxes_dev, L.tables_dev, L.n_tables,         \
-                     L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded, \
-                     L.out_layers, L.samples_out)
-  if (stats && simple) {
-    AVR_LAUNCH(true, true);
-  } else if (stats) {
-    AVR_LAUNCH(true, false);
-  } else if (simple) {
-    AVR_LAUNCH(false, true);
-  } else {
-    AVR_LAUNCH(false, false);
+  if (L.n_classify_tiles > 0) {
+    if (simple) {
+      hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
+                         stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
+    } else {
+      hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
+                         stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
+    }
+    const int status = check_launch("classify_kernel");
+    if (status != AVR_OK) return status;
   }
-#undef AVR_LAUNCH
+  if (L.samples_out != nullptr) {
+    hipLaunchKernelGGL(render_runs_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
+                       stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
+                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded,
+                       L.out_layers, L.samples_out);
+  } else {
+    hipLaunchKernelGGL(render_runs_kernel<false>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
+                       stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
+                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded,
+                       L.out_layers, L.samples_out);
+  }
   return check_launch("render_runs_kernel");
 }
 
