@@ -71,7 +71,7 @@ struct avr_context {
   hipStream_t stream = nullptr;
   hipEvent_t staged = nullptr;   // recorded after the last upload that read the pinned mirrors
   bool staged_pending = false;
-  avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin;
+  avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin, supertiles;
   void* classified = nullptr;      // grow-only buffer of the frame's classified volume
   size_t classified_capacity = 0;
 
@@ -163,6 +163,8 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
   ctx->upload(ctx->run_end, run_end, static_cast<size_t>(n_runs) * sizeof(int32_t));
   ctx->upload(ctx->tile_begin, plan.classify_tile_begin.data(),
               plan.classify_tile_begin.size() * sizeof(uint32_t));
+  ctx->upload(ctx->supertiles, plan.supertile_order.data(),
+              plan.supertile_order.size() * sizeof(uint32_t));
   ctx->mark_staging();
   if (plan.classified_bytes > ctx->classified_capacity) {
     // grow-only; a frame of the same scene never reallocates
@@ -190,6 +192,7 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
   launch.tile_begin_dev = static_cast<const uint32_t*>(ctx->tile_begin.dev());
   launch.n_boxes = n_boxes;
   launch.n_classify_tiles = plan.classify_tile_begin.back();
+  launch.supertile_order_dev = static_cast<const uint32_t*>(ctx->supertiles.dev());
   return avr::launch_render_runs(launch, ctx->stream);
 }
 
@@ -239,6 +242,7 @@ void avr_context_destroy(avr_context* ctx) {
   ctx->run_end.release();
   ctx->slices.release();
   ctx->tile_begin.release();
+  ctx->supertiles.release();
   if (ctx->classified != nullptr) (void)hipFree(ctx->classified);
   if (ctx->staged != nullptr) (void)hipEventDestroy(ctx->staged);
   if (ctx->own_stream != nullptr) (void)hipStreamDestroy(ctx->own_stream);

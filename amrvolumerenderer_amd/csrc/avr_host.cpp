@@ -491,6 +491,66 @@ float reference_sample_distance(const avr_box* boxes, int n_boxes, const double 
   return std::max(coarsest * 0.5f, 1e-5f);
 }
 
+uint32_t supertile_slots(int width, int height) {
+  const int tiles_x = (width + kTile - 1) / kTile;
+  const int tiles_y = (height + kTile - 1) / kTile;
+  uint32_t side = 1;
+  while (static_cast<int>(side) < std::max(tiles_x, tiles_y)) side <<= 1;
+  const uint32_t padded_tiles = side * side;  // Morton range covering the tile grid
+  const uint32_t slots = (padded_tiles + kSuperTileTiles - 1) / kSuperTileTiles;
+  return ((slots + kXcds - 1) / kXcds) * kXcds;
+}
+
+namespace {
+
+// Morton index of super-tile (sx, sy): the tile sequence number of its first tile / 64.
+uint32_t interleave16(uint32_t v) {
+  v &= 0xffffu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// Orders the screen super-tiles by an estimate of their march cost (rays x samples per ray of
+// the boxes projecting onto them), most expensive first.  The order only decides WHEN a
+// workgroup runs (heavy ones first, so the cheap ones fill the tail), never what it computes.
+void order_supertiles(const FramePlan& plan, std::vector<uint32_t>* order) {
+  const FrameConsts& fc = plan.consts;
+  const uint32_t slots = supertile_slots(fc.width, fc.height);
+  const int span = kTile * kSuperTileSide;  // pixels per super-tile side
+  const int sx_count = (fc.width + span - 1) / span;
+  const int sy_count = (fc.height + span - 1) / span;
+  std::vector<double> cost(slots, 0.0);
+  for (const BoxDev& box : plan.boxes) {
+    if (box.rect[2] < box.rect[0] || box.rect[3] < box.rect[1]) continue;
+    const double ex = static_cast<double>(box.maxc[0]) - box.minc[0];
+    const double ey = static_cast<double>(box.maxc[1]) - box.minc[1];
+    const double ez = static_cast<double>(box.maxc[2]) - box.minc[2];
+    const double steps = std::sqrt(ex * ex + ey * ey + ez * ez) /
+                         std::max(static_cast<double>(box.sample_dist), 1e-30);
+    if (!std::isfinite(steps)) continue;
+    for (int sy = box.rect[1] / span; sy <= box.rect[3] / span && sy < sy_count; ++sy) {
+      for (int sx = box.rect[0] / span; sx <= box.rect[2] / span && sx < sx_count; ++sx) {
+        const int x0 = std::max(box.rect[0], sx * span), x1 = std::min(box.rect[2], sx * span + span - 1);
+        const int y0 = std::max(box.rect[1], sy * span), y1 = std::min(box.rect[3], sy * span + span - 1);
+        const uint32_t slot = (interleave16(static_cast<uint32_t>(sx)) |
+                               (interleave16(static_cast<uint32_t>(sy)) << 1));
+        if (slot < slots && x1 >= x0 && y1 >= y0) {
+          cost[slot] += steps * static_cast<double>(x1 - x0 + 1) * static_cast<double>(y1 - y0 + 1);
+        }
+      }
+    }
+  }
+  order->resize(slots);
+  for (uint32_t i = 0; i < slots; ++i) (*order)[i] = i;
+  std::stable_sort(order->begin(), order->end(),
+                   [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+}
+
+}  // namespace
+
 int layer_order(const float* hints, const int32_t* owner, const int32_t* local_index, int n_layers,
                 int32_t* order_out, int32_t* run_end_out) {
   std::vector<int32_t> ids(static_cast<std::size_t>(std::max(n_layers, 0)));
@@ -660,6 +720,7 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
     dev.mesh_eps = std::sqrt(ex * ex + ey * ey + ez * ez) * 0.0001f;
     screen_rect(box, camera, basis, fc, dev.rect);
   }
+  order_supertiles(*plan, &plan->supertile_order);
 }
 
 }  // namespace avr

@@ -70,7 +70,17 @@ struct FramePlan {
   int n_tables = 0;
   std::vector<uint32_t> classify_tile_begin;  // n_boxes + 1: prefix sum of classify workgroups
   uint64_t classified_bytes = 0;              // size of the frame's classified buffer
+  std::vector<uint32_t> supertile_order;      // screen super-tiles, most expensive first
 };
+
+// Screen tiling of the march kernel: workgroup = 16 x 16 pixels, super-tile = 8 x 8 workgroups
+// (Morton order inside), super-tiles dealt round-robin to the 8 XCDs in `supertile_order`.
+constexpr int kTile = 16;
+constexpr int kSuperTileSide = 8;
+constexpr int kSuperTileTiles = kSuperTileSide * kSuperTileSide;
+constexpr int kXcds = 8;
+// Number of super-tile slots of a w x h image (multiple of kXcds).
+uint32_t supertile_slots(int width, int height);
 
 // ---- host prologue (avr_host.cpp) ---------------------------------------------------------
 void build_color_table(float alpha_scale, float normalization_factor, const float scalar_range[2],
@@ -101,6 +111,7 @@ struct RenderLaunch {
   const uint32_t* tile_begin_dev;   // n_boxes + 1 prefix of classify workgroups
   int n_boxes;
   uint32_t n_classify_tiles;
+  const uint32_t* supertile_order_dev;  // supertile_slots(width, height) entries
 };
 // classify pass (cells -> table indices) followed by the march, both on `stream`
 int launch_render_runs(const RenderLaunch& launch, void* stream);

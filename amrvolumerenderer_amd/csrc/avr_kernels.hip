@@ -25,10 +25,7 @@ namespace avr {
 
 namespace {
 
-constexpr int kTile = 16;            // workgroup = 16x16 pixels = 4 waves of 8x8
-constexpr int kBlockThreads = 256;
-constexpr int kSuperTileTiles = 64;  // tiles per Morton super-tile handed to one XCD (128x128 px)
-constexpr int kXcds = 8;
+constexpr int kBlockThreads = 256;  // workgroup = kTile x kTile pixels = 4 waves of 8x8
 
 #define AVR_INF __builtin_huge_valf()
 
@@ -255,6 +252,66 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
 
   float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
 
+#define AVR_INSIDE(x, y, z) \
+  (!((x) < min_x || (x) > max_x || (y) < min_y || (y) > max_y || (z) < min_z || (z) > max_z))
+#define AVR_ACCUMULATE(sample)                          \
+  do {                                                  \
+    const float alpha_ = (sample).w * (1.0f - acc_a);   \
+    acc_r += (sample).x * alpha_;                       \
+    acc_g += (sample).y * alpha_;                       \
+    acc_b += (sample).z * alpha_;                       \
+    acc_a += alpha_;                                    \
+  } while (0)
+
+  // ---- interior steps without the per-sample inside test ------------------------------------
+  // pos(d) = fl(o + fl(dir * d)) is monotone in d on every axis (products and sums of floats
+  // round monotonically), so if the positions at `distance` and at `safe_end` are both inside
+  // the box, every sampled position with distance <= d < safe_end is inside as well and the
+  // reference's inside test (:821-825, :838) is known to pass.  Steps from safe_end on (and
+  // whole rays whose end points fail the test, e.g. grazing rays) take the general loop below.
+  const float safe_end = tmax - (step + step);
+  bool interior = false;
+  if (distance < safe_end) {
+    const float ax = ray.ox + ray.dx * distance, ay = ray.oy + ray.dy * distance,
+                az = ray.oz + ray.dz * distance;
+    const float bx = ray.ox + ray.dx * safe_end, by = ray.oy + ray.dy * safe_end,
+                bz = ray.oz + ray.dz * safe_end;
+    interior = AVR_INSIDE(ax, ay, az) && AVR_INSIDE(bx, by, bz);
+  }
+  if (interior) {
+    // two steps per trip: both cell bytes and both table entries are requested before the
+    // first is consumed; the second sample is accumulated only if the reference's loop
+    // condition (distance < tmax && accumA < 1) still holds after the first
+    while (distance < safe_end && acc_a < 1.0f) {
+      const float d2 = distance + step;
+      const bool two = d2 < safe_end;
+      const float p1x = ray.ox + ray.dx * distance, p1y = ray.oy + ray.dy * distance,
+                  p1z = ray.oz + ray.dz * distance;
+      const uint32_t off1 =
+          cell_offset<MODE>(box, bricks_x, bricks_y, p1x - min_x, p1y - min_y, p1z - min_z);
+      const int idx1 = cells[off1];
+      int idx2 = 0;
+      if (two) {
+        const float p2x = ray.ox + ray.dx * d2, p2y = ray.oy + ray.dy * d2,
+                    p2z = ray.oz + ray.dz * d2;
+        const uint32_t off2 =
+            cell_offset<MODE>(box, bricks_x, bricks_y, p2x - min_x, p2y - min_y, p2z - min_z);
+        idx2 = cells[off2];
+      }
+      const float4 s1 = table[idx1];
+      const float4 s2 = table[idx2];
+      AVR_ACCUMULATE(s1);
+      if (STATS) ++fetches;
+      distance = d2;
+      if (two && acc_a < 1.0f) {
+        AVR_ACCUMULATE(s2);
+        if (STATS) ++fetches;
+        distance = d2 + step;
+      }
+    }
+  }
+
+  // ---- general loop --------------------------------------------------------------------------
   float pos_x = ray.ox + ray.dx * distance;
   float pos_y = ray.oy + ray.dy * distance;
   float pos_z = ray.oz + ray.dz * distance;
@@ -263,9 +320,7 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   // do the same thing -- advance without sampling while the position is outside -- so one loop
   // with an inside test reproduces both.
   while (distance < tmax && acc_a < 1.0f) {
-    const bool inside = !(pos_x < min_x || pos_x > max_x || pos_y < min_y || pos_y > max_y ||
-                          pos_z < min_z || pos_z > max_z);
-    if (inside) {
+    if (AVR_INSIDE(pos_x, pos_y, pos_z)) {
       const uint32_t offset = cell_offset<MODE>(box, bricks_x, bricks_y, pos_x - min_x,
                                                 pos_y - min_y, pos_z - min_z);
       // the cell's transfer-function table index, computed from the f64 cell value by the
@@ -273,17 +328,15 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
       const int idx = cells[offset];
       if (STATS) ++fetches;
       const float4 sample = table[idx];
-      const float alpha = sample.w * (1.0f - acc_a);
-      acc_r += sample.x * alpha;
-      acc_g += sample.y * alpha;
-      acc_b += sample.z * alpha;
-      acc_a += alpha;
+      AVR_ACCUMULATE(sample);
     }
     distance += step;
     pos_x = ray.ox + ray.dx * distance;
     pos_y = ray.oy + ray.dy * distance;
     pos_z = ray.oz + ray.dz * distance;
   }
+#undef AVR_INSIDE
+#undef AVR_ACCUMULATE
 
   // device-side clamp (:902-905) then the host epilogue's std::clamp to [0,1] (:944-947)
   acc_r = (acc_r > 1.0f) ? 1.0f : acc_r;
@@ -327,7 +380,8 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
     const int n_runs, const int n_pieces, const int tiles_x, const int tiles_y,
-    const unsigned padded_tiles, float* __restrict__ out, unsigned long long* samples_out) {
+    const uint32_t* __restrict__ supertile_order, float* __restrict__ out,
+    unsigned long long* samples_out) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
 
   // ---- stage the transfer-function tables in LDS (one per AMR sampling level) -------------
@@ -339,15 +393,16 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
   __syncthreads();
 
   // ---- XCD-aware tile assignment ------------------------------------------------------------
-  // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Hand every XCD
-  // whole Morton-ordered super-tiles so that the workgroups resident on one XCD at a time cover
-  // a compact patch of the screen and re-use the same bricks from that XCD's L2.
+  // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Every XCD gets
+  // whole super-tiles (8 x 8 workgroups in Morton order), so the workgroups resident on one
+  // XCD at a time cover a compact patch of the screen and re-use the same bricklets from that
+  // XCD's L2; super-tiles are taken in the host's cost order, most expensive first, so the
+  // long rays start early and the cheap tiles fill the tail.
   const unsigned b = blockIdx.x;
   const unsigned xcd = b % kXcds;
   const unsigned within = b / kXcds;
-  const unsigned seq =
-      ((within / kSuperTileTiles) * kXcds + xcd) * kSuperTileTiles + (within % kSuperTileTiles);
-  if (seq >= padded_tiles) return;
+  const unsigned slot = supertile_order[(within / kSuperTileTiles) * kXcds + xcd];
+  const unsigned seq = slot * kSuperTileTiles + (within % kSuperTileTiles);
   const int tile_x = static_cast<int>(compact_bits(seq));
   const int tile_y = static_cast<int>(compact_bits(seq >> 1));
   if (tile_x >= tiles_x || tile_y >= tiles_y) return;
@@ -758,23 +813,13 @@ int check_launch(const char* what) {
   return AVR_OK;
 }
 
-unsigned next_pow2(unsigned v) {
-  unsigned p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
 }  // namespace
 
 int launch_render_runs(const RenderLaunch& L, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const int tiles_x = (L.consts.width + kTile - 1) / kTile;
   const int tiles_y = (L.consts.height + kTile - 1) / kTile;
-  const unsigned side = next_pow2(static_cast<unsigned>(tiles_x > tiles_y ? tiles_x : tiles_y));
-  unsigned padded = side * side;  // Morton range covering the tile grid
-  // round up to whole (super-tile x XCD) groups so every sequence number has a block
-  const unsigned group = kSuperTileTiles * kXcds;
-  const unsigned blocks = ((padded + group - 1) / group) * group;
+  const unsigned blocks = supertile_slots(L.consts.width, L.consts.height) * kSuperTileTiles;
   const size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
   const FrameConsts& fc = L.consts;
   // the standard API path (normalise on, scalarRange {0,1}, no log, no soft clip)
@@ -794,13 +839,13 @@ int launch_render_runs(const RenderLaunch& L, void* stream_v) {
   if (L.samples_out != nullptr) {
     hipLaunchKernelGGL(render_runs_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
                        stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
-                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded,
-                       L.out_layers, L.samples_out);
+                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y,
+                       L.supertile_order_dev, L.out_layers, L.samples_out);
   } else {
     hipLaunchKernelGGL(render_runs_kernel<false>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
                        stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
-                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y, padded,
-                       L.out_layers, L.samples_out);
+                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y,
+                       L.supertile_order_dev, L.out_layers, L.samples_out);
   }
   return check_launch("render_runs_kernel");
 }
