@@ -493,11 +493,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
 // derives per SAMPLE is a pure function of the cell, so it is derived once per CELL here -- as
 // one byte in 8 x 4 x 4 bricklets.  One workgroup = 4 k-planes x 4 j-rows x 128 cells of x:
 // 16 rows of 1 KiB in, 16 complete bricklets (2 KiB, contiguous) out through LDS.
+constexpr int kStagedStride = 34;  // dwords per staged bricklet (32 + 2: conflict-free LDS writes)
+
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified) {
-  __shared__ uint32_t staged[16 * kBrickBytes / 4];  // 16 bricklets
+  __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
 
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
   const uint32_t tile = blockIdx.x;
@@ -523,34 +525,64 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
 
   const double __attribute__((address_space(1)))* cells =
       (const double __attribute__((address_space(1)))*)box.cells;
+  const uint32_t jstride = static_cast<uint32_t>(box.jstride);
+  const uint32_t kstride = static_cast<uint32_t>(box.kstride);
   const int t = static_cast<int>(threadIdx.x);
-  const int xi = t & 127;              // cell inside the 128-cell chunk
-  const int i = chunk * kClassifyChunk + xi;
+  // 16-byte loads (two cells per lane) need every row to start 16-byte aligned
+  const bool paired = ((reinterpret_cast<uintptr_t>(box.cells) & 15u) == 0) &&
+                      ((jstride & 1u) == 0) && ((kstride & 1u) == 0);
+  if (paired) {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const int xi = (t & 63) * 2;  // first of this lane's two cells inside the 128-cell chunk
+    const int i = chunk * kClassifyChunk + xi;
 #pragma unroll
-  for (int pass = 0; pass < 8; ++pass) {
-    const int row = pass * 2 + (t >> 7);  // 0..15 = kk * 4 + jj
-    const int j = bj * kBrickY + (row & 3);
-    const int k = bk * kBrickZ + (row >> 2);
-    uint32_t idx = 0;
-    if (i < nx && j < ny && k < nz) {
-      const double raw = cells[static_cast<uint32_t>(i) +
-                               static_cast<uint32_t>(j) * static_cast<uint32_t>(box.jstride) +
-                               static_cast<uint32_t>(k) * static_cast<uint32_t>(box.kstride)];
-      idx = static_cast<uint32_t>(table_index<SIMPLE>(raw, fc));
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 4 + (t >> 6);  // 0..15 = kk * 4 + jj (one row per wave)
+      const int j = bj * kBrickY + (row & 3);
+      const int k = bk * kBrickZ + (row >> 2);
+      uint32_t two = 0;
+      if (i < nx && j < ny && k < nz) {
+        const uint32_t at = static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
+                            static_cast<uint32_t>(k) * kstride;
+        if (i + 1 < nx) {
+          const double2_t raw =
+              *(const double2_t __attribute__((address_space(1)))*)(cells + at);
+          two = static_cast<uint32_t>(table_index<SIMPLE>(raw.x, fc)) |
+                (static_cast<uint32_t>(table_index<SIMPLE>(raw.y, fc)) << 8);
+        } else {
+          two = static_cast<uint32_t>(table_index<SIMPLE>(cells[at], fc));
+        }
+      }
+      // merge with the neighbouring lane: cells xi .. xi+3 of this row in one dword
+      uint32_t packed = two << (16 * (t & 1));
+      packed |= static_cast<uint32_t>(
+          __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0xB1, 0xF, 0xF, false));
+      if ((t & 1) == 0) staged[(xi >> 3) * kStagedStride + row * 2 + ((xi & 7) >> 2)] = packed;
     }
-    // pack the bytes of 4 neighbouring lanes (cells i..i+3 of one row) into one dword
-    uint32_t packed = idx << (8 * (t & 3));
-    packed |= static_cast<uint32_t>(
-        __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0xB1, 0xF, 0xF, false));
-    packed |= static_cast<uint32_t>(
-        __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0x4E, 0xF, 0xF, false));
-    if ((t & 3) == 0) {
-      // bricklet (xi >> 3) of the chunk, row `row`, bytes (xi & 7) .. +3
-      staged[(xi >> 3) * (kBrickBytes / 4) + row * 2 + ((xi & 7) >> 2)] = packed;
+  } else {
+    const int xi = t & 127;
+    const int i = chunk * kClassifyChunk + xi;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 2 + (t >> 7);
+      const int j = bj * kBrickY + (row & 3);
+      const int k = bk * kBrickZ + (row >> 2);
+      uint32_t idx = 0;
+      if (i < nx && j < ny && k < nz) {
+        const double raw = cells[static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
+                                 static_cast<uint32_t>(k) * kstride];
+        idx = static_cast<uint32_t>(table_index<SIMPLE>(raw, fc));
+      }
+      uint32_t packed = idx << (8 * (t & 3));
+      packed |= static_cast<uint32_t>(
+          __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0xB1, 0xF, 0xF, false));
+      packed |= static_cast<uint32_t>(
+          __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0x4E, 0xF, 0xF, false));
+      if ((t & 3) == 0) staged[(xi >> 3) * kStagedStride + row * 2 + ((xi & 7) >> 2)] = packed;
     }
   }
   __syncthreads();
-  // 16 complete bricklets, contiguous in the box's classified volume
+  // up to 16 complete bricklets, contiguous in the box's classified volume
   const int first_brick_x = chunk * (kClassifyChunk / kBrickX);
   const int bricks_here = (bricks_x - first_brick_x < 16) ? (bricks_x - first_brick_x) : 16;
   const uint64_t out_base =
@@ -558,7 +590,8 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
                          static_cast<uint64_t>(bj)) * static_cast<uint64_t>(bricks_x) +
                         static_cast<uint64_t>(first_brick_x)) * kBrickBytes;
   if (t * 8 < bricks_here * kBrickBytes) {
-    const uint2 v = reinterpret_cast<const uint2*>(staged)[t];
+    const uint2 v =
+        *reinterpret_cast<const uint2*>(&staged[(t >> 4) * kStagedStride + (t & 15) * 2]);
     *reinterpret_cast<uint2*>(classified + out_base + static_cast<uint64_t>(t) * 8) = v;
   }
 }
