@@ -79,6 +79,20 @@ class PaintParams(C.Structure):
     ]
 
 
+class FramePlanInfo(C.Structure):
+    _fields_ = [
+        ("n_ranks", C.c_int32), ("rank", C.c_int32), ("n_runs_total", C.c_int32),
+        ("n_local_runs", C.c_int32), ("n_local_boxes", C.c_int32),
+        ("n_pixels", C.c_int64), ("piece_begin", C.c_int64), ("piece_end", C.c_int64),
+        ("send_floats", C.c_int64), ("recv_floats", C.c_int64),
+    ]
+
+
+class RunInfo(C.Structure):
+    _fields_ = [("owner", C.c_int32), ("local_run", C.c_int32), ("first_layer", C.c_int32),
+                ("n_layers", C.c_int32), ("rect", C.c_int32 * 4)]
+
+
 # name -> (restype, argtypes); every symbol include/avr_hip.h declares.
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -106,6 +120,18 @@ SIGNATURES = {
     "avr_scene_destroy": (None, [_vp]),
     "avr_render_runs": (C.c_int, [_vp, _vp, C.POINTER(PaintParams), C.POINTER(Camera), _ip,
                                    C.c_int, _ip, C.c_int, C.c_int, _vp, _vp]),
+    "avr_frame_plan_create": (C.c_int, [C.POINTER(Box), _ip, C.c_int, C.c_int, C.c_int, _ip,
+                                         C.POINTER(PaintParams), C.POINTER(Camera),
+                                         C.POINTER(_vp)]),
+    "avr_frame_plan_destroy": (None, [_vp]),
+    "avr_frame_plan_get_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),
+    "avr_frame_plan_splits": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "avr_frame_plan_layers": (C.c_int, [_vp, _ip]),
+    "avr_frame_plan_runs": (C.c_int, [_vp, C.POINTER(RunInfo)]),
+    "avr_frame_plan_send_block": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_i64), _ip, _ip]),
+    "avr_frame_plan_recv_block": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _ip, _ip]),
+    "avr_render_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_blend_depthsort_f32x5": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "avr_blend_rgba_f32x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "avr_blend_rgba_u8x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),

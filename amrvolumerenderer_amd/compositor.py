@@ -3,210 +3,174 @@
 Mirrors the reference's Compositor plugin (Common/Compositor.hpp:19-40) and its DirectSend
 implementation for layered images (DirectSend/Base/DirectSendBase.cpp:316-458), redesigned for
 xGMI: instead of one full direct-send round per run (N(N-1) MPI messages each, almost all of
-them empty layers), every rank sends each peer ONE contiguous block holding the peer's pixel
-piece of all of its run layers -- a single all-to-all per frame (RCCL over xGMI through
-torch.distributed; gloo on CPU in the tests) -- and the receiver folds the runs in global order
-with the HIP fold kernel.  Empty layer pixels (0,0,0,0,+inf) are an exact two-sided identity of
-the depth-sort blend, so dropping the non-owners' empty contributions leaves every bit of the
-result unchanged.
+them empty full-frame layers), every rank sends each peer ONE contiguous block holding, for each
+of its runs, only the rows/columns of the run's screen rectangle that fall into the peer's pixel
+piece -- a single all-to-all per frame (RCCL over xGMI through torch.distributed; gloo on CPU in
+the tests) -- and the receiver folds the runs in global order with a HIP kernel.  Empty layer
+pixels (0,0,0,0,+inf) are an exact two-sided identity of the depth-sort blend, so dropping them
+leaves every bit of the result unchanged.
 
-The pure planning part (layer order, runs, piece ranges, split sizes) has no device dependency
-and is what the multi-process CPU tests exercise.
+The plan itself (layer order, runs, rectangles, block offsets, split sizes) is computed by the
+C ABI's avr_frame_plan_* (host only, no GPU needed) identically on every rank.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import runtime
+from . import _capi
+from .types import AmrBox, CameraParameters
 
 
-@dataclass
-class ExchangePlan:
-    """Everything a rank needs to paint its runs and take part in the exchange."""
-    n_ranks: int
-    rank: int
-    n_pixels: int
-    # global layer order: parallel arrays over all layers, sorted by (hint, owner, local index)
-    layer_owner: np.ndarray
-    layer_local_index: np.ndarray
-    # global runs, in order: owner rank and the index of the run among that owner's runs
-    run_owner: List[int]
-    run_local_id: List[int]
-    runs_per_rank: List[int]
-    # this rank's boxes in global order + run ends (input of avr_render_runs)
-    local_order: np.ndarray
-    local_run_end: np.ndarray
-    # position of each rank in the ordered group (piece k belongs to group_order[k])
-    group_order: List[int]
+class FramePlan:
+    """avr_frame_plan: one frame's global layer order, runs and sparse exchange layout."""
 
-    @property
-    def n_local_runs(self) -> int:
-        return int(self.local_run_end.size)
+    def __init__(self, all_boxes: Sequence[AmrBox], params: _capi.PaintParams,
+                 camera: CameraParameters, rank: int = 0, n_ranks: int = 1,
+                 group_order: Optional[Sequence[int]] = None, _box_array=None, _owner_array=None):
+        n = len(all_boxes)
+        # the C arrays can be prepared once per scene and re-used for every frame
+        self._boxes = _box_array if _box_array is not None else make_box_array(all_boxes)
+        self._owner = _owner_array if _owner_array is not None else make_owner_array(all_boxes)
+        group = None
+        if group_order is not None:
+            group = (C.c_int32 * n_ranks)(*[int(g) for g in group_order])
+        ccam = camera.to_c()
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_frame_plan_create(
+            self._boxes, self._owner, n, int(n_ranks), int(rank), group, C.byref(params),
+            C.byref(ccam), C.byref(handle)))
+        self._handle = handle
+        self._params = params  # keeps the colour map alive
+        info = _capi.FramePlanInfo()
+        _capi.check(_capi.lib().avr_frame_plan_get_info(self._handle, C.byref(info)))
+        self.n_ranks = info.n_ranks
+        self.rank = info.rank
+        self.n_runs_total = info.n_runs_total
+        self.n_local_runs = info.n_local_runs
+        self.n_local_boxes = info.n_local_boxes
+        self.n_pixels = info.n_pixels
+        self.piece_begin = info.piece_begin
+        self.piece_end = info.piece_end
+        self.send_floats = info.send_floats
+        self.recv_floats = info.recv_floats
+        self.width = int(params.width)
+        self.height = int(params.height)
+        send = (C.c_int64 * self.n_ranks)()
+        recv = (C.c_int64 * self.n_ranks)()
+        _capi.check(_capi.lib().avr_frame_plan_splits(self._handle, send, recv))
+        self.send_splits = [int(v) for v in send]
+        self.recv_splits = [int(v) for v in recv]
+        order = list(group_order) if group_order is not None else list(range(self.n_ranks))
+        self.group_order = [int(g) for g in order]
+        self.piece_of_rank = [self.group_order.index(r) for r in range(self.n_ranks)]
 
-    def piece_of_rank(self, rank: int) -> int:
-        return self.group_order.index(rank)
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _capi.lib().avr_frame_plan_destroy(self._handle)
+            self._handle = None
 
-    def piece_range(self, piece: int) -> Tuple[int, int]:
-        return runtime.piece_range(self.n_pixels, piece, self.n_ranks)
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
-    def my_piece_range(self) -> Tuple[int, int]:
-        return self.piece_range(self.piece_of_rank(self.rank))
+    # -- inspection (tests, tools) ----------------------------------------------------------
+    def layers(self) -> np.ndarray:
+        """Global layer order: indices into all_boxes."""
+        n = len(self._boxes) if self.n_runs_total else 0
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        _capi.check(_capi.lib().avr_frame_plan_layers(
+            self._handle, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:n] if self.n_runs_total else out[:0]
 
-    # all_to_all_single split sizes, in floats, indexed by PEER RANK
-    def send_splits(self) -> List[int]:
-        sizes = []
-        for peer in range(self.n_ranks):
-            b, e = self.piece_range(self.piece_of_rank(peer))
-            sizes.append(self.n_local_runs * (e - b) * 5)
-        return sizes
+    def runs(self) -> List[_capi.RunInfo]:
+        arr = (_capi.RunInfo * max(self.n_runs_total, 1))()
+        _capi.check(_capi.lib().avr_frame_plan_runs(self._handle, arr))
+        return list(arr)[:self.n_runs_total]
 
-    def recv_splits(self) -> List[int]:
-        b, e = self.my_piece_range()
-        return [self.runs_per_rank[peer] * (e - b) * 5 for peer in range(self.n_ranks)]
+    def send_block(self, peer: int, local_run: int) -> Tuple[int, int, int]:
+        off, first, rows = C.c_int64(), C.c_int32(), C.c_int32()
+        _capi.check(_capi.lib().avr_frame_plan_send_block(self._handle, peer, local_run,
+                                                          C.byref(off), C.byref(first),
+                                                          C.byref(rows)))
+        return off.value, first.value, rows.value
 
-
-def plan_exchange(hints_by_rank: Sequence[Sequence[float]], rank: int, n_pixels: int,
-                  group_order: Optional[Sequence[int]] = None) -> ExchangePlan:
-    """Global order, run grouping and this rank's share (DirectSendBase.cpp:329-410).
-
-    hints_by_rank[r][i] is the depth hint of local layer i of rank r (what the reference
-    all-gathers).  group_order is the visibility-ordered group (identity when None); it only
-    decides which pixel piece each rank ends up holding, never pixel values."""
-    n_ranks = len(hints_by_rank)
-    hints, owner, local_index = [], [], []
-    for r, rank_hints in enumerate(hints_by_rank):
-        for i, h in enumerate(rank_hints):
-            hints.append(h)
-            owner.append(r)
-            local_index.append(i)
-    order, run_end = runtime.layer_order(hints, owner, local_index)
-    owner_a = np.asarray(owner, dtype=np.int32)
-    local_a = np.asarray(local_index, dtype=np.int32)
-    layer_owner = owner_a[order] if order.size else np.zeros(0, np.int32)
-    layer_local = local_a[order] if order.size else np.zeros(0, np.int32)
-
-    run_owner: List[int] = []
-    run_local_id: List[int] = []
-    runs_per_rank = [0] * n_ranks
-    local_order: List[int] = []
-    local_run_end: List[int] = []
-    start = 0
-    for end in run_end.tolist():
-        o = int(layer_owner[start])
-        run_owner.append(o)
-        run_local_id.append(runs_per_rank[o])
-        runs_per_rank[o] += 1
-        if o == rank:
-            local_order.extend(int(v) for v in layer_local[start:end])
-            local_run_end.append(len(local_order))
-        start = end
-    group = list(group_order) if group_order is not None else list(range(n_ranks))
-    if sorted(group) != list(range(n_ranks)):
-        raise ValueError("group_order must be a permutation of the ranks")
-    return ExchangePlan(n_ranks=n_ranks, rank=rank, n_pixels=int(n_pixels),
-                        layer_owner=layer_owner, layer_local_index=layer_local,
-                        run_owner=run_owner, run_local_id=run_local_id,
-                        runs_per_rank=runs_per_rank,
-                        local_order=np.asarray(local_order, dtype=np.int32),
-                        local_run_end=np.asarray(local_run_end, dtype=np.int32),
-                        group_order=group)
+    def recv_block(self, global_run: int) -> Tuple[int, int, int]:
+        off, first, rows = C.c_int64(), C.c_int32(), C.c_int32()
+        _capi.check(_capi.lib().avr_frame_plan_recv_block(self._handle, global_run, C.byref(off),
+                                                          C.byref(first), C.byref(rows)))
+        return off.value, first.value, rows.value
 
 
-def send_block_offset(plan: ExchangePlan, peer: int) -> int:
-    """Offset (floats) of the block for `peer` inside a rank's send-layout buffer written by
-    avr_render_runs with n_pieces = n_ranks: 5 * n_local_runs * piece_begin(piece of peer)."""
-    b, _ = plan.piece_range(plan.piece_of_rank(peer))
-    return 5 * plan.n_local_runs * b
+def make_box_array(all_boxes: Sequence[AmrBox]):
+    return (_capi.Box * max(len(all_boxes), 1))(*[b.to_c() for b in all_boxes])
 
 
-def exchange_permutation(plan: ExchangePlan) -> Optional[List[int]]:
-    """avr_render_runs lays blocks out by PIECE index; all_to_all_single wants them by PEER
-    rank.  With the identity group order both coincide (None)."""
-    if plan.group_order == list(range(plan.n_ranks)):
-        return None
-    return [plan.piece_of_rank(peer) for peer in range(plan.n_ranks)]
-
-
-def slices_in_run_order(plan: ExchangePlan, recv_buffer, piece_len: int):
-    """Views of the received buffer ([src rank][run of src][piece pixel][5]) in global run
-    order -- the operand list of the receiver-side fold (DirectSendBase.cpp:441-445)."""
-    offsets = [0] * plan.n_ranks
-    total = 0
-    for peer in range(plan.n_ranks):
-        offsets[peer] = total
-        total += plan.runs_per_rank[peer] * piece_len * 5
-    out = []
-    for owner, local_id in zip(plan.run_owner, plan.run_local_id):
-        begin = offsets[owner] + local_id * piece_len * 5
-        out.append(recv_buffer[begin:begin + piece_len * 5])
-    return out
+def make_owner_array(all_boxes: Sequence[AmrBox]):
+    return (C.c_int32 * max(len(all_boxes), 1))(*[int(b.owner) for b in all_boxes])
 
 
 class DirectSendCompositor:
-    """compose(): run layers (send layout) -> this rank's fully composited pixel piece.
+    """The exchange + fold + gather of one frame.  `ops` supplies the device work
+    (runtime.Context on a GPU; the CPU tests plug in a stand-in built on the oracle);
+    `process_group` is a torch.distributed group (RCCL "nccl" backend on GPUs)."""
 
-    `process_group` is a torch.distributed group (RCCL "nccl" backend on GPUs); None with a
-    single rank skips the collective."""
-
-    def __init__(self, ctx: "runtime.Context", process_group=None):
-        self.ctx = ctx
+    def __init__(self, ops, process_group=None):
+        self.ops = ops
         self.process_group = process_group
 
-    def exchange(self, plan: ExchangePlan, send_buffer):
+    def exchange(self, plan: FramePlan, send_buffer):
+        """One all-to-all: block for peer s -> rank s."""
         import torch
         import torch.distributed as dist
-        b, e = plan.my_piece_range()
-        piece_len = e - b
         if plan.n_ranks == 1:
-            return send_buffer, piece_len
-        send_splits = plan.send_splits()
-        recv_splits = plan.recv_splits()
-        perm = exchange_permutation(plan)
-        if perm is not None:  # reorder blocks from piece order to peer order
-            chunks = []
-            for peer in range(plan.n_ranks):
-                off = send_block_offset(plan, peer)
-                chunks.append(send_buffer[off:off + send_splits[peer]])
-            send_buffer = torch.cat(chunks)
-        recv = torch.empty(sum(recv_splits), dtype=send_buffer.dtype, device=send_buffer.device)
-        dist.all_to_all_single(recv, send_buffer[:sum(send_splits)], recv_splits, send_splits,
-                               group=self.process_group)
-        return recv, piece_len
+            return send_buffer
+        recv = torch.empty(max(plan.recv_floats, 1), dtype=send_buffer.dtype,
+                           device=send_buffer.device)
+        dist.all_to_all_single(recv[:plan.recv_floats], send_buffer[:plan.send_floats],
+                               plan.recv_splits, plan.send_splits, group=self.process_group)
+        return recv
 
-    def compose(self, plan: ExchangePlan, send_buffer):
-        """Returns (piece tensor [piece_len, 5], piece_begin, piece_end)."""
-        recv, piece_len = self.exchange(plan, send_buffer)
-        slices = slices_in_run_order(plan, recv, piece_len)
-        b, e = plan.my_piece_range()
-        piece = self.ctx.fold_runs(slices, piece_len)
-        return piece, b, e
+    def compose(self, plan: FramePlan, send_buffer, want_rgb8: bool = False):
+        """Returns (piece [piece_len, 5], rgb8 [piece_len, 3] or None)."""
+        recv = self.exchange(plan, send_buffer)
+        return self.ops.fold_plan(plan, recv, want_rgb8)
 
-    def gather(self, plan: ExchangePlan, piece, dst: int = 0):
+    def gather(self, plan: FramePlan, piece, dst: int = 0):
         """ImageFull::Gather (Common/ImageColorOnly.hpp:220-270): pieces concatenated by
-        region begin on rank `dst`; other ranks return None."""
+        region begin on rank `dst`; other ranks return None.  Works for any per-pixel tensor
+        [piece_len, C] (the float image or its RGB8 bytes)."""
         import torch
         import torch.distributed as dist
         if plan.n_ranks == 1:
             return piece
-        lens = []
-        for r in range(plan.n_ranks):
-            b, e = plan.piece_range(plan.piece_of_rank(r))
-            lens.append(e - b)
-        max_len = max(lens)
+        from . import runtime
+        ranges = [runtime.piece_range(plan.n_pixels, k, plan.n_ranks) for k in range(plan.n_ranks)]
+        max_len = max(e - b for b, e in ranges)
         padded = piece
-        if piece.shape[0] != max_len:  # equal-size gather; the last piece is the long one
-            padded = torch.zeros(max_len, 5, dtype=piece.dtype, device=piece.device)
+        if piece.shape[0] != max_len:  # equal-size gather; only the last piece can be longer
+            padded = torch.zeros((max_len,) + tuple(piece.shape[1:]), dtype=piece.dtype,
+                                 device=piece.device)
             padded[:piece.shape[0]] = piece
         if plan.rank == dst:
             parts = [torch.empty_like(padded) for _ in range(plan.n_ranks)]
             dist.gather(padded, parts, dst=dst, group=self.process_group)
-            full = torch.empty(plan.n_pixels, 5, dtype=piece.dtype, device=piece.device)
+            full = torch.empty((plan.n_pixels,) + tuple(piece.shape[1:]), dtype=piece.dtype,
+                               device=piece.device)
+            # rank r holds the piece of its group position
+            info_order = plan_piece_of_rank(plan)
             for r in range(plan.n_ranks):
-                b, e = plan.piece_range(plan.piece_of_rank(r))
+                b, e = ranges[info_order[r]]
                 full[b:e] = parts[r][:e - b]
             return full
         dist.gather(padded, None, dst=dst, group=self.process_group)
         return None
+
+
+def plan_piece_of_rank(plan: FramePlan) -> List[int]:
+    """Piece index held by each rank (its position in the ordered group)."""
+    return plan.piece_of_rank

@@ -3,6 +3,7 @@
 // (avr_kernels.hip) on the context's stream.  No CPU compute fallback exists behind it.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "avr_internal.h"
+#include "avr_plan.h"
 
 namespace avr {
 
@@ -71,7 +73,7 @@ struct avr_context {
   hipStream_t stream = nullptr;
   hipEvent_t staged = nullptr;   // recorded after the last upload that read the pinned mirrors
   bool staged_pending = false;
-  avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin, supertiles;
+  avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin, supertiles, run_rects, run_blocks;
   void* classified = nullptr;      // grow-only buffer of the frame's classified volume
   size_t classified_capacity = 0;
 
@@ -134,9 +136,14 @@ void bind_device(avr_context* ctx) {
 int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
            const avr_scalar_transform& transform, const avr_paint_params& params,
            const avr_camera& camera, const int32_t* box_order, int n_order,
-           const int32_t* run_end, int n_runs, int n_pieces, float* out_layers,
+           const int32_t* run_end, int n_runs, int n_pieces,
+           const std::vector<avr::RunRectDev>& run_rects,
+           const std::vector<avr::RunBlockDev>& run_blocks, float* out_layers,
            uint64_t* samples_out) {
   require(out_layers != nullptr, "null output image");
+  require(run_rects.size() == static_cast<size_t>(std::max(n_runs, 0)) &&
+              run_blocks.size() == static_cast<size_t>(std::max(n_runs, 0)) * n_pieces,
+          "run tables do not match the runs");
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
   require(n_runs == 0 || (run_end != nullptr), "null run_end");
   require(n_order == 0 || (box_order != nullptr), "null box_order");
@@ -165,6 +172,8 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
               plan.classify_tile_begin.size() * sizeof(uint32_t));
   ctx->upload(ctx->supertiles, plan.supertile_order.data(),
               plan.supertile_order.size() * sizeof(uint32_t));
+  ctx->upload(ctx->run_rects, run_rects.data(), run_rects.size() * sizeof(avr::RunRectDev));
+  ctx->upload(ctx->run_blocks, run_blocks.data(), run_blocks.size() * sizeof(avr::RunBlockDev));
   ctx->mark_staging();
   if (plan.classified_bytes > ctx->classified_capacity) {
     // grow-only; a frame of the same scene never reallocates
@@ -186,6 +195,8 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
   launch.n_order = n_order;
   launch.n_runs = n_runs;
   launch.n_pieces = n_pieces;
+  launch.run_rects_dev = static_cast<const avr::RunRectDev*>(ctx->run_rects.dev());
+  launch.run_blocks_dev = static_cast<const avr::RunBlockDev*>(ctx->run_blocks.dev());
   launch.out_layers = out_layers;
   launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
   launch.classified = static_cast<uint8_t*>(ctx->classified);
@@ -243,6 +254,8 @@ void avr_context_destroy(avr_context* ctx) {
   ctx->slices.release();
   ctx->tile_begin.release();
   ctx->supertiles.release();
+  ctx->run_rects.release();
+  ctx->run_blocks.release();
   if (ctx->classified != nullptr) (void)hipFree(ctx->classified);
   if (ctx->staged != nullptr) (void)hipEventDestroy(ctx->staged);
   if (ctx->own_stream != nullptr) (void)hipStreamDestroy(ctx->own_stream);
@@ -347,8 +360,12 @@ int avr_paint_box(avr_context* ctx, const avr_box* box, const avr_scalar_transfo
             "null argument");
     const int32_t order[1] = {0};
     const int32_t run_end[1] = {1};
-    return render(ctx, box, 1, *transform, *params, *camera, order, 1, run_end, 1, 1, out_rgbad,
-                  samples_out);
+    std::vector<avr::RunRectDev> rects;
+    std::vector<avr::RunBlockDev> blocks;
+    require(params->width > 0 && params->height > 0, "image width and height must be positive");
+    avr::dense_run_tables(params->width, params->height, 1, 1, &rects, &blocks);
+    return render(ctx, box, 1, *transform, *params, *camera, order, 1, run_end, 1, 1, rects, blocks,
+                  out_rgbad, samples_out);
   });
 }
 
@@ -375,9 +392,144 @@ int avr_render_runs(avr_context* ctx, const avr_scene* scene, const avr_paint_pa
   return guarded([&]() -> int {
     bind_device(ctx);
     require(scene != nullptr && params != nullptr && camera != nullptr, "null argument");
+    require(n_runs >= 0 && n_pieces >= 1, "invalid run description");
+    require(params->width > 0 && params->height > 0, "image width and height must be positive");
+    std::vector<avr::RunRectDev> rects;
+    std::vector<avr::RunBlockDev> blocks;
+    avr::dense_run_tables(params->width, params->height, n_runs, n_pieces, &rects, &blocks);
     return render(ctx, scene->boxes.data(), static_cast<int>(scene->boxes.size()),
                   scene->transform, *params, *camera, box_order, n_order, run_end, n_runs, n_pieces,
-                  out_layers, samples_out);
+                  rects, blocks, out_layers, samples_out);
+  });
+}
+
+int avr_frame_plan_create(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
+                          int rank, const int32_t* group_order, const avr_paint_params* params,
+                          const avr_camera* camera, avr_frame_plan** out_plan) {
+  return guarded([&]() -> int {
+    require(out_plan != nullptr && params != nullptr && camera != nullptr, "null argument");
+    *out_plan = nullptr;
+    require(params->colormap_count >= 0 && (params->colormap_count == 0 || params->colormap),
+            "invalid color map");
+    auto* plan = new avr_frame_plan();
+    try {
+      avr::build_frame_plan(all_boxes, owner, n_boxes, n_ranks, rank, group_order, *params, *camera,
+                            plan);
+    } catch (...) {
+      delete plan;
+      throw;
+    }
+    *out_plan = plan;
+    return AVR_OK;
+  });
+}
+
+void avr_frame_plan_destroy(avr_frame_plan* plan) { delete plan; }
+
+int avr_frame_plan_get_info(const avr_frame_plan* plan, avr_frame_plan_info* out) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && out != nullptr, "null argument");
+    *out = plan->info;
+    return AVR_OK;
+  });
+}
+
+int avr_frame_plan_splits(const avr_frame_plan* plan, int64_t* send_splits, int64_t* recv_splits) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && send_splits != nullptr && recv_splits != nullptr, "null argument");
+    std::copy(plan->send_splits.begin(), plan->send_splits.end(), send_splits);
+    std::copy(plan->recv_splits.begin(), plan->recv_splits.end(), recv_splits);
+    return AVR_OK;
+  });
+}
+
+int avr_frame_plan_layers(const avr_frame_plan* plan, int32_t* layer_box) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && (plan->layer_box.empty() || layer_box != nullptr), "null argument");
+    std::copy(plan->layer_box.begin(), plan->layer_box.end(), layer_box);
+    return AVR_OK;
+  });
+}
+
+int avr_frame_plan_runs(const avr_frame_plan* plan, avr_run_info* runs) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && (plan->runs.empty() || runs != nullptr), "null argument");
+    std::copy(plan->runs.begin(), plan->runs.end(), runs);
+    return AVR_OK;
+  });
+}
+
+int avr_frame_plan_send_block(const avr_frame_plan* plan, int peer, int local_run, int64_t* offset,
+                              int32_t* first_row, int32_t* n_rows) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && offset != nullptr && first_row != nullptr && n_rows != nullptr,
+            "null argument");
+    require(peer >= 0 && peer < plan->info.n_ranks && local_run >= 0 &&
+                local_run < plan->info.n_local_runs,
+            "block index out of range");
+    const size_t at = static_cast<size_t>(local_run) * plan->info.n_ranks +
+                      static_cast<size_t>(plan->piece_of_rank[static_cast<size_t>(peer)]);
+    *n_rows = plan->send_block_rows[at];
+    *first_row = plan->send_blocks[at].first_row;
+    *offset = (*n_rows > 0) ? plan->send_blocks[at].offset : -1;
+    return AVR_OK;
+  });
+}
+
+int avr_frame_plan_recv_block(const avr_frame_plan* plan, int global_run, int64_t* offset,
+                              int32_t* first_row, int32_t* n_rows) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && offset != nullptr && first_row != nullptr && n_rows != nullptr,
+            "null argument");
+    require(global_run >= 0 && global_run < plan->info.n_runs_total, "run index out of range");
+    const size_t at = static_cast<size_t>(global_run);
+    *n_rows = plan->recv_block_rows[at];
+    *first_row = plan->recv_blocks[at].first_row;
+    *offset = (*n_rows > 0) ? plan->recv_blocks[at].offset : -1;
+    return AVR_OK;
+  });
+}
+
+int avr_render_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                    float* send_buffer, uint64_t* samples_out) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(scene != nullptr && plan != nullptr, "null argument");
+    require(static_cast<int>(scene->boxes.size()) == plan->info.n_local_boxes,
+            "the scene does not hold this rank's boxes of the plan");
+    if (plan->info.n_local_runs == 0) return AVR_OK;
+    return render(ctx, scene->boxes.data(), static_cast<int>(scene->boxes.size()),
+                  scene->transform, plan->params, plan->camera, plan->local_order.data(),
+                  static_cast<int>(plan->local_order.size()), plan->local_run_end.data(),
+                  plan->info.n_local_runs, plan->info.n_ranks, plan->local_rects, plan->send_blocks,
+                  send_buffer, samples_out);
+  });
+}
+
+int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
+                  float* out_piece, uint8_t* out_rgb8) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(plan != nullptr && out_piece != nullptr, "null argument");
+    require(plan->info.recv_floats == 0 || recv_buffer != nullptr, "null receive buffer");
+    if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
+    ctx->wait_staging();
+    ctx->upload(ctx->run_rects, plan->global_rects.data(),
+                plan->global_rects.size() * sizeof(avr::RunRectDev));
+    ctx->upload(ctx->run_blocks, plan->recv_blocks.data(),
+                plan->recv_blocks.size() * sizeof(avr::RunBlockDev));
+    ctx->mark_staging();
+    avr::FoldLaunch launch;
+    launch.width = plan->params.width;
+    launch.piece_begin = plan->info.piece_begin;
+    launch.piece_end = plan->info.piece_end;
+    launch.n_runs = plan->info.n_runs_total;
+    launch.run_rects_dev = static_cast<const avr::RunRectDev*>(ctx->run_rects.dev());
+    launch.run_blocks_dev = static_cast<const avr::RunBlockDev*>(ctx->run_blocks.dev());
+    launch.recv = recv_buffer;
+    launch.out_piece = out_piece;
+    launch.out_rgb8 = out_rgb8;
+    return avr::launch_fold_plan(launch, ctx->stream);
   });
 }
 

@@ -360,6 +360,22 @@ void screen_rect(const avr_box& box, const avr_camera& camera, const CameraBasis
 
 }  // namespace
 
+void box_screen_rect(const avr_box& box, const avr_camera& camera, int width, int height,
+                     int32_t rect[4]) {
+  FrameConsts fc;
+  std::memset(&fc, 0, sizeof(fc));
+  fc.width = width;
+  fc.height = height;
+  fc.aspect = static_cast<float>(width) / static_cast<float>(std::max(height, 1));
+  fc.tan_half_fov = std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f);
+  if (box.dims[0] <= 0 || box.dims[1] <= 0 || box.dims[2] <= 0) {
+    rect[0] = rect[1] = 0;
+    rect[2] = rect[3] = -1;
+    return;
+  }
+  screen_rect(box, camera, camera_basis(camera), fc, rect);
+}
+
 void build_color_table(float alpha_scale, float normalization_factor, const float scalar_range[2],
                        const avr_colormap_point* colormap, int colormap_count, float* out_table) {
   TransferFunction tf;

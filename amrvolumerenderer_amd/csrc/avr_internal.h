@@ -62,6 +62,17 @@ struct FrameConsts {
 constexpr int kBrickX = 8, kBrickY = 4, kBrickZ = 4, kBrickBytes = 128;
 constexpr int kClassifyChunk = 128;  // cells of one x-row handled by one classify workgroup
 
+// Sparse run layers: a run's layer is stored only inside the run's screen rectangle, cut into
+// one block per DirectSend piece (include/avr_hip.h, "frame plan").
+struct RunRectDev {
+  int32_t x0, y0, x1, y1;  // inclusive; x1 < x0 = empty
+};
+struct RunBlockDev {
+  int64_t offset;     // float offset of the block in the send / recv buffer (unused if empty)
+  int32_t first_row;  // image row stored in the block's first row
+  int32_t pad_;
+};
+
 // Host results for one frame over a list of boxes.
 struct FramePlan {
   FrameConsts consts;
@@ -92,6 +103,9 @@ float reference_sample_distance(const avr_box* boxes, int n_boxes, const double 
                                 const double bounds_max[3]);
 int layer_order(const float* hints, const int32_t* owner, const int32_t* local_index, int n_layers,
                 int32_t* order_out, int32_t* run_end_out);
+// Conservative screen rectangle of a box (x0,y0,x1,y1 inclusive; x1 < x0 = off-screen).
+void box_screen_rect(const avr_box& box, const avr_camera& camera, int width, int height,
+                     int32_t rect[4]);
 // Fills plan for the given boxes; throws std::invalid_argument / std::runtime_error.
 void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
                 const avr_paint_params& params, const avr_camera& camera, FramePlan* plan);
@@ -105,6 +119,8 @@ struct RenderLaunch {
   const int32_t* order_dev;     // box indices in global layer order
   const int32_t* run_end_dev;   // one-past-last position per run
   int n_order, n_runs, n_pieces;
+  const RunRectDev* run_rects_dev;    // n_runs
+  const RunBlockDev* run_blocks_dev;  // n_runs x n_pieces
   float* out_layers;
   unsigned long long* samples_out;  // may be null
   uint8_t* classified;              // frame's classified buffer (FramePlan::classified_bytes)
@@ -120,6 +136,17 @@ int launch_blend_regions(int kind, const void* top, int64_t tb, int64_t te, cons
                          int64_t bb, int64_t be, void* out, void* stream);
 int launch_encode_u8(const float* rgba, uint32_t* out, int64_t n, void* stream);
 int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream);
+struct FoldLaunch {
+  int width;
+  int64_t piece_begin, piece_end;
+  int n_runs;                          // global runs, in order
+  const RunRectDev* run_rects_dev;     // n_runs
+  const RunBlockDev* run_blocks_dev;   // n_runs: block of this rank's piece in the recv buffer
+  const float* recv;
+  float* out_piece;
+  uint8_t* out_rgb8;                   // may be null
+};
+int launch_fold_plan(const FoldLaunch& launch, void* stream);
 int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,
                      void* stream);
 int launch_downsample(const float* src, int tw, int th, int block, float* dst, void* stream);

@@ -362,24 +362,13 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   return out;
 }
 
-// Address of pixel p of run r in send layout (see avr_render_runs in include/avr_hip.h).
-__device__ __forceinline__ int64_t send_offset(int64_t p, int run, int n_runs, int64_t n_pixels,
-                                               int n_pieces) {
-  if (n_pieces <= 1) return (static_cast<int64_t>(run) * n_pixels + p) * 5;
-  const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
-  int64_t piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
-  if (piece > n_pieces - 1) piece = n_pieces - 1;
-  const int64_t begin = piece * piece_size;
-  const int64_t len = (piece < n_pieces - 1) ? piece_size : (n_pixels - begin);
-  return (static_cast<int64_t>(n_runs) * begin + static_cast<int64_t>(run) * len + (p - begin)) * 5;
-}
-
 template <bool STATS>
 __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
-    const int n_runs, const int n_pieces, const int tiles_x, const int tiles_y,
+    const int n_runs, const int n_pieces, const RunRectDev* __restrict__ run_rects,
+    const RunBlockDev* __restrict__ run_blocks, const int tiles_x, const int tiles_y,
     const uint32_t* __restrict__ supertile_order, float* __restrict__ out,
     unsigned long long* samples_out) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
@@ -468,8 +457,18 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
         acc = blend_depthsort(acc, layer);
       }
     }
-    if (live) {
-      float* dst = out + send_offset(p, run, n_runs, n_pixels, n_pieces);
+    // The run's layer is stored only inside the run's screen rectangle (outside it no box of
+    // the run can be hit, so the pixel is the empty layer pixel), in the block of the
+    // DirectSend piece the pixel belongs to.
+    const RunRectDev rect = run_rects[run];
+    if (live && px >= rect.x0 && px <= rect.x1 && py >= rect.y0 && py <= rect.y1) {
+      const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
+      int64_t piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
+      if (piece > n_pieces - 1) piece = n_pieces - 1;
+      const RunBlockDev block = run_blocks[static_cast<int64_t>(run) * n_pieces + piece];
+      float* dst = out + block.offset +
+                   (static_cast<int64_t>(py - block.first_row) * (rect.x1 - rect.x0 + 1) +
+                    (px - rect.x0)) * 5;
       dst[0] = acc.r;
       dst[1] = acc.g;
       dst[2] = acc.b;
@@ -781,6 +780,48 @@ __global__ void fold_runs_kernel(const float* const* __restrict__ slices, int n_
   }
 }
 
+// Receiver side of the layered compose for one DirectSend piece (DirectSendBase.cpp:400-446):
+// per pixel, the runs that cover it are blended in global order.  Starting from the cleared
+// pixel instead of the first run's pixel gives the same bits (exact identity of the blend).
+__global__ void fold_plan_kernel(const int width, const int64_t piece_begin,
+                                 const int64_t piece_end, const int n_runs,
+                                 const RunRectDev* __restrict__ rects,
+                                 const RunBlockDev* __restrict__ blocks,
+                                 const float* __restrict__ recv, float* __restrict__ out_piece,
+                                 uint8_t* __restrict__ out_rgb8) {
+  const int64_t n = piece_end - piece_begin;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
+       q += stride) {
+    const int64_t p = piece_begin + q;
+    const int px = static_cast<int>(p % width);
+    const int py = static_cast<int>(p / width);
+    Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};
+    for (int g = 0; g < n_runs; ++g) {
+      const RunRectDev rect = rects[g];
+      if (px < rect.x0 || px > rect.x1 || py < rect.y0 || py > rect.y1) continue;
+      const RunBlockDev block = blocks[g];
+      const float* src = recv + block.offset +
+                         (static_cast<int64_t>(py - block.first_row) * (rect.x1 - rect.x0 + 1) +
+                          (px - rect.x0)) * 5;
+      const Layer5 layer = {src[0], src[1], src[2], src[3], src[4]};
+      acc = blend_depthsort(acc, layer);
+    }
+    float* d = out_piece + q * 5;
+    d[0] = acc.r;
+    d[1] = acc.g;
+    d[2] = acc.b;
+    d[3] = acc.a;
+    d[4] = acc.d;
+    if (out_rgb8 != nullptr) {
+      uint8_t* b = out_rgb8 + q * 3;
+      b[0] = static_cast<uint8_t>(component_as_byte(acc.r));
+      b[1] = static_cast<uint8_t>(component_as_byte(acc.g));
+      b[2] = static_cast<uint8_t>(component_as_byte(acc.b));
+    }
+  }
+}
+
 // downsampleImage (VolumeRenderer.cpp:479-528): sums in dy-major, dx-minor order.
 __global__ void downsample_kernel(const float* __restrict__ src, int tw, int th, int block,
                                   float* __restrict__ dst) {
@@ -872,13 +913,15 @@ int launch_render_runs(const RenderLaunch& L, void* stream_v) {
   if (L.samples_out != nullptr) {
     hipLaunchKernelGGL(render_runs_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
                        stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
-                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y,
-                       L.supertile_order_dev, L.out_layers, L.samples_out);
+                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, L.run_rects_dev,
+                       L.run_blocks_dev, tiles_x, tiles_y, L.supertile_order_dev, L.out_layers,
+                       L.samples_out);
   } else {
     hipLaunchKernelGGL(render_runs_kernel<false>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
                        stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
-                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, tiles_x, tiles_y,
-                       L.supertile_order_dev, L.out_layers, L.samples_out);
+                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, L.run_rects_dev,
+                       L.run_blocks_dev, tiles_x, tiles_y, L.supertile_order_dev, L.out_layers,
+                       L.samples_out);
   }
   return check_launch("render_runs_kernel");
 }
@@ -938,6 +981,15 @@ int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream_v)
   hipLaunchKernelGGL(decode_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_v), in, reinterpret_cast<float4*>(rgba), n);
   return check_launch("decode_u8_kernel");
+}
+
+int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
+  const int64_t n = L.piece_end - L.piece_begin;
+  if (n <= 0) return AVR_OK;
+  hipLaunchKernelGGL(fold_plan_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream_v), L.width, L.piece_begin, L.piece_end,
+                     L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.recv, L.out_piece, L.out_rgb8);
+  return check_launch("fold_plan_kernel");
 }
 
 int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,

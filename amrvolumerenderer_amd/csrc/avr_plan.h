@@ -1,0 +1,45 @@
+// Frame plan (include/avr_hip.h, "frame plan"): global layer order, runs, per-run screen
+// rectangles and the sparse exchange layout.  Host only.
+#ifndef AVR_PLAN_H
+#define AVR_PLAN_H
+
+#include <vector>
+
+#include "avr_internal.h"
+
+struct avr_frame_plan {
+  avr_frame_plan_info info{};
+  avr_paint_params params{};
+  std::vector<avr_colormap_point> colormap;
+  avr_camera camera{};
+  std::vector<int32_t> layer_box;        // global order -> index into all_boxes
+  std::vector<avr_run_info> runs;        // global runs in order
+  std::vector<int32_t> local_order;      // this rank's local box indices in global order
+  std::vector<int32_t> local_run_end;
+  std::vector<int32_t> group_order;      // rank at group position k
+  std::vector<int32_t> piece_of_rank;
+  std::vector<int64_t> send_splits, recv_splits;
+  // sender tables: [local run][piece]
+  std::vector<avr::RunRectDev> local_rects;
+  std::vector<avr::RunBlockDev> send_blocks;
+  std::vector<int32_t> send_block_rows;  // rows of each block (0 = empty)
+  // receiver tables: [global run], this rank's piece
+  std::vector<avr::RunRectDev> global_rects;
+  std::vector<avr::RunBlockDev> recv_blocks;
+  std::vector<int32_t> recv_block_rows;
+};
+
+namespace avr {
+
+// Dense single-buffer layout of avr_render_runs expressed with the same tables: every run's
+// rectangle is the full screen.
+void dense_run_tables(int width, int height, int n_runs, int n_pieces,
+                      std::vector<RunRectDev>* rects, std::vector<RunBlockDev>* blocks);
+
+void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
+                      int rank, const int32_t* group_order, const avr_paint_params& params,
+                      const avr_camera& camera, avr_frame_plan* plan);
+
+}  // namespace avr
+
+#endif

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import runtime, scenes
-from .compositor import DirectSendCompositor, ExchangePlan, plan_exchange
+from .compositor import DirectSendCompositor, FramePlan, make_box_array, make_owner_array
 from .types import AmrBox, CameraParameters, ScalarTransform, VolumeBounds, make_params
 
 
@@ -75,63 +75,72 @@ class FrameRenderer:
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
         self.compositor = DirectSendCompositor(ctx, process_group)
-        # localIndex of every box on its owner (position in that rank's localBoxes)
-        self._by_rank: List[List[int]] = [[] for _ in range(n_ranks)]
-        for i, b in enumerate(self.all_boxes):
-            self._by_rank[b.owner].append(i)
-        if len(self._by_rank[rank]) != len(self.local_boxes):
+        n_local = sum(1 for b in self.all_boxes if b.owner == rank)
+        if n_local != len(self.local_boxes):
             raise ValueError("local_boxes does not match the ownership of all_boxes")
+        # replicated metadata in C form, built once per scene
+        self._box_array = make_box_array(self.all_boxes)
+        self._owner_array = make_owner_array(self.all_boxes)
         # coarsest min spacing over all ranks == MPI_Allreduce(MAX) of VolumeRenderer.cpp:1166
         self.reference_sample_distance = runtime.reference_sample_distance(
             self.all_boxes, bounds.min_corner, bounds.max_corner)
         self._send: Optional[torch.Tensor] = None
-        self.last_plan: Optional[ExchangePlan] = None
+        self.last_plan: Optional[FramePlan] = None
 
     # -- planning (host) -------------------------------------------------------------------------
-    def plan(self, camera: CameraParameters, n_pixels: int,
-             group_order: Optional[Sequence[int]] = None) -> ExchangePlan:
-        hints_by_rank = [[runtime.box_depth_hint(self.all_boxes[i], camera) for i in idx]
-                         for idx in self._by_rank]
-        return plan_exchange(hints_by_rank, self.rank, n_pixels, group_order)
-
-    # -- one frame ------------------------------------------------------------------------------
-    def paint(self, plan: ExchangePlan, params, camera: CameraParameters,
-              samples: Optional[torch.Tensor] = None, sync_streams: bool = True) -> torch.Tensor:
-        need = max(plan.n_local_runs, 1) * plan.n_pixels * 5
-        if self._send is None or self._send.numel() < need:
-            self._send = self.ctx.empty(need)
-        return self.scene.render_runs(params, camera, plan.local_order, plan.local_run_end,
-                                      plan.n_ranks, out=self._send, samples=samples,
-                                      sync_streams=sync_streams)
-
     def make_params(self, p: RenderParameters):
         root = validate_render_parameters(p)
         return make_params(p.width * root, p.height * root, self.scalar_range, p.box_transparency,
                            self.reference_sample_distance, self.bounds, self.color_map), root
 
+    def plan(self, params, camera: CameraParameters,
+             group_order: Optional[Sequence[int]] = None) -> FramePlan:
+        """Layer order, runs and exchange layout of one frame (what composeLayered derives from
+        its allgathers, DirectSendBase.cpp:329-410), from the replicated box metadata."""
+        return FramePlan(self.all_boxes, params, camera, self.rank, self.n_ranks, group_order,
+                         _box_array=self._box_array, _owner_array=self._owner_array)
+
+    # -- one frame ------------------------------------------------------------------------------
+    def paint(self, plan: FramePlan, samples: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Classify + march of this rank's runs into the sparse send buffer."""
+        need = max(plan.send_floats, 1)
+        if self._send is None or self._send.numel() < need:
+            self._send = self.ctx.empty(need)
+        return self.scene.render_plan(plan, out=self._send, samples=samples)
+
     def render(self, p: RenderParameters, camera: CameraParameters,
-               samples: Optional[torch.Tensor] = None, quantize: bool = True,
+               samples: Optional[torch.Tensor] = None, want_image: bool = False,
                group_order: Optional[Sequence[int]] = None):
-        """Returns (image, rgb8) on rank 0 -- the gathered (downsampled) depth-sort image
-        [H, W, 5] and its RGB8 bytes [H, W, 3] in file row order -- and (None, None) elsewhere."""
+        """One frame.  On rank 0 returns (image, rgb8): rgb8 = the output file's pixel bytes
+        [H, W, 3] (rows top-down, SavePPM.cpp:25), image = the gathered (downsampled) depth-sort
+        image [H, W, 5] if want_image (or antialiasing > 1), else None.  Other ranks get
+        (None, None)."""
         params, root = self.make_params(p)
-        n_pixels = params.width * params.height
-        plan = self.plan(camera, n_pixels, group_order)
+        plan = self.plan(params, camera, group_order)
         self.last_plan = plan
-        self.ctx.join()  # cell data / earlier torch work on the caller's stream
-        with torch.cuda.stream(self.ctx.stream):
-            send = self.paint(plan, params, camera, samples, sync_streams=False)
-            if plan.n_ranks == 1 and plan.n_local_runs == 1:
-                full = send[:n_pixels * 5].view(n_pixels, 5)  # one run on one rank: already final
+        ctx = self.ctx
+        ctx.join()  # cell data / earlier torch work on the caller's stream
+        with torch.cuda.stream(ctx.stream):
+            send = self.paint(plan, samples)
+            # 8-bit conversion is per pixel, so without antialiasing it is done on each rank's
+            # piece before the gather (3 bytes per pixel on the wire instead of 20)
+            early_rgb8 = (root == 1)
+            piece, piece_rgb8 = self.compositor.compose(plan, send, want_rgb8=early_rgb8)
+            image = None
+            rgb8 = None
+            if early_rgb8:
+                flat = self.compositor.gather(plan, piece_rgb8, dst=0)
+                if flat is not None:
+                    rgb8 = torch.flip(flat.view(p.height, p.width, 3), dims=[0])
+                if want_image:
+                    full = self.compositor.gather(plan, piece, dst=0)
+                    if full is not None:
+                        image = full.view(p.height, p.width, 5)
             else:
-                piece, _, _ = self.compositor.compose(plan, send)
                 full = self.compositor.gather(plan, piece, dst=0)
-            if full is None:
-                return None, None
-            image = full.view(params.height, params.width, 5)
-            if root > 1:
-                image = self.ctx.downsample(full.reshape(-1), p.width, p.height, root)
-            rgb8 = self.ctx.quantize_rgb8(image.reshape(-1), p.width, p.height) if quantize else None
+                if full is not None:
+                    image = ctx.downsample(full.reshape(-1), p.width, p.height, root)
+                    rgb8 = ctx.quantize_rgb8(image.reshape(-1), p.width, p.height)
         return image, rgb8
 
 

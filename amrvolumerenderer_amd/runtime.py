@@ -241,6 +241,23 @@ class Context:
         self.publish()
         return out
 
+    def fold_plan(self, plan, recv: torch.Tensor, want_rgb8: bool = False):
+        """avr_fold_plan: receiver-side fold of this rank's piece.  Returns
+        (piece [piece_len, 5], rgb8 [piece_len, 3] or None)."""
+        self._check_tensor(recv, torch.float32, "recv")
+        if recv.numel() < plan.recv_floats:
+            raise ValueError("receive buffer is too small")
+        n = plan.piece_end - plan.piece_begin
+        piece = self.empty(max(n, 0), 5)
+        rgb8 = self.empty(max(n, 0), 3, dtype=torch.uint8) if want_rgb8 else None
+        self.join()
+        _capi.check(_capi.lib().avr_fold_plan(
+            self._handle, plan._handle, C.c_void_p(recv.data_ptr()),
+            C.c_void_p(piece.data_ptr()),
+            C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None))
+        self.publish()
+        return piece, rgb8
+
     def downsample(self, src: torch.Tensor, target_w: int, target_h: int, block: int
                    ) -> torch.Tensor:
         self._check_tensor(src, torch.float32, "src")
@@ -267,6 +284,24 @@ class Context:
 
 class Scene:
     """The rank's local boxes + scalar transform (avr_scene).  Keeps the cell tensors alive."""
+
+    def render_plan(self, plan, out: Optional[torch.Tensor] = None,
+                    samples: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_render_plan: classify + march of this rank's runs into the sparse send buffer."""
+        ctx = self.ctx
+        if out is None:
+            out = ctx.empty(max(plan.send_floats, 1))
+        ctx._check_tensor(out, torch.float32, "out")
+        if out.numel() < plan.send_floats:
+            raise ValueError("send buffer is too small")
+        if samples is not None:
+            ctx._check_tensor(samples, torch.int64, "samples")
+        ctx.join()
+        _capi.check(_capi.lib().avr_render_plan(
+            ctx._handle, self._handle, plan._handle, C.c_void_p(out.data_ptr()),
+            C.c_void_p(samples.data_ptr()) if samples is not None else None))
+        ctx.publish()
+        return out
 
     def __init__(self, ctx: Context, boxes: Sequence[AmrBox], transform: ScalarTransform):
         self.ctx = ctx

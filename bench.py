@@ -66,8 +66,10 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
                        renderer.reference_sample_distance, spec.bounds.min_corner,
                        spec.bounds.max_corner)
     n = len(local_boxes)
-    # stratified: boxes spread evenly over the level-major list; stop at the time budget
-    picks = [int(i * n / 16) for i in range(16)] if n >= 16 else list(range(n))
+    # stratified: a stride-16 sweep over the level-major box list (offsets 0, 8, 4, 12, ...), so
+    # any prefix is spread over all levels; stop at the time budget
+    offsets = [0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15]
+    picks = [i for o in offsets for i in range(o, n, 16)]
     total_samples, total_time, used = 0, 0.0, 0
     for i in picks:
         box = local_boxes[i]
@@ -85,7 +87,7 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
         "unit": "Mray-samples/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle VolumePainter::paint of {used} of {n} boxes (stratified over the "
+        "sample": f"oracle VolumePainter::paint of {used} of {n} boxes (stride-16 sweep of the "
                   f"level-major box list) at {params.width}x{params.height}, same camera and "
                   f"transfer function, {total_samples} samples in {total_time:.1f} s, "
                   f"OpenMP over image rows",
@@ -155,7 +157,8 @@ def main():
             dist.all_reduce(s, group=group)
         frame_samples.append(int(s.item()))
     local_runs = renderer.last_plan.n_local_runs
-    total_runs = len(renderer.last_plan.run_owner)
+    total_runs = renderer.last_plan.n_runs_total
+    send_floats = renderer.last_plan.send_floats
 
     def step(i):
         return renderer.render(rparams, cameras[i % len(cameras)])
@@ -173,11 +176,11 @@ def main():
     kernel_events = []
     orig_paint = renderer.paint
 
-    def timed_paint(plan, p, cam, samples=None, sync_streams=True):
+    def timed_paint(plan, samples=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(ctx.stream)
-        out = orig_paint(plan, p, cam, samples, sync_streams)
+        out = orig_paint(plan, samples)
         e1.record(ctx.stream)
         kernel_events.append((e0, e1))
         return out
@@ -204,7 +207,8 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = samples_total / elapsed / 1e6
 
-    # ---- roofline of the dominant kernel (render_runs_kernel), this rank's launch ------------
+    # ---- roofline of the paint stage (classify_kernel + render_runs_kernel, launched back to
+    # back by one avr_render_plan call), this rank's launch ----------------------------------
     # algorithmic bytes per launch = 8 B per executed cell fetch (one amrex::Real) + 20 B per
     # emitted layer pixel; samples of THIS rank's launch:
     samples_dev.zero_()
@@ -212,16 +216,15 @@ def main():
     ctx.synchronize()
     my_samples = int(samples_dev.item())
     n_pixels = params.width * params.height
-    algo_bytes = 8.0 * my_samples + 20.0 * n_pixels * max(local_runs, 1)
+    algo_bytes = 8.0 * my_samples + 4.0 * send_floats
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": "render_runs_kernel",
+        "bound": "hbm", "kernel": "classify_kernel + render_runs_kernel (one avr_render_plan)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(algo_bytes),
         "samples_this_rank": my_samples,
-        "compulsory_bytes": int(sum(b.values.numel() for b in local_boxes) * 8
-                                + 20 * n_pixels * max(local_runs, 1)),
+        "compulsory_bytes": int(sum(b.values.numel() for b in local_boxes) * 8 + 4 * send_floats),
     }
 
     out = {

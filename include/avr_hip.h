@@ -154,11 +154,13 @@ int avr_scene_create(avr_context *ctx, const avr_box *boxes, int n_boxes,
 void avr_scene_destroy(avr_scene *scene);
 
 /* Fused replacement of the per-box loop + owner-side run fold
- * (VolumeRenderer.cpp:1201-1219 + DirectSendBase.cpp:413-426): paints the local boxes
- * box_order[0..n) (indices into the scene, already in global layer order) and folds each run
- * (run_end[r] = one-past-last position of run r in box_order) with the depth-sort blend, in
- * order.  Run r's layer is written for ALL pixels in "send layout": the image is cut in
- * n_pieces DirectSend pieces (avr_piece_range) and
+ * (VolumeRenderer.cpp:1201-1219 + DirectSendBase.cpp:413-426): first a streaming classify pass
+ * turns every f64 cell of the scene into its transfer-function table index (the per-sample
+ * arithmetic of VolumePainter.cpp:870-883 is a pure function of the cell), then one thread per
+ * pixel marches the local boxes box_order[0..n) (indices into the scene, already in global
+ * layer order) and folds each run (run_end[r] = one-past-last position of run r in box_order)
+ * with the depth-sort blend, in order.  Run r's layer is written for ALL pixels in dense "send
+ * layout": the image is cut in n_pieces DirectSend pieces (avr_piece_range) and
  *     out[ piece_offset(k) + (r * piece_len(k) + (p - piece_begin(k))) * 5 .. +5 ]
  * with piece_offset(k) = 5 * n_runs * piece_begin(k); for n_pieces == 1 this is simply
  * out[r][p][5].  The result is bit-identical to painting every box into its own layer and
@@ -168,6 +170,86 @@ int avr_render_runs(avr_context *ctx, const avr_scene *scene, const avr_paint_pa
                     const avr_camera *camera, const int32_t *box_order, int n_order,
                     const int32_t *run_end, int n_runs, int n_pieces, float *out_layers,
                     uint64_t *samples_out);
+
+/* ---- frame plan: layered DirectSend with one sparse exchange ------------------------------ */
+
+/* One frame's compositing plan, identical on every rank.  Replaces the per-frame allgather of
+ * layer counts / depth hints, the global sort and the run grouping of
+ * DirectSendBase::composeLayered (DirectSend/Base/DirectSendBase.cpp:329-410) -- depth hints
+ * depend only on box corners and the camera, so every rank derives them from the replicated box
+ * metadata -- and adds, per run, the conservative screen rectangle of its boxes: pixels outside
+ * it hold the empty layer pixel (0,0,0,0,+inf), an exact identity of the blend, and are neither
+ * stored nor sent.
+ *
+ *   all_boxes[n_boxes]  metadata of every box of the scene (cells may be NULL), level-major;
+ *   owner[n_boxes]      owning rank; a rank's local index of a box is its position among the
+ *                       boxes it owns (geometry.localBoxes order);
+ *   group_order         rank at position k of the ordered MPI group of Compositor::compose
+ *                       (Common/Compositor.hpp:19-40); NULL = identity.  Position k holds
+ *                       pixel piece k (DirectSendBase.cpp:76-130).  Pixel values do not depend
+ *                       on it (SURVEY.md 8c probe 1).
+ * Exchange layout (floats; 5 per pixel):
+ *   send buffer = for peer rank s = 0..n-1: for local run r: block(piece of s, r)
+ *   recv buffer = for source rank s = 0..n-1: for run r of s: block(my piece, r)
+ *   block(k, r) = rows [max(rect.y0, first row of piece k), min(rect.y1, last row of piece k)]
+ *                 x columns [rect.x0, rect.x1] of run r, row-major.
+ * so one all-to-all (split sizes from avr_frame_plan_splits) replaces the N(N-1) messages per
+ * run of the reference. */
+typedef struct avr_frame_plan avr_frame_plan;
+
+typedef struct {
+  int32_t n_ranks, rank;
+  int32_t n_runs_total;   /* global runs, all ranks */
+  int32_t n_local_runs;   /* runs owned by this rank */
+  int32_t n_local_boxes;
+  int64_t n_pixels;       /* render width * height */
+  int64_t piece_begin;    /* this rank's DirectSend piece [begin, end) */
+  int64_t piece_end;
+  int64_t send_floats;    /* total size of the send / recv buffers */
+  int64_t recv_floats;
+} avr_frame_plan_info;
+
+/* One run as seen by the exchange (for inspection and tests). */
+typedef struct {
+  int32_t owner;          /* owning rank */
+  int32_t local_run;      /* index among the owner's runs */
+  int32_t first_layer;    /* position of its first layer in the global order */
+  int32_t n_layers;
+  int32_t rect[4];        /* x0, y0, x1, y1 inclusive; x1 < x0 = empty */
+} avr_run_info;
+
+int avr_frame_plan_create(const avr_box *all_boxes, const int32_t *owner, int n_boxes,
+                          int n_ranks, int rank, const int32_t *group_order,
+                          const avr_paint_params *params, const avr_camera *camera,
+                          avr_frame_plan **out_plan);
+void avr_frame_plan_destroy(avr_frame_plan *plan);
+int avr_frame_plan_get_info(const avr_frame_plan *plan, avr_frame_plan_info *out);
+/* all_to_all split sizes in floats, indexed by peer rank (n_ranks entries each). */
+int avr_frame_plan_splits(const avr_frame_plan *plan, int64_t *send_splits, int64_t *recv_splits);
+/* Global layer order: layer_box[l] = index into all_boxes of the l-th layer; n_boxes entries. */
+int avr_frame_plan_layers(const avr_frame_plan *plan, int32_t *layer_box);
+/* runs[n_runs_total] in global order. */
+int avr_frame_plan_runs(const avr_frame_plan *plan, avr_run_info *runs);
+/* Offset (floats) of block(piece of `peer`, local run r) in the send buffer and of
+ * block(my piece, global run g) in the recv buffer; -1 when the block is empty.
+ * first_row receives the image row of the block's first row. */
+int avr_frame_plan_send_block(const avr_frame_plan *plan, int peer, int local_run,
+                              int64_t *offset, int32_t *first_row, int32_t *n_rows);
+int avr_frame_plan_recv_block(const avr_frame_plan *plan, int global_run, int64_t *offset,
+                              int32_t *first_row, int32_t *n_rows);
+
+/* Classify + march of this rank's runs into the sparse send buffer (send_floats floats).
+ * The scene must hold this rank's boxes in local-index order.  samples_out as avr_paint_box. */
+int avr_render_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                    float *send_buffer, uint64_t *samples_out);
+
+/* Receiver side of composeLayered (DirectSendBase.cpp:400-446) for this rank's piece: folds
+ * the runs in global order from the received buffer (recv_floats floats; with one rank the send
+ * buffer itself) into out_piece[(piece_end - piece_begin) * 5]; pixels no run covers become the
+ * cleared layer pixel (DirectSendBase.cpp:450-455).  If out_rgb8 is non-NULL the piece is also
+ * written as RGB8 (Color::GetComponentAsByte, 3 bytes per pixel, same pixel order). */
+int avr_fold_plan(avr_context *ctx, const avr_frame_plan *plan, const float *recv_buffer,
+                  float *out_piece, uint8_t *out_rgb8);
 
 /* ---- image algebra ----------------------------------------------------------------------- */
 

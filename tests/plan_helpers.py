@@ -1,0 +1,103 @@
+"""Test-side restatement of the sparse exchange layout documented in include/avr_hip.h
+("frame plan"), independent of the C implementation: packs oracle run layers into send buffers
+and folds received buffers on the CPU.  Used by the CPU multi-rank tests (where no HIP kernel can
+run) and to cross-check avr_render_plan / avr_fold_plan on the GPU."""
+from __future__ import annotations
+
+import numpy as np
+
+from amrvolumerenderer_amd import runtime
+
+
+def piece_rows(n_pixels, piece, n_pieces, width):
+    b, e = runtime.piece_range(n_pixels, piece, n_pieces)
+    if e <= b:
+        return b, e, 0, -1
+    return b, e, b // width, (e - 1) // width
+
+
+def oracle_run_layers(O, layers_by_box, plan):
+    """Run layers (full frame, [n_pixels, 5]) of every global run, by the reference's rule:
+    the owner folds its run's layers in order (DirectSendBase.cpp:413-426)."""
+    order = plan.layers()
+    out = []
+    for run in plan.runs():
+        ids = order[run.first_layer:run.first_layer + run.n_layers]
+        acc = layers_by_box[ids[0]].reshape(-1, 5)
+        for i in ids[1:]:
+            acc = O.blend_depthsort(acc, layers_by_box[i].reshape(-1, 5))
+        out.append(np.ascontiguousarray(acc))
+    return out
+
+
+def pack_send_buffer(plan, run_layers, fill=np.nan):
+    """What avr_render_plan must produce on plan.rank: for peer s, for local run r, the rows of
+    the run's rectangle inside the peer's piece.  Positions outside the piece ("holes" of
+    partial rows) are filled with `fill`."""
+    W = plan.width
+    runs = [r for r in plan.runs() if r.owner == plan.rank]
+    global_ids = [g for g, r in enumerate(plan.runs()) if r.owner == plan.rank]
+    buf = np.full(max(plan.send_floats, 1), fill, dtype=np.float32)
+    cursor = 0
+    for peer in range(plan.n_ranks):
+        b, e, row_lo, row_hi = piece_rows(plan.n_pixels, plan.piece_of_rank[peer], plan.n_ranks, W)
+        for local, run in enumerate(runs):
+            x0, y0, x1, y1 = run.rect
+            off, first, rows = plan.send_block(peer, local)
+            lo, hi = max(y0, row_lo), min(y1, row_hi)
+            want_rows = max(hi - lo + 1, 0) if (x1 >= x0 and y1 >= y0) else 0
+            assert rows == want_rows, (rows, want_rows)
+            if rows == 0:
+                assert off == -1
+                continue
+            assert off == cursor and first == lo
+            layer = run_layers[global_ids[local]].reshape(-1, W, 5)
+            w = x1 - x0 + 1
+            block = layer[lo:hi + 1, x0:x1 + 1].copy()
+            ys, xs = np.mgrid[lo:hi + 1, x0:x1 + 1]
+            p = ys * W + xs
+            block[(p < b) | (p >= e)] = fill
+            buf[cursor:cursor + rows * w * 5] = block.reshape(-1)
+            cursor += rows * w * 5
+        assert cursor == sum(plan.send_splits[:peer + 1])
+    assert cursor == plan.send_floats
+    return buf
+
+
+def fold_recv_buffer(O, plan, recv):
+    """What avr_fold_plan must produce: per pixel of the piece, blend the covering runs in
+    global order starting from the cleared pixel."""
+    W = plan.width
+    b, e = plan.piece_begin, plan.piece_end
+    n = e - b
+    out = np.zeros((n, 5), np.float32)
+    out[:, 4] = np.inf
+    for g, run in enumerate(plan.runs()):
+        off, first, rows = plan.recv_block(g)
+        if rows == 0:
+            continue
+        x0, y0, x1, y1 = run.rect
+        w = x1 - x0 + 1
+        block = np.asarray(recv[off:off + rows * w * 5]).reshape(rows, w, 5)
+        ys, xs = np.mgrid[first:first + rows, x0:x1 + 1]
+        p = (ys * W + xs).reshape(-1)
+        keep = (p >= b) & (p < e)
+        idx = p[keep] - b
+        layer = np.ascontiguousarray(block.reshape(-1, 5)[keep])
+        out[idx] = O.blend_depthsort(np.ascontiguousarray(out[idx]), layer)
+    return out
+
+
+def route(plans, send_buffers):
+    """The all-to-all, done by hand: the block for peer s of every rank, concatenated by source
+    rank, is rank s's receive buffer."""
+    n = len(plans)
+    recv = []
+    for s in range(n):
+        parts = []
+        for src in range(n):
+            begin = sum(plans[src].send_splits[:s])
+            parts.append(send_buffers[src][begin:begin + plans[src].send_splits[s]])
+            assert plans[s].recv_splits[src] == plans[src].send_splits[s]
+        recv.append(np.concatenate(parts) if parts else np.zeros(0, np.float32))
+    return recv

@@ -1,0 +1,101 @@
+"""GPU parity of the plan path: avr_render_plan (classify + march into the sparse send buffer)
+and avr_fold_plan, for N simulated ranks on one GPU, against the oracle's per-box layers and
+layered DirectSend compose.  Also the full FrameRenderer frame (1 rank) incl. antialiasing."""
+import numpy as np
+import pytest
+import torch
+
+from amrvolumerenderer_amd import runtime, scenes
+from amrvolumerenderer_amd.compositor import FramePlan
+from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+from amrvolumerenderer_amd.types import make_params
+
+import plan_helpers as PH
+from helpers import assert_bit_equal, device_box
+from test_frame_plan import local_indices, painted_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_ranks,policy,size,transparency", [
+    (1, "morton", (96, 64), 0.9), (2, "morton", (75, 43), 0.8), (4, "round_robin", (75, 43), 0.8),
+    (8, "morton", (128, 128), 0.0), (3, "block", (50, 70), 0.97)])
+def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency):
+    W, H = size
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cam = scenes.default_camera()
+    cells, layers, hints, ref = painted_scene(O, spec, cam, W, H, transparency)
+    scenes.assign_owners(spec, n_ranks, policy)
+    owners = [b.owner for b in spec.boxes]
+    want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
+    meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+    params = make_params(W, H, spec.scalar_range, transparency, ref, spec.bounds)
+
+    plans, sends = [], []
+    for r in range(n_ranks):
+        plan = FramePlan(meta, params, cam, r, n_ranks)
+        local = [device_box(ctx, cells[i], spec.boxes[i].min_corner, spec.boxes[i].max_corner,
+                            spec.boxes[i].level, r)
+                 for i in scenes.local_box_indices(spec, r)]
+        scene = ctx.create_scene(local, spec.transform)
+        out = torch.full((max(plan.send_floats, 1),), float("nan"), device=ctx.device)
+        send = scene.render_plan(plan, out=out)
+        ctx.synchronize()
+        send = send.cpu().numpy()
+        # the march must have written exactly the layout documented in include/avr_hip.h
+        run_layers = PH.oracle_run_layers(O, layers, plan)
+        expect = PH.pack_send_buffer(plan, run_layers)
+        written = ~np.isnan(expect)
+        assert_bit_equal(send[written], expect[written], f"send buffer of rank {r}")
+        assert np.all(np.isnan(send[~written][: max(plan.send_floats - written.sum(), 0)]))
+        plans.append(plan)
+        sends.append(send)
+
+    recvs = PH.route(plans, sends)
+    got = np.zeros((W * H, 5), np.float32)
+    got8 = np.zeros((W * H, 3), np.uint8)
+    for plan, recv in zip(plans, recvs):
+        dev = torch.from_numpy(np.ascontiguousarray(recv)).to(ctx.device)
+        if dev.numel() == 0:
+            dev = torch.zeros(1, device=ctx.device)
+        piece, rgb8 = ctx.fold_plan(plan, dev, want_rgb8=True)
+        ctx.synchronize()
+        got[plan.piece_begin:plan.piece_end] = piece.cpu().numpy()
+        got8[plan.piece_begin:plan.piece_end] = rgb8.cpu().numpy()
+    assert_bit_equal(got, want, f"{n_ranks} ranks {policy}")
+    assert np.array_equal(got8, O.quantize_rgb8(want, W, H)[::-1].reshape(-1, 3))
+
+
+@pytest.mark.parametrize("antialiasing", [1, 4])
+def test_frame_renderer_single_rank(O, ctx, antialiasing):
+    root = int(round(antialiasing ** 0.5))
+    W, H = 64, 40
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cam = scenes.default_camera()
+    cells, layers, hints, ref = painted_scene(O, spec, cam, W * root, H * root, 0.5)
+    owners = [0] * len(cells)
+    want, _, _ = O.compose_layered(layers, hints, owners, np.arange(len(cells)), 1)
+    if root > 1:
+        want = O.downsample(want, W, H, root).reshape(-1, 5)
+    want8 = O.quantize_rgb8(want, W, H)
+
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+    assert np.float32(renderer.reference_sample_distance) == np.float32(ref)
+    image, rgb8 = renderer.render(RenderParameters(W, H, 0.5, antialiasing), cam, want_image=True)
+    ctx.synchronize()
+    assert_bit_equal(image.cpu().numpy(), want, "frame image")
+    assert np.array_equal(rgb8.cpu().numpy(), want8)
+
+
+def test_render_parameter_validation(ctx):
+    from amrvolumerenderer_amd.renderer import validate_render_parameters
+    with pytest.raises(ValueError):
+        validate_render_parameters(RenderParameters(64, 64, 0.0, 3))  # not a perfect square
+    with pytest.raises(ValueError):
+        validate_render_parameters(RenderParameters(0, 64))
+    with pytest.raises(ValueError):
+        validate_render_parameters(RenderParameters(64, 64, 1.5))
+    assert validate_render_parameters(RenderParameters(64, 64, 0.2, 9)) == 3
