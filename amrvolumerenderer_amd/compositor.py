@@ -119,9 +119,12 @@ class DirectSendCompositor:
     (runtime.Context on a GPU; the CPU tests plug in a stand-in built on the oracle);
     `process_group` is a torch.distributed group (RCCL "nccl" backend on GPUs)."""
 
-    def __init__(self, ops, process_group=None):
+    def __init__(self, ops, process_group=None, stage_through_host: bool = False):
         self.ops = ops
         self.process_group = process_group
+        # rehearsal mode: a gloo group with device tensors (several ranks sharing one GPU);
+        # collectives then run on host copies.  Never used with the RCCL backend.
+        self.stage_through_host = stage_through_host
 
     def exchange(self, plan: FramePlan, send_buffer):
         """One all-to-all: block for peer s -> rank s."""
@@ -129,6 +132,12 @@ class DirectSendCompositor:
         import torch.distributed as dist
         if plan.n_ranks == 1:
             return send_buffer
+        if self.stage_through_host:
+            host_recv = torch.empty(max(plan.recv_floats, 1), dtype=send_buffer.dtype)
+            dist.all_to_all_single(host_recv[:plan.recv_floats],
+                                   send_buffer[:plan.send_floats].cpu(), plan.recv_splits,
+                                   plan.send_splits, group=self.process_group)
+            return host_recv.to(send_buffer.device)
         recv = torch.empty(max(plan.recv_floats, 1), dtype=send_buffer.dtype,
                            device=send_buffer.device)
         dist.all_to_all_single(recv[:plan.recv_floats], send_buffer[:plan.send_floats],
@@ -148,6 +157,14 @@ class DirectSendCompositor:
         import torch.distributed as dist
         if plan.n_ranks == 1:
             return piece
+        if self.stage_through_host and piece.device.type != "cpu":
+            device = piece.device
+            self.stage_through_host = False
+            try:
+                full = self.gather(plan, piece.cpu(), dst)
+            finally:
+                self.stage_through_host = True
+            return full.to(device) if full is not None else None
         from . import runtime
         ranges = [runtime.piece_range(plan.n_pixels, k, plan.n_ranks) for k in range(plan.n_ranks)]
         max_len = max(e - b for b, e in ranges)

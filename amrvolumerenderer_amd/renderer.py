@@ -63,7 +63,8 @@ class FrameRenderer:
     def __init__(self, ctx: runtime.Context, all_boxes: Sequence[AmrBox],
                  local_boxes: Sequence[AmrBox], transform: ScalarTransform,
                  bounds: VolumeBounds, scalar_range=(0.0, 1.0), rank: int = 0,
-                 n_ranks: int = 1, process_group=None, color_map=None):
+                 n_ranks: int = 1, process_group=None, color_map=None,
+                 stage_through_host: bool = False):
         self.ctx = ctx
         self.rank = rank
         self.n_ranks = n_ranks
@@ -74,7 +75,7 @@ class FrameRenderer:
         self.scalar_range = tuple(scalar_range)
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
-        self.compositor = DirectSendCompositor(ctx, process_group)
+        self.compositor = DirectSendCompositor(ctx, process_group, stage_through_host)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
         if n_local != len(self.local_boxes):
             raise ValueError("local_boxes does not match the ownership of all_boxes")

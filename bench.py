@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the bounded cpu_baseline sample")
     ap.add_argument("--orbit", type=int, default=0, help="average over this many orbit views")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="debug: all ranks share cuda:0 and talk over gloo through host copies "
+                         "(exercises the N>1 code path on a 1-GPU box; not a measurement)")
     return ap.parse_args()
 
 
@@ -71,7 +74,7 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
     offsets = [0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15]
     picks = [i for o in offsets for i in range(o, n, 16)]
     total_samples, total_time, used = 0, 0.0, 0
-    for i in picks:
+    for i in picks * 8:   # whole frames back to back until the time budget is reached
         box = local_boxes[i]
         cells = box.values.cpu().numpy()
         ob = O.make_box(cells, box.min_corner, box.max_corner)
@@ -87,8 +90,8 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
         "unit": "Mray-samples/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle VolumePainter::paint of {used} of {n} boxes (stride-16 sweep of the "
-                  f"level-major box list) at {params.width}x{params.height}, same camera and "
+        "sample": f"oracle VolumePainter::paint of {used} box paints ({n} boxes in the scene; "
+                  f"stride-16 sweeps of the level-major box list, repeated) at {params.width}x{params.height}, same camera and "
                   f"transfer function, {total_samples} samples in {total_time:.1f} s, "
                   f"OpenMP over image rows",
     }
@@ -108,12 +111,17 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
 
     from amrvolumerenderer_amd import build as avr_build
@@ -138,7 +146,8 @@ def main():
     all_boxes, local_boxes = build_scene_on_device(ctx, spec, rank)
     torch.cuda.synchronize()
     renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
-                             spec.scalar_range, rank, world, group)
+                             spec.scalar_range, rank, world, group,
+                             stage_through_host=args.rehearse_on_one_gpu)
     rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
                                antialiasing=args.antialiasing)
     cameras = ([scenes.orbit_camera(v, args.orbit) for v in range(args.orbit)]
@@ -154,6 +163,8 @@ def main():
         torch.cuda.synchronize()
         s = samples_dev.clone()
         if world > 1:
+            if args.rehearse_on_one_gpu:
+                s = s.cpu()
             dist.all_reduce(s, group=group)
         frame_samples.append(int(s.item()))
     local_runs = renderer.last_plan.n_local_runs
@@ -197,7 +208,8 @@ def main():
     elapsed = time.perf_counter() - t0
     renderer.paint = orig_paint
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+    t = torch.tensor([elapsed], dtype=torch.float64,
+                     device="cpu" if args.rehearse_on_one_gpu else ctx.device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     elapsed = float(t.item())
