@@ -120,7 +120,7 @@ def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 
     _, rgb8 = renderer.render(RenderParameters(options.width, options.height,
                                                options.box_transparency, options.antialiasing,
                                                options.visibility_graph), options.camera)
-    ctx.synchronize()
+    renderer.synchronize()
     if rank == 0:
         if not save_ppm(rgb8, options.output_filename):
             return 1

@@ -75,7 +75,10 @@ class FrameRenderer:
         self.scalar_range = tuple(scalar_range)
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
-        self.compositor = DirectSendCompositor(ctx, process_group, stage_through_host)
+        # Second context = second HIP stream: frame i's exchange, fold and gather run there while
+        # frame i+1 is classified and marched on ctx.stream (frames are independent).
+        self.comm_ctx = runtime.Context(ctx.device_index)
+        self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
         if n_local != len(self.local_boxes):
             raise ValueError("local_boxes does not match the ownership of all_boxes")
@@ -85,7 +88,9 @@ class FrameRenderer:
         # coarsest min spacing over all ranks == MPI_Allreduce(MAX) of VolumeRenderer.cpp:1166
         self.reference_sample_distance = runtime.reference_sample_distance(
             self.all_boxes, bounds.min_corner, bounds.max_corner)
-        self._send: Optional[torch.Tensor] = None
+        self._send: List[Optional[torch.Tensor]] = [None, None]   # double-buffered send layout
+        self._send_free: List[Optional[torch.cuda.Event]] = [None, None]
+        self._frame = 0
         self.last_plan: Optional[FramePlan] = None
 
     # -- planning (host) -------------------------------------------------------------------------
@@ -102,12 +107,17 @@ class FrameRenderer:
                          _box_array=self._box_array, _owner_array=self._owner_array)
 
     # -- one frame ------------------------------------------------------------------------------
-    def paint(self, plan: FramePlan, samples: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Classify + march of this rank's runs into the sparse send buffer."""
+    def paint(self, plan: FramePlan, samples: Optional[torch.Tensor] = None,
+              slot: int = 0) -> torch.Tensor:
+        """Classify + march of this rank's runs into the sparse send buffer `slot`."""
         need = max(plan.send_floats, 1)
-        if self._send is None or self._send.numel() < need:
-            self._send = self.ctx.empty(need)
-        return self.scene.render_plan(plan, out=self._send, samples=samples)
+        if self._send[slot] is None or self._send[slot].numel() < need:
+            self._send[slot] = self.ctx.empty(need)
+        return self.scene.render_plan(plan, out=self._send[slot], samples=samples)
+
+    def synchronize(self) -> None:
+        self.ctx.synchronize()
+        self.comm_ctx.synchronize()
 
     def render(self, p: RenderParameters, camera: CameraParameters,
                samples: Optional[torch.Tensor] = None, want_image: bool = False,
@@ -115,18 +125,31 @@ class FrameRenderer:
         """One frame.  On rank 0 returns (image, rgb8): rgb8 = the output file's pixel bytes
         [H, W, 3] (rows top-down, SavePPM.cpp:25), image = the gathered (downsampled) depth-sort
         image [H, W, 5] if want_image (or antialiasing > 1), else None.  Other ranks get
-        (None, None)."""
+        (None, None).  The results are produced on comm_ctx.stream: call synchronize() (or order
+        your stream after it) before reading them."""
         params, root = self.make_params(p)
         plan = self.plan(params, camera, group_order)
         self.last_plan = plan
-        ctx = self.ctx
+        ctx, comm = self.ctx, self.comm_ctx
+        slot = self._frame & 1
+        self._frame += 1
         ctx.join()  # cell data / earlier torch work on the caller's stream
+        if self._send_free[slot] is not None:
+            # the frame before last read this send buffer on the other stream
+            ctx.stream.wait_event(self._send_free[slot])
         with torch.cuda.stream(ctx.stream):
-            send = self.paint(plan, samples)
+            send = self.paint(plan, samples, slot)
+            painted = torch.cuda.Event()
+            painted.record(ctx.stream)
+        with torch.cuda.stream(comm.stream):
+            comm.stream.wait_event(painted)
             # 8-bit conversion is per pixel, so without antialiasing it is done on each rank's
             # piece before the gather (3 bytes per pixel on the wire instead of 20)
             early_rgb8 = (root == 1)
             piece, piece_rgb8 = self.compositor.compose(plan, send, want_rgb8=early_rgb8)
+            released = torch.cuda.Event()
+            released.record(comm.stream)
+            self._send_free[slot] = released
             image = None
             rgb8 = None
             if early_rgb8:
@@ -140,8 +163,8 @@ class FrameRenderer:
             else:
                 full = self.compositor.gather(plan, piece, dst=0)
                 if full is not None:
-                    image = ctx.downsample(full.reshape(-1), p.width, p.height, root)
-                    rgb8 = ctx.quantize_rgb8(image.reshape(-1), p.width, p.height)
+                    image = comm.downsample(full.reshape(-1), p.width, p.height, root)
+                    rgb8 = comm.quantize_rgb8(image.reshape(-1), p.width, p.height)
         return image, rgb8
 
 

@@ -159,7 +159,7 @@ def main():
     for cam in cameras:
         samples_dev.zero_()
         renderer.render(rparams, cam, samples=samples_dev)
-        ctx.synchronize()
+        renderer.synchronize()
         torch.cuda.synchronize()
         s = samples_dev.clone()
         if world > 1:
@@ -176,7 +176,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    ctx.synchronize()
+    renderer.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -187,11 +187,11 @@ def main():
     kernel_events = []
     orig_paint = renderer.paint
 
-    def timed_paint(plan, samples=None):
+    def timed_paint(plan, samples=None, slot=0):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(ctx.stream)
-        out = orig_paint(plan, samples)
+        out = orig_paint(plan, samples, slot)
         e1.record(ctx.stream)
         kernel_events.append((e0, e1))
         return out
@@ -201,7 +201,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    ctx.synchronize()
+    renderer.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,7 +225,7 @@ def main():
     # emitted layer pixel; samples of THIS rank's launch:
     samples_dev.zero_()
     renderer.render(rparams, cameras[0], samples=samples_dev)
-    ctx.synchronize()
+    renderer.synchronize()
     my_samples = int(samples_dev.item())
     n_pixels = params.width * params.height
     algo_bytes = 8.0 * my_samples + 4.0 * send_floats

@@ -45,7 +45,7 @@ def _worker(rank, world, port, policy, antialiasing, out_path):
         samples = torch.zeros(1, dtype=torch.int64, device=ctx.device)
         image, rgb8 = renderer.render(RenderParameters(W, H, 0.85, antialiasing), cam,
                                       samples=samples, want_image=True)
-        ctx.synchronize()
+        renderer.synchronize()
         if rank == 0:
             owners = [b.owner for b in spec.boxes]
             want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, world),

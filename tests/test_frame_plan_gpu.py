@@ -85,7 +85,7 @@ def test_frame_renderer_single_rank(O, ctx, antialiasing):
     renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
     assert np.float32(renderer.reference_sample_distance) == np.float32(ref)
     image, rgb8 = renderer.render(RenderParameters(W, H, 0.5, antialiasing), cam, want_image=True)
-    ctx.synchronize()
+    renderer.synchronize()
     assert_bit_equal(image.cpu().numpy(), want, "frame image")
     assert np.array_equal(rgb8.cpu().numpy(), want8)
 
@@ -99,3 +99,24 @@ def test_render_parameter_validation(ctx):
     with pytest.raises(ValueError):
         validate_render_parameters(RenderParameters(64, 64, 1.5))
     assert validate_render_parameters(RenderParameters(64, 64, 0.2, 9)) == 3
+
+
+def test_pipelined_frames_reuse_buffers_safely(O, ctx):
+    """Frames are pipelined over two streams with double-buffered send layouts: a burst of
+    frames with different cameras / sizes must each equal its own single-frame result."""
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+    jobs = [(scenes.orbit_camera(v), RenderParameters(96 + 16 * (v % 3), 64, 0.3 * (v % 3), 1))
+            for v in range(7)]
+    burst = [renderer.render(p, cam, want_image=True) for cam, p in jobs]  # no sync in between
+    renderer.synchronize()
+    burst = [(img.cpu().numpy(), rgb.cpu().numpy()) for img, rgb in burst]
+    for (cam, p), (img, rgb) in zip(jobs, burst):
+        one_img, one_rgb = renderer.render(p, cam, want_image=True)
+        renderer.synchronize()
+        assert np.array_equal(img.view(np.uint32), one_img.cpu().numpy().view(np.uint32))
+        assert np.array_equal(rgb, one_rgb.cpu().numpy())
