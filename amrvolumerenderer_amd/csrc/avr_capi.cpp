@@ -204,6 +204,10 @@ int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
   launch.n_boxes = n_boxes;
   launch.n_classify_tiles = plan.classify_tile_begin.back();
   launch.supertile_order_dev = static_cast<const uint32_t*>(ctx->supertiles.dev());
+  launch.only_mode = plan.boxes.empty() ? -1 : plan.boxes[0].index_mode;
+  for (const avr::BoxDev& dev : plan.boxes) {
+    if (dev.index_mode != launch.only_mode) launch.only_mode = -1;
+  }
   return avr::launch_render_runs(launch, ctx->stream);
 }
 

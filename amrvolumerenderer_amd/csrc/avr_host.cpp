@@ -703,6 +703,10 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
       const uint64_t bricks_z = static_cast<uint64_t>((dev.nz + kBrickZ - 1) / kBrickZ);
       const uint64_t chunks = static_cast<uint64_t>((dev.nx + kClassifyChunk - 1) / kClassifyChunk);
       const uint64_t tiles = bricks_y * bricks_z * chunks;
+      // 24-bit multiplies in the bricklet address arithmetic of the march
+      if (bricks_x * bricks_y * kBrickBytes >= (uint64_t{1} << 24)) {
+        throw std::invalid_argument("box cross-section too large (ceil(nx/8)*ceil(ny/4) >= 2^17)");
+      }
       const uint64_t total_tiles = plan->classify_tile_begin[static_cast<std::size_t>(b)] + tiles;
       if (total_tiles >= (uint64_t{1} << 31)) throw std::invalid_argument("scene has too many cells");
       plan->classify_tile_begin[static_cast<std::size_t>(b) + 1] = static_cast<uint32_t>(total_tiles);

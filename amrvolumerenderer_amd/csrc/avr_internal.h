@@ -128,6 +128,7 @@ struct RenderLaunch {
   int n_boxes;
   uint32_t n_classify_tiles;
   const uint32_t* supertile_order_dev;  // supertile_slots(width, height) entries
+  int only_mode;                        // the IndexMode shared by every box, or -1
 };
 // classify pass (cells -> table indices) followed by the march, both on `stream`
 int launch_render_runs(const RenderLaunch& launch, void* stream);

@@ -153,14 +153,16 @@ __device__ __forceinline__ void slab_axis(float origin, float direction, float i
 // Byte offset of cell (i, j, k) inside a box's classified volume: 128-byte bricklets of
 // 8 x 4 x 4 cells, so that the cells a bundle of neighbouring rays touches over several steps
 // share cache lines in all three directions (an x-fastest row would only help along x).
-__device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, int bricks_x,
-                                                    int bricks_y) {
-  const uint32_t brick = (static_cast<uint32_t>(k >> 2) * static_cast<uint32_t>(bricks_y) +
-                          static_cast<uint32_t>(j >> 2)) * static_cast<uint32_t>(bricks_x) +
-                         static_cast<uint32_t>(i >> 3);
-  const uint32_t within = (static_cast<uint32_t>(k & 3) << 5) | (static_cast<uint32_t>(j & 3) << 3) |
-                          static_cast<uint32_t>(i & 7);
-  return (brick << 7) | within;
+__device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_t row_pitch,
+                                                    uint32_t plane_pitch) {
+  // ((k>>2)*by + (j>>2))*bx*128 + (i>>3)*128 + (k&3)*32 + (j&3)*8 + (i&7)
+  //   = i + (i>>3)*120  +  j*8 + (j>>2)*(bx*128 - 32)  +  k*32 + (k>>2)*(by*bx*128 - 128)
+  // with row_pitch = bx*128 - 32 and plane_pitch = by*bx*128 - 128, both < 2^24 (host check),
+  // so every product is a 24-bit multiply (full-rate v_mad_u32_u24).
+  uint32_t offset = __umul24(static_cast<uint32_t>(i) >> 3, 120u) + static_cast<uint32_t>(i);
+  offset += __umul24(static_cast<uint32_t>(j) >> 2, row_pitch) + (static_cast<uint32_t>(j) << 3);
+  offset += __umul24(static_cast<uint32_t>(k) >> 2, plane_pitch) + (static_cast<uint32_t>(k) << 5);
+  return offset;
 }
 
 // Cell indices of an inside sample: the reference's clamp(int(floor((pos - min) / d)), 0, n - 1)
@@ -168,8 +170,9 @@ __device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, int bri
 // truncation equals floor and only the upper clamp can bind on the multiply paths; the
 // exact-divide path restates the reference literally.
 template <int MODE>
-__device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, int bricks_x, int bricks_y,
-                                                float fx, float fy, float fz) {
+__device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, uint32_t row_pitch,
+                                                uint32_t plane_pitch, float fx, float fy,
+                                                float fz) {
   int i = 0, j = 0, k = 0;
   bool exact = (MODE == kExactDivide);
   if (MODE != kExactDivide) {
@@ -202,7 +205,7 @@ __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, int bricks_x,
     j = ej;
     k = ek;
   }
-  return bricklet_offset(i, j, k, bricks_x, bricks_y);
+  return bricklet_offset(i, j, k, row_pitch, plane_pitch);
 }
 
 typedef const double __attribute__((address_space(1))) * GlobalCells;
@@ -244,8 +247,10 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   const float step = box.sample_dist;
   const uint8_t __attribute__((address_space(1)))* cells =
       (const uint8_t __attribute__((address_space(1)))*)(classified + box.cls_offset);
-  const int bricks_x = (box.nx + kBrickX - 1) >> 3;
-  const int bricks_y = (box.ny + kBrickY - 1) >> 2;
+  const uint32_t bricks_x = static_cast<uint32_t>(box.nx + kBrickX - 1) >> 3;
+  const uint32_t bricks_y = static_cast<uint32_t>(box.ny + kBrickY - 1) >> 2;
+  const uint32_t row_pitch = bricks_x * kBrickBytes - 32u;
+  const uint32_t plane_pitch = bricks_y * bricks_x * kBrickBytes - 128u;
 
   float distance = tmin + box.mesh_eps;
   if (distance < 0.0f) distance = box.mesh_eps;
@@ -279,35 +284,41 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     interior = AVR_INSIDE(ax, ay, az) && AVR_INSIDE(bx, by, bz);
   }
   if (interior) {
-    // two steps per trip: both cell bytes and both table entries are requested before the
-    // first is consumed; the second sample is accumulated only if the reference's loop
-    // condition (distance < tmax && accumA < 1) still holds after the first
-    while (distance < safe_end && acc_a < 1.0f) {
-      const float d2 = distance + step;
-      const bool two = d2 < safe_end;
+    // two steps per trip while both lie below safe_end: both cell bytes and both table entries
+    // are requested before the first is consumed; the second sample is accumulated only if
+    // the reference's loop condition (accumA < 1) still holds after the first.  A last single
+    // step below safe_end, if any, falls through to the general loop.
+    float d2 = distance + step;
+    while (d2 < safe_end && acc_a < 1.0f) {
       const float p1x = ray.ox + ray.dx * distance, p1y = ray.oy + ray.dy * distance,
                   p1z = ray.oz + ray.dz * distance;
+      const float p2x = ray.ox + ray.dx * d2, p2y = ray.oy + ray.dy * d2,
+                  p2z = ray.oz + ray.dz * d2;
       const uint32_t off1 =
-          cell_offset<MODE>(box, bricks_x, bricks_y, p1x - min_x, p1y - min_y, p1z - min_z);
+          cell_offset<MODE>(box, row_pitch, plane_pitch, p1x - min_x, p1y - min_y, p1z - min_z);
+      const uint32_t off2 =
+          cell_offset<MODE>(box, row_pitch, plane_pitch, p2x - min_x, p2y - min_y, p2z - min_z);
       const int idx1 = cells[off1];
-      int idx2 = 0;
-      if (two) {
-        const float p2x = ray.ox + ray.dx * d2, p2y = ray.oy + ray.dy * d2,
-                    p2z = ray.oz + ray.dz * d2;
-        const uint32_t off2 =
-            cell_offset<MODE>(box, bricks_x, bricks_y, p2x - min_x, p2y - min_y, p2z - min_z);
-        idx2 = cells[off2];
-      }
+      const int idx2 = cells[off2];
       const float4 s1 = table[idx1];
       const float4 s2 = table[idx2];
       AVR_ACCUMULATE(s1);
-      if (STATS) ++fetches;
-      distance = d2;
-      if (two && acc_a < 1.0f) {
-        AVR_ACCUMULATE(s2);
-        if (STATS) ++fetches;
-        distance = d2 + step;
-      }
+      // Second sample without a branch (a branch would let the compiler sink the second load
+      // below it and serialise the two memory round trips): accumulate into copies and keep
+      // them only if the reference's loop would have run this step.
+      const bool second = acc_a < 1.0f;
+      const float alpha2 = s2.w * (1.0f - acc_a);
+      const float r2 = acc_r + s2.x * alpha2;
+      const float g2 = acc_g + s2.y * alpha2;
+      const float b2 = acc_b + s2.z * alpha2;
+      const float a2 = acc_a + alpha2;
+      acc_r = second ? r2 : acc_r;
+      acc_g = second ? g2 : acc_g;
+      acc_b = second ? b2 : acc_b;
+      acc_a = second ? a2 : acc_a;
+      distance = second ? (d2 + step) : d2;
+      if (STATS) fetches += second ? 2u : 1u;
+      d2 = distance + step;
     }
   }
 
@@ -321,7 +332,7 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   // with an inside test reproduces both.
   while (distance < tmax && acc_a < 1.0f) {
     if (AVR_INSIDE(pos_x, pos_y, pos_z)) {
-      const uint32_t offset = cell_offset<MODE>(box, bricks_x, bricks_y, pos_x - min_x,
+      const uint32_t offset = cell_offset<MODE>(box, row_pitch, plane_pitch, pos_x - min_x,
                                                 pos_y - min_y, pos_z - min_z);
       // the cell's transfer-function table index, computed from the f64 cell value by the
       // classify pass of this frame (same arithmetic as VolumePainter.cpp:870-883)
@@ -362,7 +373,9 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   return out;
 }
 
-template <bool STATS>
+// ONLY_MODE >= 0: every box of the launch uses that IndexMode (the common case: one scene, one
+// kind of spacing), so only that march variant is compiled in; -1 dispatches per box.
+template <bool STATS, int ONLY_MODE>
 __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
@@ -444,7 +457,13 @@ __global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
       if (hit) {
         const float4* table = lds_tables + box.lut * kTableSize;
         Layer5 layer;
-        if (box.index_mode == kPow2Multiply) {  // wave-uniform
+        if (ONLY_MODE == kPow2Multiply) {
+          layer = march_box<STATS, kPow2Multiply>(box, fc, classified, table, ray, tmin, tmax,
+                                                  fetches);
+        } else if (ONLY_MODE == kReciprocal) {
+          layer = march_box<STATS, kReciprocal>(box, fc, classified, table, ray, tmin, tmax,
+                                                fetches);
+        } else if (box.index_mode == kPow2Multiply) {  // wave-uniform
           layer = march_box<STATS, kPow2Multiply>(box, fc, classified, table, ray, tmin, tmax,
                                                   fetches);
         } else if (box.index_mode == kReciprocal) {
@@ -910,19 +929,21 @@ int launch_render_runs(const RenderLaunch& L, void* stream_v) {
     const int status = check_launch("classify_kernel");
     if (status != AVR_OK) return status;
   }
-  if (L.samples_out != nullptr) {
-    hipLaunchKernelGGL(render_runs_kernel<true>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
-                       stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
-                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, L.run_rects_dev,
-                       L.run_blocks_dev, tiles_x, tiles_y, L.supertile_order_dev, L.out_layers,
-                       L.samples_out);
+  const bool stats = L.samples_out != nullptr;
+#define AVR_LAUNCH(STATS, ONLY)                                                                 \
+  hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \
+                     lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,      \
+                     L.n_tables, L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces,              \
+                     L.run_rects_dev, L.run_blocks_dev, tiles_x, tiles_y, L.supertile_order_dev, \
+                     L.out_layers, L.samples_out)
+  if (L.only_mode == kPow2Multiply) {
+    if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
+  } else if (L.only_mode == kReciprocal) {
+    if (stats) AVR_LAUNCH(true, kReciprocal); else AVR_LAUNCH(false, kReciprocal);
   } else {
-    hipLaunchKernelGGL(render_runs_kernel<false>, dim3(blocks), dim3(kBlockThreads), lds_bytes,
-                       stream, L.consts, L.boxes_dev, L.classified, L.tables_dev, L.n_tables,
-                       L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces, L.run_rects_dev,
-                       L.run_blocks_dev, tiles_x, tiles_y, L.supertile_order_dev, L.out_layers,
-                       L.samples_out);
+    if (stats) AVR_LAUNCH(true, -1); else AVR_LAUNCH(false, -1);
   }
+#undef AVR_LAUNCH
   return check_launch("render_runs_kernel");
 }
 
