@@ -284,41 +284,67 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     interior = AVR_INSIDE(ax, ay, az) && AVR_INSIDE(bx, by, bz);
   }
   if (interior) {
-    // two steps per trip while both lie below safe_end: both cell bytes and both table entries
-    // are requested before the first is consumed; the second sample is accumulated only if
-    // the reference's loop condition (accumA < 1) still holds after the first.  A last single
-    // step below safe_end, if any, falls through to the general loop.
-    float d2 = distance + step;
-    while (d2 < safe_end && acc_a < 1.0f) {
-      const float p1x = ray.ox + ray.dx * distance, p1y = ray.oy + ray.dy * distance,
-                  p1z = ray.oz + ray.dz * distance;
-      const float p2x = ray.ox + ray.dx * d2, p2y = ray.oy + ray.dy * d2,
-                  p2z = ray.oz + ray.dz * d2;
-      const uint32_t off1 =
-          cell_offset<MODE>(box, row_pitch, plane_pitch, p1x - min_x, p1y - min_y, p1z - min_z);
-      const uint32_t off2 =
-          cell_offset<MODE>(box, row_pitch, plane_pitch, p2x - min_x, p2y - min_y, p2z - min_z);
+    // Four steps per trip while all four lie below safe_end: the four cell bytes and the four
+    // table entries are requested before the first is consumed (four memory round trips in
+    // flight per wave).  Sample k+1 is accumulated only if the reference's loop condition
+    // (accumA < 1) still holds after sample k -- done with selects, not branches, so the
+    // compiler cannot sink the later loads below the earlier accumulates.  Remaining steps
+    // below safe_end fall through to the general loop.
+    while (acc_a < 1.0f) {
+      const float d1 = distance;
+      const float d2 = d1 + step;
+      const float d3 = d2 + step;
+      const float d4 = d3 + step;
+      if (!(d4 < safe_end)) break;
+      const uint32_t off1 = cell_offset<MODE>(box, row_pitch, plane_pitch,
+                                              (ray.ox + ray.dx * d1) - min_x,
+                                              (ray.oy + ray.dy * d1) - min_y,
+                                              (ray.oz + ray.dz * d1) - min_z);
+      const uint32_t off2 = cell_offset<MODE>(box, row_pitch, plane_pitch,
+                                              (ray.ox + ray.dx * d2) - min_x,
+                                              (ray.oy + ray.dy * d2) - min_y,
+                                              (ray.oz + ray.dz * d2) - min_z);
+      const uint32_t off3 = cell_offset<MODE>(box, row_pitch, plane_pitch,
+                                              (ray.ox + ray.dx * d3) - min_x,
+                                              (ray.oy + ray.dy * d3) - min_y,
+                                              (ray.oz + ray.dz * d3) - min_z);
+      const uint32_t off4 = cell_offset<MODE>(box, row_pitch, plane_pitch,
+                                              (ray.ox + ray.dx * d4) - min_x,
+                                              (ray.oy + ray.dy * d4) - min_y,
+                                              (ray.oz + ray.dz * d4) - min_z);
       const int idx1 = cells[off1];
       const int idx2 = cells[off2];
+      const int idx3 = cells[off3];
+      const int idx4 = cells[off4];
       const float4 s1 = table[idx1];
       const float4 s2 = table[idx2];
+      const float4 s3 = table[idx3];
+      const float4 s4 = table[idx4];
       AVR_ACCUMULATE(s1);
-      // Second sample without a branch (a branch would let the compiler sink the second load
-      // below it and serialise the two memory round trips): accumulate into copies and keep
-      // them only if the reference's loop would have run this step.
-      const bool second = acc_a < 1.0f;
-      const float alpha2 = s2.w * (1.0f - acc_a);
-      const float r2 = acc_r + s2.x * alpha2;
-      const float g2 = acc_g + s2.y * alpha2;
-      const float b2 = acc_b + s2.z * alpha2;
-      const float a2 = acc_a + alpha2;
-      acc_r = second ? r2 : acc_r;
-      acc_g = second ? g2 : acc_g;
-      acc_b = second ? b2 : acc_b;
-      acc_a = second ? a2 : acc_a;
-      distance = second ? (d2 + step) : d2;
-      if (STATS) fetches += second ? 2u : 1u;
-      d2 = distance + step;
+      unsigned taken = 1u;
+      float next = d2;
+#define AVR_ACCUMULATE_IF_RUNNING(sample, following)          \
+      {                                                         \
+        const bool running_ = acc_a < 1.0f;                     \
+        const float alpha_ = (sample).w * (1.0f - acc_a);       \
+        const float r_ = acc_r + (sample).x * alpha_;           \
+        const float g_ = acc_g + (sample).y * alpha_;           \
+        const float b_ = acc_b + (sample).z * alpha_;           \
+        const float a_ = acc_a + alpha_;                        \
+        acc_r = running_ ? r_ : acc_r;                          \
+        acc_g = running_ ? g_ : acc_g;                          \
+        acc_b = running_ ? b_ : acc_b;                          \
+        acc_a = running_ ? a_ : acc_a;                          \
+        next = running_ ? (following) : next;                   \
+        taken += running_ ? 1u : 0u;                            \
+      }
+      // once accumA reaches 1 it stays >= 1 (alpha >= 0), so the later samples are rejected too
+      AVR_ACCUMULATE_IF_RUNNING(s2, d3)
+      AVR_ACCUMULATE_IF_RUNNING(s3, d4)
+      AVR_ACCUMULATE_IF_RUNNING(s4, d4 + step)
+#undef AVR_ACCUMULATE_IF_RUNNING
+      distance = next;
+      if (STATS) fetches += taken;
     }
   }
 
@@ -375,8 +401,11 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
 
 // ONLY_MODE >= 0: every box of the launch uses that IndexMode (the common case: one scene, one
 // kind of spacing), so only that march variant is compiled in; -1 dispatches per box.
+// <= 80 SGPRs: 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16))
+// (MI355X_MICROARCH.md, "Residency"), i.e. 8 per CU only up to 80 SGPRs, 6 at 98+.
 template <bool STATS, int ONLY_MODE>
-__global__ __launch_bounds__(kBlockThreads) void render_runs_kernel(
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(80))) void
+render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
