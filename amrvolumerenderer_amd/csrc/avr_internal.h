@@ -87,7 +87,7 @@ struct FramePlan {
 // Screen tiling of the march kernel: workgroup = 16 x 16 pixels, super-tile = 8 x 8 workgroups
 // (Morton order inside), super-tiles dealt round-robin to the 8 XCDs in `supertile_order`.
 constexpr int kTile = 16;
-constexpr int kSuperTileSide = 8;
+constexpr int kSuperTileSide = 2;
 constexpr int kSuperTileTiles = kSuperTileSide * kSuperTileSide;
 constexpr int kXcds = 8;
 // Number of super-tile slots of a w x h image (multiple of kXcds).
