@@ -131,6 +131,8 @@ SIGNATURES = {
     "avr_frame_plan_send_block": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_i64), _ip, _ip]),
     "avr_frame_plan_recv_block": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _ip, _ip]),
     "avr_render_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_classify_plan": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_blend_depthsort_f32x5": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "avr_blend_rgba_f32x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),

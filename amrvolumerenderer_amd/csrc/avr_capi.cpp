@@ -67,6 +67,34 @@ class StagedBuffer {
 }  // namespace
 }  // namespace avr
 
+struct avr_scene {
+  avr_context* ctx = nullptr;
+  std::vector<avr_box> boxes;
+  avr_scalar_transform transform{};
+  // two classified volumes, so that the classify pass of frame i+1 can overlap the march of
+  // frame i (grow-only; a frame of the same scene never reallocates)
+  void* classified[2] = {nullptr, nullptr};
+  size_t classified_capacity[2] = {0, 0};
+  int device = 0;
+
+  ~avr_scene() {
+    for (void* buffer : classified) {
+      if (buffer != nullptr) (void)hipFree(buffer);
+    }
+  }
+  uint8_t* classified_slot(int slot, size_t bytes, hipStream_t stream) {
+    if (bytes > classified_capacity[slot]) {
+      avr::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+      if (classified[slot] != nullptr) (void)hipFree(classified[slot]);
+      classified[slot] = nullptr;
+      classified_capacity[slot] = 0;
+      avr::hip_check(hipMalloc(&classified[slot], bytes), "hipMalloc(classified)");
+      classified_capacity[slot] = bytes;
+    }
+    return static_cast<uint8_t*>(classified[slot]);
+  }
+};
+
 struct avr_context {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -74,8 +102,7 @@ struct avr_context {
   hipEvent_t staged = nullptr;   // recorded after the last upload that read the pinned mirrors
   bool staged_pending = false;
   avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin, supertiles, run_rects, run_blocks;
-  void* classified = nullptr;      // grow-only buffer of the frame's classified volume
-  size_t classified_capacity = 0;
+  avr_scene scratch_scene;         // classified storage of avr_paint_box
 
   void wait_staging() {
     if (staged_pending) {
@@ -96,11 +123,6 @@ struct avr_context {
   }
 };
 
-struct avr_scene {
-  avr_context* ctx = nullptr;
-  std::vector<avr_box> boxes;
-  avr_scalar_transform transform{};
-};
 
 namespace {
 
@@ -131,84 +153,97 @@ void require(bool condition, const char* message) {
 void bind_device(avr_context* ctx) {
   require(ctx != nullptr, "null context");
   avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
+  if (ctx->stream == nullptr) {  // no external stream was supplied: create the context's own
+    avr::hip_check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
+                   "hipStreamCreate");
+    ctx->stream = ctx->own_stream;
+  }
 }
 
-int render(avr_context* ctx, const avr_box* boxes, int n_boxes,
+enum Phase { kClassify = 1, kMarch = 2 };
+
+// One frame's device work for a list of boxes: the classify pass and/or the march.
+// `classified` must hold plan.classified_bytes bytes; `cached` (optional) carries the host
+// prologue from the classify call of a frame to its march call.
+int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const avr_scalar_transform& transform, const avr_paint_params& params,
            const avr_camera& camera, const int32_t* box_order, int n_order,
            const int32_t* run_end, int n_runs, int n_pieces,
            const std::vector<avr::RunRectDev>& run_rects,
-           const std::vector<avr::RunBlockDev>& run_blocks, float* out_layers,
-           uint64_t* samples_out) {
-  require(out_layers != nullptr, "null output image");
-  require(run_rects.size() == static_cast<size_t>(std::max(n_runs, 0)) &&
-              run_blocks.size() == static_cast<size_t>(std::max(n_runs, 0)) * n_pieces,
-          "run tables do not match the runs");
+           const std::vector<avr::RunBlockDev>& run_blocks, avr_scene* scene, int slot,
+           float* out_layers, uint64_t* samples_out, avr::FramePlan* cached) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
-  require(n_runs == 0 || (run_end != nullptr), "null run_end");
-  require(n_order == 0 || (box_order != nullptr), "null box_order");
-  int previous = 0;
-  for (int r = 0; r < n_runs; ++r) {
-    require(run_end[r] >= previous && run_end[r] <= n_order, "run_end must be non-decreasing");
-    previous = run_end[r];
+  require(slot == 0 || slot == 1, "classified slot must be 0 or 1");
+  avr::FramePlan local;
+  avr::FramePlan& plan = cached ? *cached : local;
+  if (plan.boxes.size() != static_cast<size_t>(n_boxes) || plan.supertile_order.empty()) {
+    avr::plan_frame(boxes, n_boxes, transform, params, camera, &plan);
   }
-  require(n_runs == 0 || run_end[n_runs - 1] == n_order, "runs must cover box_order");
-  for (int i = 0; i < n_order; ++i) {
-    require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
-  }
-
-  avr::FramePlan plan;
-  avr::plan_frame(boxes, n_boxes, transform, params, camera, &plan);
   if (n_runs == 0) return AVR_OK;
   require(plan.n_tables <= avr::kMaxLdsTables,
           "too many distinct sampling levels for the LDS transfer-function cache");
 
-  ctx->wait_staging();
-  ctx->upload(ctx->boxes, plan.boxes.data(), plan.boxes.size() * sizeof(avr::BoxDev));
-  ctx->upload(ctx->tables, plan.tables.data(), plan.tables.size() * sizeof(float));
-  ctx->upload(ctx->order, box_order, static_cast<size_t>(n_order) * sizeof(int32_t));
-  ctx->upload(ctx->run_end, run_end, static_cast<size_t>(n_runs) * sizeof(int32_t));
-  ctx->upload(ctx->tile_begin, plan.classify_tile_begin.data(),
-              plan.classify_tile_begin.size() * sizeof(uint32_t));
-  ctx->upload(ctx->supertiles, plan.supertile_order.data(),
-              plan.supertile_order.size() * sizeof(uint32_t));
-  ctx->upload(ctx->run_rects, run_rects.data(), run_rects.size() * sizeof(avr::RunRectDev));
-  ctx->upload(ctx->run_blocks, run_blocks.data(), run_blocks.size() * sizeof(avr::RunBlockDev));
-  ctx->mark_staging();
-  if (plan.classified_bytes > ctx->classified_capacity) {
-    // grow-only; a frame of the same scene never reallocates
-    avr::hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    if (ctx->classified != nullptr) (void)hipFree(ctx->classified);
-    ctx->classified = nullptr;
-    ctx->classified_capacity = 0;
-    avr::hip_check(hipMalloc(&ctx->classified, plan.classified_bytes), "hipMalloc(classified)");
-    ctx->classified_capacity = plan.classified_bytes;
-  }
-
   avr::RenderLaunch launch;
   launch.consts = plan.consts;
-  launch.boxes_dev = static_cast<const avr::BoxDev*>(ctx->boxes.dev());
-  launch.tables_dev = static_cast<const float*>(ctx->tables.dev());
-  launch.n_tables = plan.n_tables;
-  launch.order_dev = static_cast<const int32_t*>(ctx->order.dev());
-  launch.run_end_dev = static_cast<const int32_t*>(ctx->run_end.dev());
-  launch.n_order = n_order;
-  launch.n_runs = n_runs;
-  launch.n_pieces = n_pieces;
-  launch.run_rects_dev = static_cast<const avr::RunRectDev*>(ctx->run_rects.dev());
-  launch.run_blocks_dev = static_cast<const avr::RunBlockDev*>(ctx->run_blocks.dev());
-  launch.out_layers = out_layers;
-  launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
-  launch.classified = static_cast<uint8_t*>(ctx->classified);
-  launch.tile_begin_dev = static_cast<const uint32_t*>(ctx->tile_begin.dev());
   launch.n_boxes = n_boxes;
   launch.n_classify_tiles = plan.classify_tile_begin.back();
-  launch.supertile_order_dev = static_cast<const uint32_t*>(ctx->supertiles.dev());
-  launch.only_mode = plan.boxes.empty() ? -1 : plan.boxes[0].index_mode;
-  for (const avr::BoxDev& dev : plan.boxes) {
-    if (dev.index_mode != launch.only_mode) launch.only_mode = -1;
+  launch.classified = scene->classified_slot(slot, plan.classified_bytes, ctx->stream);
+
+  ctx->wait_staging();
+  ctx->upload(ctx->boxes, plan.boxes.data(), plan.boxes.size() * sizeof(avr::BoxDev));
+  launch.boxes_dev = static_cast<const avr::BoxDev*>(ctx->boxes.dev());
+  if (phases & kClassify) {
+    ctx->upload(ctx->tile_begin, plan.classify_tile_begin.data(),
+                plan.classify_tile_begin.size() * sizeof(uint32_t));
+    launch.tile_begin_dev = static_cast<const uint32_t*>(ctx->tile_begin.dev());
   }
-  return avr::launch_render_runs(launch, ctx->stream);
+  if (phases & kMarch) {
+    require(out_layers != nullptr, "null output image");
+    require(n_runs == 0 || (run_end != nullptr), "null run_end");
+    require(n_order == 0 || (box_order != nullptr), "null box_order");
+    require(run_rects.size() == static_cast<size_t>(n_runs) &&
+                run_blocks.size() == static_cast<size_t>(n_runs) * n_pieces,
+            "run tables do not match the runs");
+    int previous = 0;
+    for (int r = 0; r < n_runs; ++r) {
+      require(run_end[r] >= previous && run_end[r] <= n_order, "run_end must be non-decreasing");
+      previous = run_end[r];
+    }
+    require(run_end[n_runs - 1] == n_order, "runs must cover box_order");
+    for (int i = 0; i < n_order; ++i) {
+      require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
+    }
+    ctx->upload(ctx->tables, plan.tables.data(), plan.tables.size() * sizeof(float));
+    ctx->upload(ctx->order, box_order, static_cast<size_t>(n_order) * sizeof(int32_t));
+    ctx->upload(ctx->run_end, run_end, static_cast<size_t>(n_runs) * sizeof(int32_t));
+    ctx->upload(ctx->supertiles, plan.supertile_order.data(),
+                plan.supertile_order.size() * sizeof(uint32_t));
+    ctx->upload(ctx->run_rects, run_rects.data(), run_rects.size() * sizeof(avr::RunRectDev));
+    ctx->upload(ctx->run_blocks, run_blocks.data(), run_blocks.size() * sizeof(avr::RunBlockDev));
+    launch.tables_dev = static_cast<const float*>(ctx->tables.dev());
+    launch.n_tables = plan.n_tables;
+    launch.order_dev = static_cast<const int32_t*>(ctx->order.dev());
+    launch.run_end_dev = static_cast<const int32_t*>(ctx->run_end.dev());
+    launch.n_order = n_order;
+    launch.n_runs = n_runs;
+    launch.n_pieces = n_pieces;
+    launch.run_rects_dev = static_cast<const avr::RunRectDev*>(ctx->run_rects.dev());
+    launch.run_blocks_dev = static_cast<const avr::RunBlockDev*>(ctx->run_blocks.dev());
+    launch.out_layers = out_layers;
+    launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
+    launch.supertile_order_dev = static_cast<const uint32_t*>(ctx->supertiles.dev());
+    launch.only_mode = plan.boxes.empty() ? -1 : plan.boxes[0].index_mode;
+    for (const avr::BoxDev& dev : plan.boxes) {
+      if (dev.index_mode != launch.only_mode) launch.only_mode = -1;
+    }
+  }
+  ctx->mark_staging();
+  if (phases & kClassify) {
+    const int status = avr::launch_classify(launch, ctx->stream);
+    if (status != AVR_OK) return status;
+  }
+  if (phases & kMarch) return avr::launch_march(launch, ctx->stream);
+  return AVR_OK;
 }
 
 }  // namespace
@@ -233,10 +268,11 @@ int avr_context_create(int device_id, avr_context** out_ctx) {
     auto* ctx = new avr_context();
     ctx->device = device_id;
     try {
-      avr::hip_check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
-                     "hipStreamCreate");
       avr::hip_check(hipEventCreateWithFlags(&ctx->staged, hipEventDisableTiming),
                      "hipEventCreate");
+      // The context's own stream is created only if the caller never supplies one
+      // (avr_context_set_stream): HIP maps streams round-robin onto a few hardware queues, and
+      // an unused stream would push a later one onto an already used queue.
     } catch (...) {
       delete ctx;
       throw;
@@ -260,7 +296,6 @@ void avr_context_destroy(avr_context* ctx) {
   ctx->supertiles.release();
   ctx->run_rects.release();
   ctx->run_blocks.release();
-  if (ctx->classified != nullptr) (void)hipFree(ctx->classified);
   if (ctx->staged != nullptr) (void)hipEventDestroy(ctx->staged);
   if (ctx->own_stream != nullptr) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -268,8 +303,10 @@ void avr_context_destroy(avr_context* ctx) {
 
 int avr_context_set_stream(avr_context* ctx, void* hip_stream) {
   return guarded([&]() -> int {
-    bind_device(ctx);
+    require(ctx != nullptr, "null context");
+    avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->wait_staging();
+    // NULL: back to the context's own stream (created on first use)
     ctx->stream = (hip_stream != nullptr) ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return AVR_OK;
   });
@@ -368,8 +405,8 @@ int avr_paint_box(avr_context* ctx, const avr_box* box, const avr_scalar_transfo
     std::vector<avr::RunBlockDev> blocks;
     require(params->width > 0 && params->height > 0, "image width and height must be positive");
     avr::dense_run_tables(params->width, params->height, 1, 1, &rects, &blocks);
-    return render(ctx, box, 1, *transform, *params, *camera, order, 1, run_end, 1, 1, rects, blocks,
-                  out_rgbad, samples_out);
+    return render(ctx, kClassify | kMarch, box, 1, *transform, *params, *camera, order, 1, run_end,
+                  1, 1, rects, blocks, &ctx->scratch_scene, 0, out_rgbad, samples_out, nullptr);
   });
 }
 
@@ -401,9 +438,10 @@ int avr_render_runs(avr_context* ctx, const avr_scene* scene, const avr_paint_pa
     std::vector<avr::RunRectDev> rects;
     std::vector<avr::RunBlockDev> blocks;
     avr::dense_run_tables(params->width, params->height, n_runs, n_pieces, &rects, &blocks);
-    return render(ctx, scene->boxes.data(), static_cast<int>(scene->boxes.size()),
-                  scene->transform, *params, *camera, box_order, n_order, run_end, n_runs, n_pieces,
-                  rects, blocks, out_layers, samples_out);
+    return render(ctx, kClassify | kMarch, scene->boxes.data(),
+                  static_cast<int>(scene->boxes.size()), scene->transform, *params, *camera,
+                  box_order, n_order, run_end, n_runs, n_pieces, rects, blocks,
+                  const_cast<avr_scene*>(scene), 0, out_layers, samples_out, nullptr);
   });
 }
 
@@ -494,20 +532,37 @@ int avr_frame_plan_recv_block(const avr_frame_plan* plan, int global_run, int64_
   });
 }
 
-int avr_render_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
-                    float* send_buffer, uint64_t* samples_out) {
+static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
+                      const avr_frame_plan* plan, int slot, float* send_buffer,
+                      uint64_t* samples_out) {
   return guarded([&]() -> int {
     bind_device(ctx);
     require(scene != nullptr && plan != nullptr, "null argument");
     require(static_cast<int>(scene->boxes.size()) == plan->info.n_local_boxes,
             "the scene does not hold this rank's boxes of the plan");
     if (plan->info.n_local_runs == 0) return AVR_OK;
-    return render(ctx, scene->boxes.data(), static_cast<int>(scene->boxes.size()),
+    return render(ctx, phases, scene->boxes.data(), static_cast<int>(scene->boxes.size()),
                   scene->transform, plan->params, plan->camera, plan->local_order.data(),
                   static_cast<int>(plan->local_order.size()), plan->local_run_end.data(),
                   plan->info.n_local_runs, plan->info.n_ranks, plan->local_rects, plan->send_blocks,
-                  send_buffer, samples_out);
+                  const_cast<avr_scene*>(scene), slot, send_buffer, samples_out,
+                  &const_cast<avr_frame_plan*>(plan)->prologue);
   });
+}
+
+int avr_render_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                    float* send_buffer, uint64_t* samples_out) {
+  return plan_phase(ctx, kClassify | kMarch, scene, plan, 0, send_buffer, samples_out);
+}
+
+int avr_classify_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                      int slot) {
+  return plan_phase(ctx, kClassify, scene, plan, slot, nullptr, nullptr);
+}
+
+int avr_march_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan, int slot,
+                   float* send_buffer, uint64_t* samples_out) {
+  return plan_phase(ctx, kMarch, scene, plan, slot, send_buffer, samples_out);
 }
 
 int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,

@@ -130,8 +130,10 @@ struct RenderLaunch {
   const uint32_t* supertile_order_dev;  // supertile_slots(width, height) entries
   int only_mode;                        // the IndexMode shared by every box, or -1
 };
-// classify pass (cells -> table indices) followed by the march, both on `stream`
-int launch_render_runs(const RenderLaunch& launch, void* stream);
+// classify pass (cells -> table indices) and march; the march reads what the classify pass of
+// the same frame wrote into `classified`
+int launch_classify(const RenderLaunch& launch, void* stream);
+int launch_march(const RenderLaunch& launch, void* stream);
 int launch_blend(int kind, const void* top, const void* bottom, void* out, int64_t n, void* stream);
 int launch_blend_regions(int kind, const void* top, int64_t tb, int64_t te, const void* bottom,
                          int64_t bb, int64_t be, void* out, void* stream);

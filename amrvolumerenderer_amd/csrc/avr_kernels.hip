@@ -937,27 +937,29 @@ int check_launch(const char* what) {
 
 }  // namespace
 
-int launch_render_runs(const RenderLaunch& L, void* stream_v) {
+int launch_classify(const RenderLaunch& L, void* stream_v) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (L.n_classify_tiles == 0) return AVR_OK;
+  const FrameConsts& fc = L.consts;
+  // the standard API path (normalise on, scalarRange {0,1}, no log, no soft clip)
+  const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
+                      fc.inverse_range == 1.0f;
+  if (simple) {
+    hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
+  } else {
+    hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
+  }
+  return check_launch("classify_kernel");
+}
+
+int launch_march(const RenderLaunch& L, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const int tiles_x = (L.consts.width + kTile - 1) / kTile;
   const int tiles_y = (L.consts.height + kTile - 1) / kTile;
   const unsigned blocks = supertile_slots(L.consts.width, L.consts.height) * kSuperTileTiles;
   const size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
-  const FrameConsts& fc = L.consts;
-  // the standard API path (normalise on, scalarRange {0,1}, no log, no soft clip)
-  const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
-                      fc.inverse_range == 1.0f;
-  if (L.n_classify_tiles > 0) {
-    if (simple) {
-      hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
-                         stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
-    } else {
-      hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
-                         stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
-    }
-    const int status = check_launch("classify_kernel");
-    if (status != AVR_OK) return status;
-  }
   const bool stats = L.samples_out != nullptr;
 #define AVR_LAUNCH(STATS, ONLY)                                                                 \
   hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \

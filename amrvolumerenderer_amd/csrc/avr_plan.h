@@ -27,6 +27,9 @@ struct avr_frame_plan {
   std::vector<avr::RunRectDev> global_rects;
   std::vector<avr::RunBlockDev> recv_blocks;
   std::vector<int32_t> recv_block_rows;
+  // host prologue of this frame's local boxes, filled by the first device call that needs it
+  // (avr_classify_plan) and re-used by the next (avr_march_plan)
+  avr::FramePlan prologue;
 };
 
 namespace avr {

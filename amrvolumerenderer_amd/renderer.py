@@ -78,6 +78,8 @@ class FrameRenderer:
         # Second context = second HIP stream: frame i's exchange, fold and gather run there while
         # frame i+1 is classified and marched on ctx.stream (frames are independent).
         self.comm_ctx = runtime.Context(ctx.device_index)
+        # (Running the classify pass of frame i+1 on a third stream beside frame i's march was
+        # measured and gains nothing: the two kernels just share the CUs -- DESIGN.md section 3.)
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
         if n_local != len(self.local_boxes):

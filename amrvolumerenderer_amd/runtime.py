@@ -285,6 +285,26 @@ class Context:
 class Scene:
     """The rank's local boxes + scalar transform (avr_scene).  Keeps the cell tensors alive."""
 
+    def classify_plan(self, ctx: "Context", plan, slot: int) -> None:
+        """avr_classify_plan on `ctx`'s stream: cells -> table indices into classified volume
+        `slot`.  No stream ordering is added here; the caller orders it against the march."""
+        _capi.check(_capi.lib().avr_classify_plan(ctx._handle, self._handle, plan._handle,
+                                                  int(slot)))
+
+    def march_plan(self, ctx: "Context", plan, slot: int, out: torch.Tensor,
+                   samples: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_march_plan on `ctx`'s stream: ray march of classified volume `slot` into the
+        sparse send buffer."""
+        ctx._check_tensor(out, torch.float32, "out")
+        if out.numel() < plan.send_floats:
+            raise ValueError("send buffer is too small")
+        if samples is not None:
+            ctx._check_tensor(samples, torch.int64, "samples")
+        _capi.check(_capi.lib().avr_march_plan(
+            ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(out.data_ptr()),
+            C.c_void_p(samples.data_ptr()) if samples is not None else None))
+        return out
+
     def render_plan(self, plan, out: Optional[torch.Tensor] = None,
                     samples: Optional[torch.Tensor] = None) -> torch.Tensor:
         """avr_render_plan: classify + march of this rank's runs into the sparse send buffer."""

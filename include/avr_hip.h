@@ -243,6 +243,15 @@ int avr_frame_plan_recv_block(const avr_frame_plan *plan, int global_run, int64_
 int avr_render_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
                     float *send_buffer, uint64_t *samples_out);
 
+/* The two halves of avr_render_plan as separate calls, for pipelining frames: the classify pass
+ * of frame i+1 (any context / stream) may run while frame i is still marched.  `slot` (0 or 1)
+ * selects one of the scene's two classified volumes; the caller orders march(slot) after
+ * classify(slot) of the same frame and classify(slot) after the previous march(slot). */
+int avr_classify_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                      int slot);
+int avr_march_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan, int slot,
+                   float *send_buffer, uint64_t *samples_out);
+
 /* Receiver side of composeLayered (DirectSendBase.cpp:400-446) for this rank's piece: folds
  * the runs in global order from the received buffer (recv_floats floats; with one rank the send
  * buffer itself) into out_piece[(piece_end - piece_begin) * 5]; pixels no run covers become the

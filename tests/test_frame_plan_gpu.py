@@ -120,3 +120,31 @@ def test_pipelined_frames_reuse_buffers_safely(O, ctx):
         renderer.synchronize()
         assert np.array_equal(img.view(np.uint32), one_img.cpu().numpy().view(np.uint32))
         assert np.array_equal(rgb, one_rgb.cpu().numpy())
+
+
+def test_two_phase_plan_calls_equal_the_fused_call(ctx):
+    """avr_classify_plan + avr_march_plan (either classified slot, classify on another
+    context's stream) produce the same send buffer as avr_render_plan."""
+    from amrvolumerenderer_amd import runtime as rt
+    spec = scenes.make_amr_scene(32, 2, 8, "noise")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    scene = ctx.create_scene(local, spec.transform)
+    ref = rt.reference_sample_distance(meta, spec.bounds.min_corner, spec.bounds.max_corner)
+    params = make_params(80, 56, spec.scalar_range, 0.7, ref, spec.bounds)
+    plan = FramePlan(meta, params, scenes.default_camera(), 0, 1)
+    want = scene.render_plan(plan).clone()
+    ctx.synchronize()
+    other = rt.Context(0)
+    for slot in (0, 1, 0):
+        plan2 = FramePlan(meta, params, scenes.default_camera(), 0, 1)
+        scene.classify_plan(other, plan2, slot)
+        done = torch.cuda.Event()
+        done.record(other.stream)
+        ctx.stream.wait_event(done)
+        out = torch.zeros_like(want)
+        scene.march_plan(ctx, plan2, slot, out)
+        ctx.synchronize()
+        assert torch.equal(out.view(torch.int32), want.view(torch.int32))
