@@ -320,29 +320,51 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
       const float4 s2 = table[idx2];
       const float4 s3 = table[idx3];
       const float4 s4 = table[idx4];
-      AVR_ACCUMULATE(s1);
-      unsigned taken = 1u;
-      float next = d2;
+      // Fast path: accumulate all four unconditionally into copies; if no lane of the wave
+      // saturated (accumA >= 1) before its fourth sample -- the normal case -- commit them.
+      unsigned taken = 4u;
+      float next = d4 + step;
+      {
+        const float w1 = s1.w * (1.0f - acc_a);
+        const float a1 = acc_a + w1;
+        const float w2 = s2.w * (1.0f - a1);
+        const float a2 = a1 + w2;
+        const float w3 = s3.w * (1.0f - a2);
+        const float a3 = a2 + w3;
+        const bool stops_early = (a1 >= 1.0f) || (a2 >= 1.0f) || (a3 >= 1.0f);
+        if (__builtin_amdgcn_ballot_w64(stops_early) == 0) {
+          const float w4 = s4.w * (1.0f - a3);
+          acc_r = (((acc_r + s1.x * w1) + s2.x * w2) + s3.x * w3) + s4.x * w4;
+          acc_g = (((acc_g + s1.y * w1) + s2.y * w2) + s3.y * w3) + s4.y * w4;
+          acc_b = (((acc_b + s1.z * w1) + s2.z * w2) + s3.z * w3) + s4.z * w4;
+          acc_a = a3 + w4;
+        } else {
+          // some lane's ray terminates inside this group: per-sample selects
+          AVR_ACCUMULATE(s1);
+          taken = 1u;
+          next = d2;
 #define AVR_ACCUMULATE_IF_RUNNING(sample, following)          \
-      {                                                         \
-        const bool running_ = acc_a < 1.0f;                     \
-        const float alpha_ = (sample).w * (1.0f - acc_a);       \
-        const float r_ = acc_r + (sample).x * alpha_;           \
-        const float g_ = acc_g + (sample).y * alpha_;           \
-        const float b_ = acc_b + (sample).z * alpha_;           \
-        const float a_ = acc_a + alpha_;                        \
-        acc_r = running_ ? r_ : acc_r;                          \
-        acc_g = running_ ? g_ : acc_g;                          \
-        acc_b = running_ ? b_ : acc_b;                          \
-        acc_a = running_ ? a_ : acc_a;                          \
-        next = running_ ? (following) : next;                   \
-        taken += running_ ? 1u : 0u;                            \
-      }
-      // once accumA reaches 1 it stays >= 1 (alpha >= 0), so the later samples are rejected too
-      AVR_ACCUMULATE_IF_RUNNING(s2, d3)
-      AVR_ACCUMULATE_IF_RUNNING(s3, d4)
-      AVR_ACCUMULATE_IF_RUNNING(s4, d4 + step)
+          {                                                     \
+            const bool running_ = acc_a < 1.0f;                 \
+            const float alpha_ = (sample).w * (1.0f - acc_a);   \
+            const float r_ = acc_r + (sample).x * alpha_;       \
+            const float g_ = acc_g + (sample).y * alpha_;       \
+            const float b_ = acc_b + (sample).z * alpha_;       \
+            const float a_ = acc_a + alpha_;                    \
+            acc_r = running_ ? r_ : acc_r;                      \
+            acc_g = running_ ? g_ : acc_g;                      \
+            acc_b = running_ ? b_ : acc_b;                      \
+            acc_a = running_ ? a_ : acc_a;                      \
+            next = running_ ? (following) : next;               \
+            taken += running_ ? 1u : 0u;                        \
+          }
+          // once accumA reaches 1 it stays >= 1 (alpha >= 0), so later samples are rejected too
+          AVR_ACCUMULATE_IF_RUNNING(s2, d3)
+          AVR_ACCUMULATE_IF_RUNNING(s3, d4)
+          AVR_ACCUMULATE_IF_RUNNING(s4, d4 + step)
 #undef AVR_ACCUMULATE_IF_RUNNING
+        }
+      }
       distance = next;
       if (STATS) fetches += taken;
     }
