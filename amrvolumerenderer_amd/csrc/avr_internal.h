@@ -84,7 +84,7 @@ struct FramePlan {
   std::vector<uint32_t> supertile_order;      // screen super-tiles, most expensive first
 };
 
-// Screen tiling of the march kernel: workgroup = 16 x 16 pixels, super-tile = 8 x 8 workgroups
+// Screen tiling of the march kernel: workgroup = 16 x 16 pixels, super-tile = 2 x 2 workgroups
 // (Morton order inside), super-tiles dealt round-robin to the 8 XCDs in `supertile_order`.
 constexpr int kTile = 16;
 constexpr int kSuperTileSide = 2;

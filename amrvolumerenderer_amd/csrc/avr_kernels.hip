@@ -447,7 +447,7 @@ render_runs_kernel(
 
   // ---- XCD-aware tile assignment ------------------------------------------------------------
   // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Every XCD gets
-  // whole super-tiles (8 x 8 workgroups in Morton order), so the workgroups resident on one
+  // whole super-tiles (2 x 2 workgroups in Morton order), so the workgroups resident on one
   // XCD at a time cover a compact patch of the screen and re-use the same bricklets from that
   // XCD's L2; super-tiles are taken in the host's cost order, most expensive first, so the
   // long rays start early and the cheap tiles fill the tail.

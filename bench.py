@@ -97,6 +97,36 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
     }
 
 
+def profiled_traffic(args, world):
+    """HBM bytes per paint-stage launch from the committed rocprofv3 PMC summary of THIS command
+    (profiles/r1_final/pmc_summary.txt: separate --pmc passes, tools/pmc_passes.sh).  FETCH_SIZE
+    and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane)
+    coalesced stream, so the classify kernel's reads are doubled and the march's byte gathers
+    are not (MI355X_MICROARCH.md, HBM).  Only valid for the default single-GPU workload."""
+    default = (world == 1 and args.config == "config4" and args.field == "smooth"
+               and args.transparency == 0.97 and not args.width and not args.height
+               and args.antialiasing == 1 and args.orbit == 0)
+    path = os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.txt")
+    if not default or not os.path.exists(path):
+        return None, None
+    counters, kernel = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            kernel = line.strip()
+            continue
+        parts = line.split()
+        if len(parts) >= 3 and parts[-1].startswith("mean="):
+            counters[(kernel, parts[0])] = float(parts[-1][5:])
+    try:
+        kib = (2.0 * counters[("classify_kernel", "FETCH_SIZE")]
+               + counters[("classify_kernel", "WRITE_SIZE")]
+               + counters[("render_runs_kernel", "FETCH_SIZE")]
+               + counters[("render_runs_kernel", "WRITE_SIZE")])
+    except KeyError:
+        return None, None
+    return int(kib * 1024), "profiles/r1_final/pmc_summary.txt"
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -230,10 +260,12 @@ def main():
     n_pixels = params.width * params.height
     algo_bytes = 8.0 * my_samples + 4.0 * send_floats
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_source = profiled_traffic(args, world)
     roofline = {
         "bound": "hbm", "kernel": "classify_kernel + render_runs_kernel (one avr_render_plan)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_source": traffic_source,
         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes": int(algo_bytes),
         "samples_this_rank": my_samples,
         "compulsory_bytes": int(sum(b.values.numel() for b in local_boxes) * 8 + 4 * send_floats),
