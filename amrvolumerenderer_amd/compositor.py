@@ -144,9 +144,13 @@ class DirectSendCompositor:
                                plan.recv_splits, plan.send_splits, group=self.process_group)
         return recv
 
-    def compose(self, plan: FramePlan, send_buffer, want_rgb8: bool = False):
-        """Returns (piece [piece_len, 5], rgb8 [piece_len, 3] or None)."""
+    def compose(self, plan: FramePlan, send_buffer, want_rgb8: bool = False,
+                on_ops_stream: bool = False):
+        """Returns (piece [piece_len, 5], rgb8 [piece_len, 3] or None).  on_ops_stream: the
+        caller already made the ops' stream current (no extra stream ordering needed)."""
         recv = self.exchange(plan, send_buffer)
+        if on_ops_stream:
+            return self.ops.fold_plan(plan, recv, want_rgb8, sync_streams=False)
         return self.ops.fold_plan(plan, recv, want_rgb8)
 
     def gather(self, plan: FramePlan, piece, dst: int = 0):

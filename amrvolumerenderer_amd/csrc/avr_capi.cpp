@@ -35,33 +35,96 @@ void hip_check(hipError_t err, const char* what) {
   }
 }
 
-// A grow-only device buffer with a pinned host mirror for asynchronous uploads.
-class StagedBuffer {
+// Per-call descriptors (box table, transfer-function tables, run tables, ...) travel to the
+// device in ONE asynchronous copy per call: they are packed into a pinned host block and copied
+// to its device twin.  A ring of blocks lets the host run several calls ahead of the GPU
+// without waiting (a block is re-used only after the copy that read it has completed).
+class StagingRing {
  public:
-  ~StagedBuffer() { release(); }
+  static constexpr int kSlots = 4;
+  static constexpr size_t kAlign = 256;
+
+  ~StagingRing() { release(); }
+
   void release() {
-    if (dev_ != nullptr) (void)hipFree(dev_);
-    if (host_ != nullptr) (void)hipHostFree(host_);
-    dev_ = nullptr;
-    host_ = nullptr;
-    capacity_ = 0;
+    for (Slot& slot : slots_) {
+      if (slot.dev != nullptr) (void)hipFree(slot.dev);
+      if (slot.host != nullptr) (void)hipHostFree(slot.host);
+      if (slot.done != nullptr) (void)hipEventDestroy(slot.done);
+      slot = Slot{};
+    }
   }
-  void reserve(size_t bytes) {
-    if (bytes <= capacity_) return;
-    release();
-    size_t cap = 4096;
-    while (cap < bytes) cap *= 2;
-    hip_check(hipMalloc(&dev_, cap), "hipMalloc(staging)");
-    hip_check(hipHostMalloc(&host_, cap, hipHostMallocDefault), "hipHostMalloc(staging)");
-    capacity_ = cap;
+
+  // Starts a batch with room for `bytes` in `items` arrays.
+  void begin(size_t bytes, int items) {
+    current_ = &slots_[next_];
+    next_ = (next_ + 1) % kSlots;
+    if (current_->done == nullptr) {
+      hip_check(hipEventCreateWithFlags(&current_->done, hipEventDisableTiming), "hipEventCreate");
+    }
+    if (current_->pending) {
+      hip_check(hipEventSynchronize(current_->done), "hipEventSynchronize(staging)");
+      current_->pending = false;
+    }
+    const size_t need = bytes + static_cast<size_t>(items + 1) * kAlign;
+    if (need > current_->capacity) {
+      if (current_->dev != nullptr) (void)hipFree(current_->dev);
+      if (current_->host != nullptr) (void)hipHostFree(current_->host);
+      current_->dev = current_->host = nullptr;
+      current_->capacity = 0;
+      size_t cap = 1 << 16;
+      while (cap < need) cap *= 2;
+      hip_check(hipMalloc(&current_->dev, cap), "hipMalloc(staging)");
+      hip_check(hipHostMalloc(&current_->host, cap, hipHostMallocDefault), "hipHostMalloc(staging)");
+      current_->capacity = cap;
+    }
+    used_ = 0;
   }
-  void* host() const { return host_; }
-  void* dev() const { return dev_; }
+
+  // Adds one array to the batch; returns where it will be on the device.
+  template <typename T>
+  const T* add(const T* src, size_t count) {
+    used_ = (used_ + kAlign - 1) / kAlign * kAlign;
+    const size_t bytes = count * sizeof(T);
+    if (used_ + bytes > current_->capacity) throw std::runtime_error("staging batch overflow");
+    if (bytes != 0) std::memcpy(static_cast<char*>(current_->host) + used_, src, bytes);
+    const T* device = reinterpret_cast<const T*>(static_cast<char*>(current_->dev) + used_);
+    used_ += bytes;
+    return device;
+  }
+
+  // One copy for the whole batch, ordered on `stream` before the kernels that read it.
+  void commit(hipStream_t stream) {
+    if (used_ != 0) {
+      hip_check(hipMemcpyAsync(current_->dev, current_->host, used_, hipMemcpyHostToDevice, stream),
+                "hipMemcpyAsync(staging)");
+    }
+    hip_check(hipEventRecord(current_->done, stream), "hipEventRecord(staging)");
+    current_->pending = true;
+  }
+
+  // Blocks until every committed batch has been copied (before the context's stream changes).
+  void drain() {
+    for (Slot& slot : slots_) {
+      if (slot.pending) {
+        hip_check(hipEventSynchronize(slot.done), "hipEventSynchronize(staging)");
+        slot.pending = false;
+      }
+    }
+  }
 
  private:
-  void* dev_ = nullptr;
-  void* host_ = nullptr;
-  size_t capacity_ = 0;
+  struct Slot {
+    void* dev = nullptr;
+    void* host = nullptr;
+    size_t capacity = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+  };
+  Slot slots_[kSlots];
+  Slot* current_ = nullptr;
+  int next_ = 0;
+  size_t used_ = 0;
 };
 
 }  // namespace
@@ -99,28 +162,8 @@ struct avr_context {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t staged = nullptr;   // recorded after the last upload that read the pinned mirrors
-  bool staged_pending = false;
-  avr::StagedBuffer boxes, tables, order, run_end, slices, tile_begin, supertiles, run_rects, run_blocks;
+  avr::StagingRing staging;
   avr_scene scratch_scene;         // classified storage of avr_paint_box
-
-  void wait_staging() {
-    if (staged_pending) {
-      avr::hip_check(hipEventSynchronize(staged), "hipEventSynchronize(staging)");
-      staged_pending = false;
-    }
-  }
-  void mark_staging() {
-    avr::hip_check(hipEventRecord(staged, stream), "hipEventRecord(staging)");
-    staged_pending = true;
-  }
-  void upload(avr::StagedBuffer& buffer, const void* src, size_t bytes) {
-    if (bytes == 0) return;
-    buffer.reserve(bytes);
-    std::memcpy(buffer.host(), src, bytes);
-    avr::hip_check(hipMemcpyAsync(buffer.dev(), buffer.host(), bytes, hipMemcpyHostToDevice, stream),
-                   "hipMemcpyAsync(staging)");
-  }
 };
 
 
@@ -189,14 +232,8 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   launch.n_classify_tiles = plan.classify_tile_begin.back();
   launch.classified = scene->classified_slot(slot, plan.classified_bytes, ctx->stream);
 
-  ctx->wait_staging();
-  ctx->upload(ctx->boxes, plan.boxes.data(), plan.boxes.size() * sizeof(avr::BoxDev));
-  launch.boxes_dev = static_cast<const avr::BoxDev*>(ctx->boxes.dev());
-  if (phases & kClassify) {
-    ctx->upload(ctx->tile_begin, plan.classify_tile_begin.data(),
-                plan.classify_tile_begin.size() * sizeof(uint32_t));
-    launch.tile_begin_dev = static_cast<const uint32_t*>(ctx->tile_begin.dev());
-  }
+  size_t bytes = plan.boxes.size() * sizeof(avr::BoxDev);
+  if (phases & kClassify) bytes += plan.classify_tile_begin.size() * sizeof(uint32_t);
   if (phases & kMarch) {
     require(out_layers != nullptr, "null output image");
     require(n_runs == 0 || (run_end != nullptr), "null run_end");
@@ -213,31 +250,37 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     for (int i = 0; i < n_order; ++i) {
       require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
     }
-    ctx->upload(ctx->tables, plan.tables.data(), plan.tables.size() * sizeof(float));
-    ctx->upload(ctx->order, box_order, static_cast<size_t>(n_order) * sizeof(int32_t));
-    ctx->upload(ctx->run_end, run_end, static_cast<size_t>(n_runs) * sizeof(int32_t));
-    ctx->upload(ctx->supertiles, plan.supertile_order.data(),
-                plan.supertile_order.size() * sizeof(uint32_t));
-    ctx->upload(ctx->run_rects, run_rects.data(), run_rects.size() * sizeof(avr::RunRectDev));
-    ctx->upload(ctx->run_blocks, run_blocks.data(), run_blocks.size() * sizeof(avr::RunBlockDev));
-    launch.tables_dev = static_cast<const float*>(ctx->tables.dev());
+    bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
+             plan.supertile_order.size() * sizeof(uint32_t) +
+             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev);
+  }
+  avr::StagingRing& staging = ctx->staging;
+  staging.begin(bytes, 8);
+  launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
+  if (phases & kClassify) {
+    launch.tile_begin_dev =
+        staging.add(plan.classify_tile_begin.data(), plan.classify_tile_begin.size());
+  }
+  if (phases & kMarch) {
+    launch.tables_dev = staging.add(plan.tables.data(), plan.tables.size());
     launch.n_tables = plan.n_tables;
-    launch.order_dev = static_cast<const int32_t*>(ctx->order.dev());
-    launch.run_end_dev = static_cast<const int32_t*>(ctx->run_end.dev());
+    launch.order_dev = staging.add(box_order, static_cast<size_t>(n_order));
+    launch.run_end_dev = staging.add(run_end, static_cast<size_t>(n_runs));
     launch.n_order = n_order;
     launch.n_runs = n_runs;
     launch.n_pieces = n_pieces;
-    launch.run_rects_dev = static_cast<const avr::RunRectDev*>(ctx->run_rects.dev());
-    launch.run_blocks_dev = static_cast<const avr::RunBlockDev*>(ctx->run_blocks.dev());
+    launch.run_rects_dev = staging.add(run_rects.data(), run_rects.size());
+    launch.run_blocks_dev = staging.add(run_blocks.data(), run_blocks.size());
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
-    launch.supertile_order_dev = static_cast<const uint32_t*>(ctx->supertiles.dev());
+    launch.supertile_order_dev =
+        staging.add(plan.supertile_order.data(), plan.supertile_order.size());
     launch.only_mode = plan.boxes.empty() ? -1 : plan.boxes[0].index_mode;
     for (const avr::BoxDev& dev : plan.boxes) {
       if (dev.index_mode != launch.only_mode) launch.only_mode = -1;
     }
   }
-  ctx->mark_staging();
+  staging.commit(ctx->stream);
   if (phases & kClassify) {
     const int status = avr::launch_classify(launch, ctx->stream);
     if (status != AVR_OK) return status;
@@ -267,16 +310,6 @@ int avr_context_create(int device_id, avr_context** out_ctx) {
     avr::hip_check(hipSetDevice(device_id), "hipSetDevice");
     auto* ctx = new avr_context();
     ctx->device = device_id;
-    try {
-      avr::hip_check(hipEventCreateWithFlags(&ctx->staged, hipEventDisableTiming),
-                     "hipEventCreate");
-      // The context's own stream is created only if the caller never supplies one
-      // (avr_context_set_stream): HIP maps streams round-robin onto a few hardware queues, and
-      // an unused stream would push a later one onto an already used queue.
-    } catch (...) {
-      delete ctx;
-      throw;
-    }
     ctx->stream = ctx->own_stream;
     *out_ctx = ctx;
     return AVR_OK;
@@ -287,16 +320,7 @@ void avr_context_destroy(avr_context* ctx) {
   if (ctx == nullptr) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream != nullptr) (void)hipStreamSynchronize(ctx->own_stream);
-  ctx->boxes.release();
-  ctx->tables.release();
-  ctx->order.release();
-  ctx->run_end.release();
-  ctx->slices.release();
-  ctx->tile_begin.release();
-  ctx->supertiles.release();
-  ctx->run_rects.release();
-  ctx->run_blocks.release();
-  if (ctx->staged != nullptr) (void)hipEventDestroy(ctx->staged);
+  ctx->staging.release();
   if (ctx->own_stream != nullptr) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -305,7 +329,7 @@ int avr_context_set_stream(avr_context* ctx, void* hip_stream) {
   return guarded([&]() -> int {
     require(ctx != nullptr, "null context");
     avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
-    ctx->wait_staging();
+    ctx->staging.drain();
     // NULL: back to the context's own stream (created on first use)
     ctx->stream = (hip_stream != nullptr) ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
     return AVR_OK;
@@ -572,19 +596,17 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
     require(plan != nullptr && out_piece != nullptr, "null argument");
     require(plan->info.recv_floats == 0 || recv_buffer != nullptr, "null receive buffer");
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
-    ctx->wait_staging();
-    ctx->upload(ctx->run_rects, plan->global_rects.data(),
-                plan->global_rects.size() * sizeof(avr::RunRectDev));
-    ctx->upload(ctx->run_blocks, plan->recv_blocks.data(),
-                plan->recv_blocks.size() * sizeof(avr::RunBlockDev));
-    ctx->mark_staging();
     avr::FoldLaunch launch;
+    ctx->staging.begin(plan->global_rects.size() * sizeof(avr::RunRectDev) +
+                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev),
+                       2);
+    launch.run_rects_dev = ctx->staging.add(plan->global_rects.data(), plan->global_rects.size());
+    launch.run_blocks_dev = ctx->staging.add(plan->recv_blocks.data(), plan->recv_blocks.size());
+    ctx->staging.commit(ctx->stream);
     launch.width = plan->params.width;
     launch.piece_begin = plan->info.piece_begin;
     launch.piece_end = plan->info.piece_end;
     launch.n_runs = plan->info.n_runs_total;
-    launch.run_rects_dev = static_cast<const avr::RunRectDev*>(ctx->run_rects.dev());
-    launch.run_blocks_dev = static_cast<const avr::RunBlockDev*>(ctx->run_blocks.dev());
     launch.recv = recv_buffer;
     launch.out_piece = out_piece;
     launch.out_rgb8 = out_rgb8;
@@ -662,11 +684,10 @@ int avr_fold_runs_depthsort(avr_context* ctx, const float* const* slices_host, i
     if (n_pixels == 0) return AVR_OK;
     require(out != nullptr && (n_slices == 0 || slices_host != nullptr), "null argument");
     for (int s = 0; s < n_slices; ++s) require(slices_host[s] != nullptr, "null slice");
-    ctx->wait_staging();
-    ctx->upload(ctx->slices, slices_host, static_cast<size_t>(n_slices) * sizeof(float*));
-    ctx->mark_staging();
-    return avr::launch_fold_runs(static_cast<const float* const*>(ctx->slices.dev()), n_slices, out,
-                                 n_pixels, ctx->stream);
+    ctx->staging.begin(static_cast<size_t>(n_slices) * sizeof(float*), 1);
+    const float* const* slices_dev = ctx->staging.add(slices_host, static_cast<size_t>(n_slices));
+    ctx->staging.commit(ctx->stream);
+    return avr::launch_fold_runs(slices_dev, n_slices, out, n_pixels, ctx->stream);
   });
 }
 

@@ -208,8 +208,6 @@ __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, uint32_t row_
   return bricklet_offset(i, j, k, row_pitch, plane_pitch);
 }
 
-typedef const double __attribute__((address_space(1))) * GlobalCells;
-
 // Transfer-function table index of one cell value.
 //   SIMPLE = the standard API path: no log scaling, normalise on, no soft
 //   clip, scalarRange {0,1}.  There scalar = float(clamp_d((v - min) * inv, 0, 1)) and

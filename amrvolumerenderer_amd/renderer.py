@@ -115,7 +115,8 @@ class FrameRenderer:
         need = max(plan.send_floats, 1)
         if self._send[slot] is None or self._send[slot].numel() < need:
             self._send[slot] = self.ctx.empty(need)
-        return self.scene.render_plan(plan, out=self._send[slot], samples=samples)
+        return self.scene.render_plan(plan, out=self._send[slot], samples=samples,
+                                      sync_streams=False)
 
     def synchronize(self) -> None:
         self.ctx.synchronize()
@@ -148,7 +149,8 @@ class FrameRenderer:
             # 8-bit conversion is per pixel, so without antialiasing it is done on each rank's
             # piece before the gather (3 bytes per pixel on the wire instead of 20)
             early_rgb8 = (root == 1)
-            piece, piece_rgb8 = self.compositor.compose(plan, send, want_rgb8=early_rgb8)
+            piece, piece_rgb8 = self.compositor.compose(plan, send, want_rgb8=early_rgb8,
+                                                          on_ops_stream=True)
             released = torch.cuda.Event()
             released.record(comm.stream)
             self._send_free[slot] = released

@@ -241,21 +241,25 @@ class Context:
         self.publish()
         return out
 
-    def fold_plan(self, plan, recv: torch.Tensor, want_rgb8: bool = False):
+    def fold_plan(self, plan, recv: torch.Tensor, want_rgb8: bool = False,
+                  sync_streams: bool = True):
         """avr_fold_plan: receiver-side fold of this rank's piece.  Returns
-        (piece [piece_len, 5], rgb8 [piece_len, 3] or None)."""
+        (piece [piece_len, 5], rgb8 [piece_len, 3] or None).  sync_streams=False: the caller
+        already runs on this context's stream."""
         self._check_tensor(recv, torch.float32, "recv")
         if recv.numel() < plan.recv_floats:
             raise ValueError("receive buffer is too small")
         n = plan.piece_end - plan.piece_begin
         piece = self.empty(max(n, 0), 5)
         rgb8 = self.empty(max(n, 0), 3, dtype=torch.uint8) if want_rgb8 else None
-        self.join()
+        if sync_streams:
+            self.join()
         _capi.check(_capi.lib().avr_fold_plan(
             self._handle, plan._handle, C.c_void_p(recv.data_ptr()),
             C.c_void_p(piece.data_ptr()),
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None))
-        self.publish()
+        if sync_streams:
+            self.publish()
         return piece, rgb8
 
     def downsample(self, src: torch.Tensor, target_w: int, target_h: int, block: int
@@ -306,7 +310,8 @@ class Scene:
         return out
 
     def render_plan(self, plan, out: Optional[torch.Tensor] = None,
-                    samples: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    samples: Optional[torch.Tensor] = None,
+                    sync_streams: bool = True) -> torch.Tensor:
         """avr_render_plan: classify + march of this rank's runs into the sparse send buffer."""
         ctx = self.ctx
         if out is None:
@@ -316,11 +321,13 @@ class Scene:
             raise ValueError("send buffer is too small")
         if samples is not None:
             ctx._check_tensor(samples, torch.int64, "samples")
-        ctx.join()
+        if sync_streams:
+            ctx.join()
         _capi.check(_capi.lib().avr_render_plan(
             ctx._handle, self._handle, plan._handle, C.c_void_p(out.data_ptr()),
             C.c_void_p(samples.data_ptr()) if samples is not None else None))
-        ctx.publish()
+        if sync_streams:
+            ctx.publish()
         return out
 
     def __init__(self, ctx: Context, boxes: Sequence[AmrBox], transform: ScalarTransform):

@@ -31,7 +31,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="config4",
-                    choices=["config1", "config2", "config3", "config4", "config5", "tiny"])
+                    choices=["config1", "config2", "config3", "config4", "config5", "tiny", "hostbound"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--field", default="smooth", choices=["smooth", "noise", "radial"])
@@ -49,7 +49,8 @@ def parse_args():
 
 
 CONFIG_IMAGE = {"config1": (256, 256), "config2": (1024, 1024), "config3": (2048, 2048),
-                "config4": (2048, 2048), "config5": (4096, 4096), "tiny": (256, 256)}
+                "config4": (2048, 2048), "config5": (4096, 4096), "tiny": (256, 256),
+                "hostbound": (2048, 2048)}
 
 
 def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
@@ -165,6 +166,10 @@ def main():
 
     if args.config == "tiny":
         spec = scenes.make_amr_scene(64, 2, 16, args.field, "tiny_amr2_64")
+    elif args.config == "hostbound":
+        # 176 boxes' worth of host planning, but only the 8 finest boxes... keep it simple: a
+        # 3-level scene of 8^3 boxes whose GPU work is small next to the host cost of a frame
+        spec = scenes.make_amr_scene(32, 3, 8, args.field, "hostbound_amr3_32")
     else:
         spec = getattr(scenes, args.config)(args.field)
     scenes.assign_owners(spec, world, args.ownership)
