@@ -134,6 +134,12 @@ SIGNATURES = {
     "avr_classify_plan": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_scene_scalar_stats": (C.c_int, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "avr_scene_transform_from_stats": (C.c_int, [C.POINTER(C.c_double), _i64, C.c_int, C.c_int,
+                                                  C.POINTER(ScalarTransform),
+                                                  C.POINTER(C.c_double), _fp, _fp]),
+    "avr_scene_histogram": (C.c_int, [_vp, _vp, C.POINTER(ScalarTransform), C.c_float, C.c_float,
+                                       C.c_int, _vp]),
     "avr_blend_depthsort_f32x5": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "avr_blend_rgba_f32x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),
     "avr_blend_rgba_u8x4": (C.c_int, [_vp, _vp, _vp, _vp, _i64]),

@@ -51,6 +51,81 @@ class SceneGeometry:
     scalar_range: Tuple[float, float] = (0.0, 1.0)
 
 
+def build_scene_geometry(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
+                         bounds: VolumeBounds, log_scale_input: bool = False,
+                         normalize_to_data_range: bool = True, process_group=None,
+                         n_ranks: int = 1) -> "SceneGeometry":
+    """The scalar part of detail::BuildSceneGeometry (VolumeRenderer/SceneBuilder.cpp:315-443):
+    one streaming pass over the local cells (min, max, min positive, finite count), the
+    MIN / MAX / SUM reductions over ranks (:327-344, :368-385) and the scalar transform.
+    The geometric part (world corners, global rescale, padded bounds) needs amrex::Geometry and
+    is the caller's: boxes arrive with their corners."""
+    import torch
+    import torch.distributed as dist
+    from . import runtime
+    scene = ctx.create_scene(local_boxes, ScalarTransform())
+    lo, hi, lo_pos, finite = scene.scalar_stats()
+    if n_ranks > 1:
+        device = ctx.device if dist.get_backend(process_group) == "nccl" else "cpu"
+        mins = torch.tensor([lo, lo_pos], dtype=torch.float64, device=device)
+        maxs = torch.tensor([hi], dtype=torch.float64, device=device)
+        count = torch.tensor([finite], dtype=torch.int64, device=device)
+        dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=process_group)
+        dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=process_group)
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=process_group)
+        lo, lo_pos, hi, finite = mins[0].item(), mins[1].item(), maxs[0].item(), int(count.item())
+    transform, _, scalar_range = runtime.scene_transform_from_stats(
+        (lo, hi, lo_pos), finite, log_scale_input, normalize_to_data_range)
+    return SceneGeometry(list(all_boxes), list(local_boxes), transform, bounds, scalar_range)
+
+
+def compute_histogram(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
+                      log_scale: bool = False, bins: int = 256, process_group=None,
+                      n_ranks: int = 1) -> dict:
+    """api::ComputeHistogram / python compute_histogram (VolumeRendererApi.cpp:397-413,
+    python/amrVolumeRenderer/module.cpp:304-356) for boxes already in HBM: scene statistics with
+    normalisation to the data range, then the 64-bit bin counts of every cell
+    (ComputeSceneHistogram, SceneBuilder.cpp:445-577).  Returns the module's dict keys."""
+    import torch
+    import torch.distributed as dist
+    from . import runtime
+    if bins <= 0:
+        raise ValueError("binCount must be positive")
+    scene = ctx.create_scene(local_boxes, ScalarTransform())
+    lo, hi, lo_pos, finite = scene.scalar_stats()
+    stage = n_ranks > 1 and dist.get_backend(process_group) != "nccl"
+    if n_ranks > 1:
+        device = "cpu" if stage else ctx.device
+        mins = torch.tensor([lo, lo_pos], dtype=torch.float64, device=device)
+        maxs = torch.tensor([hi], dtype=torch.float64, device=device)
+        count = torch.tensor([finite], dtype=torch.int64, device=device)
+        dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=process_group)
+        dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=process_group)
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=process_group)
+        lo, lo_pos, hi, finite = mins[0].item(), mins[1].item(), maxs[0].item(), int(count.item())
+    transform, processed_range, scalar_range = runtime.scene_transform_from_stats(
+        (lo, hi, lo_pos), finite, log_scale, True)
+    original = (lo, hi if hi != lo else lo + 1.0)
+    counts = scene.histogram(transform, scalar_range[0], scalar_range[1], bins)
+    if n_ranks > 1:
+        if stage:
+            host = counts.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+            counts = host
+        else:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=process_group)
+    ctx.synchronize()
+    host_counts = counts.cpu().numpy().astype("uint64")
+    samples = int(host_counts.sum())
+    if samples == 0:
+        host_counts[:] = 0
+    return {"counts": host_counts, "normalized_range": scalar_range,
+            "processed_range": processed_range,
+            "original_range": (float(__import__("numpy").float32(original[0])),
+                               float(__import__("numpy").float32(original[1]))),
+            "samples": samples}
+
+
 def _finite(values) -> bool:
     return all(math.isfinite(float(v)) for v in values)
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -611,6 +612,87 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
     launch.out_piece = out_piece;
     launch.out_rgb8 = out_rgb8;
     return avr::launch_fold_plan(launch, ctx->stream);
+  });
+}
+
+int avr_scene_scalar_stats(avr_context* ctx, const avr_scene* scene, double stats_host[3],
+                           int64_t* finite_count_host) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(scene != nullptr && stats_host != nullptr && finite_count_host != nullptr,
+            "null argument");
+    avr::FramePlan plan;
+    avr::plan_cells(scene->boxes.data(), static_cast<int>(scene->boxes.size()), scene->transform,
+                    &plan);
+    const uint32_t n_tiles = plan.classify_tile_begin.back();
+    void* scratch = nullptr;
+    avr::hip_check(hipMalloc(&scratch, (static_cast<size_t>(avr::kScanWorkgroups) + 1) * 32),
+                   "hipMalloc");
+    struct { double lo, hi, lo_positive; long long finite; } result{};
+    int status = AVR_OK;
+    try {
+      ctx->staging.begin(plan.boxes.size() * sizeof(avr::BoxDev) +
+                             plan.classify_tile_begin.size() * sizeof(uint32_t), 2);
+      const avr::BoxDev* boxes_dev = ctx->staging.add(plan.boxes.data(), plan.boxes.size());
+      const uint32_t* tiles_dev =
+          ctx->staging.add(plan.classify_tile_begin.data(), plan.classify_tile_begin.size());
+      ctx->staging.commit(ctx->stream);
+      char* out_dev = static_cast<char*>(scratch) + static_cast<size_t>(avr::kScanWorkgroups) * 32;
+      status = avr::launch_scalar_stats(boxes_dev, tiles_dev, static_cast<int>(plan.boxes.size()),
+                                        n_tiles, scratch, out_dev, ctx->stream);
+      if (status == AVR_OK) {
+        avr::hip_check(hipMemcpyAsync(&result, out_dev, sizeof(result), hipMemcpyDeviceToHost,
+                                      ctx->stream), "hipMemcpyAsync");
+        avr::hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+      }
+    } catch (...) {
+      (void)hipFree(scratch);
+      throw;
+    }
+    (void)hipFree(scratch);
+    stats_host[0] = result.lo;
+    stats_host[1] = result.hi;
+    stats_host[2] = result.lo_positive;
+    *finite_count_host = result.finite;
+    return status;
+  });
+}
+
+int avr_scene_transform_from_stats(const double stats[3], int64_t finite_count, int log_scale,
+                                   int normalize_to_data_range, avr_scalar_transform* transform,
+                                   double processed[2], float processed_range[2],
+                                   float scalar_range[2]) {
+  return guarded([&]() -> int {
+    require(stats != nullptr && transform != nullptr && processed != nullptr &&
+                processed_range != nullptr && scalar_range != nullptr, "null argument");
+    avr::scene_transform_from_stats(stats, finite_count, log_scale != 0,
+                                    normalize_to_data_range != 0, transform, processed,
+                                    processed_range, scalar_range);
+    return AVR_OK;
+  });
+}
+
+int avr_scene_histogram(avr_context* ctx, const avr_scene* scene,
+                        const avr_scalar_transform* transform, float range_min, float range_max,
+                        int bin_count, uint64_t* counts_dev) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(scene != nullptr && transform != nullptr && counts_dev != nullptr, "null argument");
+    require(bin_count > 0, "binCount must be positive");  // SceneBuilder.cpp:448-450
+    const float width = range_max - range_min;
+    if (!(width > 0.0f) || !std::isfinite(width)) return AVR_OK;  // (:470-472): empty histogram
+    avr::FramePlan plan;
+    avr::plan_cells(scene->boxes.data(), static_cast<int>(scene->boxes.size()), *transform, &plan);
+    ctx->staging.begin(plan.boxes.size() * sizeof(avr::BoxDev) +
+                           plan.classify_tile_begin.size() * sizeof(uint32_t), 2);
+    const avr::BoxDev* boxes_dev = ctx->staging.add(plan.boxes.data(), plan.boxes.size());
+    const uint32_t* tiles_dev =
+        ctx->staging.add(plan.classify_tile_begin.data(), plan.classify_tile_begin.size());
+    ctx->staging.commit(ctx->stream);
+    return avr::launch_histogram(plan.consts, boxes_dev, tiles_dev,
+                                 static_cast<int>(plan.boxes.size()),
+                                 plan.classify_tile_begin.back(), range_min, range_max, bin_count,
+                                 counts_dev, ctx->stream);
   });
 }
 

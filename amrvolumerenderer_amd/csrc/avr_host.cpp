@@ -567,6 +567,76 @@ void order_supertiles(const FramePlan& plan, std::vector<uint32_t>* order) {
 
 }  // namespace
 
+void plan_cells(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
+                FramePlan* plan) {
+  // the statistics kernels only need the cell addressing part of the frame plan; a fixed
+  // dummy view keeps plan_frame's validation of strides and sizes
+  avr_paint_params params{};
+  params.width = 1;
+  params.height = 1;
+  params.scalar_range[0] = 0.0f;
+  params.scalar_range[1] = 1.0f;
+  for (int c = 0; c < 3; ++c) {
+    params.bounds_min[c] = 0.0;
+    params.bounds_max[c] = 1.0;
+  }
+  avr_camera camera{};
+  camera.eye[2] = 1.0;
+  camera.up[1] = 1.0;
+  camera.fov_y_degrees = 45.0f;
+  camera.near_plane = 0.1f;
+  camera.far_plane = 10.0f;
+  plan_frame(boxes, n_boxes, transform, params, camera, plan);
+}
+
+void scene_transform_from_stats(const double stats[3], int64_t finite_count, bool log_scale,
+                                bool normalize_to_data_range, avr_scalar_transform* transform,
+                                double processed[2], float processed_range[2],
+                                float scalar_range[2]) {
+  const double inf = std::numeric_limits<double>::infinity();
+  const double original_min = (finite_count > 0) ? stats[0] : inf;
+  const double original_max = (finite_count > 0) ? stats[1] : -inf;
+  double processed_min = original_min, processed_max = original_max;
+  std::memset(transform, 0, sizeof(*transform));
+  transform->log_scale_input = log_scale ? 1 : 0;
+  if (log_scale) {
+    const double positive_min = (stats[2] > 0.0 && std::isfinite(stats[2])) ? stats[2] : inf;
+    if (!(positive_min < inf) || !(positive_min > 0.0)) {
+      throw std::runtime_error("Log scaling requested but no positive scalar values were found.");
+    }
+    transform->positive_floor = positive_min;
+    processed_min = std::log(positive_min);
+    processed_max = std::log(std::max(original_max, positive_min));
+  }
+  if (!std::isfinite(processed_min) || !std::isfinite(processed_max)) {
+    throw std::runtime_error("Scalar data does not have a finite range.");
+  }
+  if (processed_min == processed_max) processed_max = processed_min + 1.0;
+  auto to_range = [](double lo, double hi, float out[2]) {  // makeScalarRange (:106-112)
+    if (lo == hi) hi = lo + 1.0;
+    out[0] = static_cast<float>(lo);
+    out[1] = static_cast<float>(hi);
+  };
+  to_range(processed_min, processed_max, processed_range);
+  processed[0] = processed_min;
+  processed[1] = processed_max;
+  transform->normalization_min = processed_min;
+  transform->inverse_normalization_span = 1.0 / (processed_max - processed_min);
+  scalar_range[0] = processed_range[0];
+  scalar_range[1] = processed_range[1];
+  if (normalize_to_data_range) {  // SetSceneNormalizationRange (:427-443)
+    const double span = processed_max - processed_min;
+    if (!(span > 0.0) || !std::isfinite(span)) {
+      throw std::runtime_error("Failed to establish a finite scalar range for color mapping.");
+    }
+    transform->normalize_to_unit_range = 1;
+    transform->normalization_min = processed_min;
+    transform->inverse_normalization_span = 1.0 / span;
+    scalar_range[0] = 0.0f;
+    scalar_range[1] = 1.0f;
+  }
+}
+
 int layer_order(const float* hints, const int32_t* owner, const int32_t* local_index, int n_layers,
                 int32_t* order_out, int32_t* run_end_out) {
   std::vector<int32_t> ids(static_cast<std::size_t>(std::max(n_layers, 0)));

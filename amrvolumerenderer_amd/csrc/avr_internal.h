@@ -155,6 +155,25 @@ int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, i
 int launch_downsample(const float* src, int tw, int th, int block, float* dst, void* stream);
 int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream);
 
+constexpr uint32_t kScanWorkgroups = 2048;  // grid of the grid-stride cell scans
+// scene statistics (avr_scene_stats.hip).  partial_dev: kScanWorkgroups x 32 bytes of scratch;
+// out_dev: 32 bytes {min, max, min positive (double), finite count (int64)}.
+int launch_scalar_stats(const BoxDev* boxes_dev, const uint32_t* tile_begin_dev, int n_boxes,
+                        uint32_t n_tiles, void* partial_dev, void* out_dev, void* stream);
+int launch_histogram(const FrameConsts& consts, const BoxDev* boxes_dev,
+                     const uint32_t* tile_begin_dev, int n_boxes, uint32_t n_tiles,
+                     float range_min, float range_max, int bin_count, uint64_t* counts_dev,
+                     void* stream);
+// BoxDev records + classify tiling of a box list without any camera (scene statistics).
+void plan_cells(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
+                FramePlan* plan);
+// The scalar-transform part of BuildSceneGeometry (SceneBuilder.cpp:315-443); throws
+// std::runtime_error like the reference.
+void scene_transform_from_stats(const double stats[3], int64_t finite_count, bool log_scale,
+                                bool normalize_to_data_range, avr_scalar_transform* transform,
+                                double processed[2], float processed_range[2],
+                                float scalar_range[2]);
+
 void set_error(const std::string& message);
 
 }  // namespace avr

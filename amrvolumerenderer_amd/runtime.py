@@ -81,6 +81,29 @@ def layer_order(hints, owner, local_index) -> Tuple[np.ndarray, np.ndarray]:
     return order[:n].copy(), run_end[:n_runs.value].copy()
 
 
+def scene_transform_from_stats(stats: Sequence[float], finite_count: int, log_scale: bool = False,
+                               normalize_to_data_range: bool = True):
+    """The scalar-transform part of BuildSceneGeometry (SceneBuilder.cpp:315-443) from reduced
+    statistics (min, max, min positive).  Returns (ScalarTransform, processed_range,
+    scalar_range); raises RuntimeError where the reference throws std::runtime_error."""
+    st = (C.c_double * 3)(*[float(v) for v in stats])
+    ctr = _capi.ScalarTransform()
+    processed = (C.c_double * 2)()
+    pr, sr = (C.c_float * 2)(), (C.c_float * 2)()
+    _capi.check(_capi.lib().avr_scene_transform_from_stats(
+        st, int(finite_count), int(bool(log_scale)), int(bool(normalize_to_data_range)),
+        C.byref(ctr), processed, pr, sr))
+    span = processed[1] - processed[0]
+    transform = ScalarTransform(
+        log_scale_input=bool(ctr.log_scale_input),
+        normalize_to_unit_range=bool(ctr.normalize_to_unit_range),
+        positive_floor=ctr.positive_floor, processed_min=processed[0], processed_max=processed[1],
+        inverse_processed_span=1.0 / span, normalization_min=ctr.normalization_min,
+        normalization_max=processed[1],
+        inverse_normalization_span=ctr.inverse_normalization_span)
+    return transform, (pr[0], pr[1]), (sr[0], sr[1])
+
+
 def piece_range(image_size: int, piece_index: int, num_pieces: int) -> Tuple[int, int]:
     """getPieceRange (DirectSend/Base/DirectSendBase.cpp:59-74)."""
     b, e = C.c_int64(), C.c_int64()
@@ -288,6 +311,34 @@ class Context:
 
 class Scene:
     """The rank's local boxes + scalar transform (avr_scene).  Keeps the cell tensors alive."""
+
+    def scalar_stats(self) -> Tuple[float, float, float, int]:
+        """avr_scene_scalar_stats: (min, max, min positive, finite count) of this rank's cells
+        (reduceLocalScalarStats, SceneBuilder.cpp:53-97).  Synchronises."""
+        stats = (C.c_double * 3)()
+        count = C.c_int64()
+        self.ctx.join()
+        _capi.check(_capi.lib().avr_scene_scalar_stats(self.ctx._handle, self._handle, stats,
+                                                       C.byref(count)))
+        return stats[0], stats[1], stats[2], int(count.value)
+
+    def histogram(self, transform: ScalarTransform, range_min: float, range_max: float,
+                  bin_count: int, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_scene_histogram: adds this rank's cells to counts[bin_count] (int64 on device)."""
+        if bin_count <= 0:
+            raise ValueError("binCount must be positive")
+        if counts is None:
+            counts = torch.zeros(bin_count, dtype=torch.int64, device=self.ctx.device)
+        self.ctx._check_tensor(counts, torch.int64, "counts")
+        if counts.numel() != bin_count:
+            raise ValueError("counts has the wrong size")
+        ctr = transform.to_c()
+        self.ctx.join()
+        _capi.check(_capi.lib().avr_scene_histogram(
+            self.ctx._handle, self._handle, C.byref(ctr), float(range_min), float(range_max),
+            int(bin_count), C.c_void_p(counts.data_ptr())))
+        self.ctx.publish()
+        return counts
 
     def classify_plan(self, ctx: "Context", plan, slot: int) -> None:
         """avr_classify_plan on `ctx`'s stream: cells -> table indices into classified volume

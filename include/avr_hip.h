@@ -302,6 +302,31 @@ int avr_downsample_depthsort(avr_context *ctx, const float *src, int target_w, i
 int avr_quantize_rgb8(avr_context *ctx, const float *src, int w, int h, int stride,
                       uint8_t *dst);
 
+/* ---- scene statistics -------------------------------------------------- */
+
+/* reduceLocalScalarStats (VolumeRenderer/SceneBuilder.cpp:53-97) over the scene's boxes: one
+ * streaming pass.  stats_host[0..2] = min, max, min positive over the finite cells (+inf, -inf,
+ * +inf when there is none), *finite_count_host = their number.  Synchronises the stream. */
+int avr_scene_scalar_stats(avr_context *ctx, const avr_scene *scene, double stats_host[3],
+                           int64_t *finite_count_host);
+
+/* The scalar-transform part of BuildSceneGeometry (SceneBuilder.cpp:315-443) from statistics
+ * already reduced over all ranks (host only): positive floor / processed range for log
+ * scaling, normalisation to the data range (SetSceneNormalizationRange, :427-443).
+ * processed[2] = processed min/max in double, processed_range / scalar_range as the float
+ * pairs of SceneGeometry.  AVR_ERR_RUNTIME where the reference throws std::runtime_error. */
+int avr_scene_transform_from_stats(const double stats[3], int64_t finite_count, int log_scale,
+                                   int normalize_to_data_range, avr_scalar_transform *transform,
+                                   double processed[2], float processed_range[2],
+                                   float scalar_range[2]);
+
+/* The binning of ComputeSceneHistogram (SceneBuilder.cpp:445-577): every cell of the scene is
+ * transformed, clamped to [range_min, range_max] and counted; counts_dev[bin_count] (device,
+ * uint64) is ADDED to (the caller zeroes it and sums over ranks). */
+int avr_scene_histogram(avr_context *ctx, const avr_scene *scene,
+                        const avr_scalar_transform *transform, float range_min, float range_max,
+                        int bin_count, uint64_t *counts_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1072,6 +1072,117 @@ void orc_quantize_rgb8(const float *src, int w, int h, int stride, uint8_t *dst)
   }
 }
 
+/* ========================================================================================= */
+/* Scene statistics and histogram                                          */
+/* ========================================================================================= */
+
+int64_t orc_scalar_stats(const orc_box *boxes, int n_boxes, double stats[3]) {
+  double lo = INFINITY, hi = -INFINITY, lo_pos = INFINITY;
+  int64_t finite = 0;
+  for (int b = 0; b < n_boxes; ++b) {
+    const orc_box *box = &boxes[b];
+    for (int k = 0; k < box->dims[2]; ++k) {
+      for (int j = 0; j < box->dims[1]; ++j) {
+        const double *row = box->cells + (int64_t)j * box->jstride + (int64_t)k * box->kstride;
+        for (int i = 0; i < box->dims[0]; ++i) {
+          const double raw = row[i];
+          if (!isfinite(raw)) continue; /* contributes {inf, -inf, inf, 0} */
+          if (raw < lo) lo = raw;
+          if (raw > hi) hi = raw;
+          if (raw > 0.0 && raw < lo_pos) lo_pos = raw;
+          ++finite;
+        }
+      }
+    }
+  }
+  stats[0] = lo;
+  stats[1] = hi;
+  stats[2] = lo_pos;
+  return finite;
+}
+
+static void make_scalar_range(double lo, double hi, float out[2]) { /* SceneBuilder.cpp:106-112 */
+  if (lo == hi) hi = lo + 1.0;
+  out[0] = (float)lo;
+  out[1] = (float)hi;
+}
+
+int orc_scene_transform(const double stats[3], int64_t finite_count, int log_scale,
+                        int normalize_to_data_range, orc_transform *tr, double *processed_min,
+                        double *processed_max, float processed_range[2], float scalar_range[2]) {
+  const double original_min = (finite_count > 0) ? stats[0] : INFINITY;
+  const double original_max = (finite_count > 0) ? stats[1] : -INFINITY;
+  double pmin = original_min, pmax = original_max;
+  memset(tr, 0, sizeof(*tr));
+  tr->log_scale_input = log_scale ? 1 : 0;
+  tr->normalize_to_unit_range = 0;
+  tr->positive_floor = 0.0;
+  if (log_scale) {
+    const double positive_min = (stats[2] > 0.0 && isfinite(stats[2])) ? stats[2] : INFINITY;
+    if (!(positive_min < INFINITY) || !isfinite(positive_min) || !(positive_min > 0.0)) return 1;
+    tr->positive_floor = positive_min;
+    pmin = log(positive_min);
+    pmax = log((original_max < positive_min) ? positive_min : original_max); /* std::max */
+  }
+  if (!isfinite(pmin) || !isfinite(pmax)) return 2;
+  if (pmin == pmax) pmax = pmin + 1.0;
+  make_scalar_range(pmin, pmax, processed_range);
+  *processed_min = pmin;
+  *processed_max = pmax;
+  tr->normalization_min = pmin;
+  tr->inverse_normalization_span = 1.0 / (pmax - pmin);
+  scalar_range[0] = processed_range[0];
+  scalar_range[1] = processed_range[1];
+  if (normalize_to_data_range) { /* SetSceneNormalizationRange, SceneBuilder.cpp:427-443 */
+    const double span = pmax - pmin;
+    if (!(span > 0.0) || !isfinite(span)) return 2;
+    tr->normalize_to_unit_range = 1;
+    tr->normalization_min = pmin;
+    tr->inverse_normalization_span = 1.0 / span;
+    scalar_range[0] = 0.0f;
+    scalar_range[1] = 1.0f;
+  }
+  return 0;
+}
+
+void orc_histogram(const orc_box *boxes, int n_boxes, const orc_transform *transform,
+                   float range_min, float range_max, int bin_count, uint64_t *counts) {
+  for (int i = 0; i < bin_count; ++i) counts[i] = 0;
+  const float range_width = range_max - range_min;
+  if (!(range_width > 0.0f) || !isfinite(range_width)) return;
+  const float inverse_width = 1.0f / range_width;
+  for (int b = 0; b < n_boxes; ++b) {
+    const orc_box *box = &boxes[b];
+    if (box->dims[0] <= 0 || box->dims[1] <= 0 || box->dims[2] <= 0) continue;
+    for (int k = 0; k < box->dims[2]; ++k) {
+      for (int j = 0; j < box->dims[1]; ++j) {
+        const double *row = box->cells + (int64_t)j * box->jstride + (int64_t)k * box->kstride;
+        for (int i = 0; i < box->dims[0]; ++i) {
+          float value = orc_apply_scalar_transform(row[i], transform);
+          if (value < range_min) {
+            value = range_min;
+          } else if (value > range_max) {
+            value = range_max;
+          }
+          float normalized = (value - range_min) * inverse_width;
+          if (normalized < 0.0f) {
+            normalized = 0.0f;
+          } else if (normalized > 1.0f) {
+            normalized = 1.0f;
+          }
+          int index = (int)(normalized * (float)bin_count);
+          if (index >= bin_count) {
+            index = bin_count - 1;
+          } else if (index < 0) {
+            index = 0;
+          }
+          counts[index] += 1;
+        }
+      }
+    }
+  }
+}
+
 uint64_t orc_fnv1a64(const void *data, uint64_t n_bytes) {
   const unsigned char *p = (const unsigned char *)data;
   uint64_t h = 0xcbf29ce484222325ULL;

@@ -146,6 +146,26 @@ void orc_downsample(const float *src, int target_w, int target_h, int block, flo
  * written top-down (y = h-1 .. 0); src is w*h pixels with `stride` floats each. */
 void orc_quantize_rgb8(const float *src, int w, int h, int stride, uint8_t *dst);
 
+/* ---- scene scalar statistics and histogram ---------------------------------- */
+
+/* reduceLocalScalarStats (VolumeRenderer/SceneBuilder.cpp:53-97) over a list of boxes:
+ * stats[0] = min, stats[1] = max, stats[2] = min positive over the finite cells
+ * (+inf / -inf / +inf when there is none); returns the number of finite cells. */
+int64_t orc_scalar_stats(const orc_box *boxes, int n_boxes, double stats[3]);
+
+/* The scalar-transform part of BuildSceneGeometry (SceneBuilder.cpp:315-443) from the already
+ * reduced statistics.  normalize_to_data_range as SceneBuildOptions; processed_range and
+ * scalar_range receive the float pairs.  Returns 0, or 1 when log scaling finds no positive
+ * value, 2 when the range is not finite (the reference throws std::runtime_error). */
+int orc_scene_transform(const double stats[3], int64_t finite_count, int log_scale,
+                        int normalize_to_data_range, orc_transform *transform,
+                        double *processed_min, double *processed_max, float processed_range[2],
+                        float scalar_range[2]);
+
+/* ComputeSceneHistogram's per-cell binning (SceneBuilder.cpp:495-532). */
+void orc_histogram(const orc_box *boxes, int n_boxes, const orc_transform *transform,
+                   float range_min, float range_max, int bin_count, uint64_t *counts);
+
 /* 64-bit FNV-1a over a byte buffer (used to compare with hashes recorded in SURVEY.md). */
 uint64_t orc_fnv1a64(const void *data, uint64_t n_bytes);
 

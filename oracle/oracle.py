@@ -130,6 +130,15 @@ def lib():
         L.orc_downsample.restype = None
         L.orc_quantize_rgb8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_quantize_rgb8.restype = None
+        L.orc_scalar_stats.argtypes = [C.POINTER(Box), C.c_int, C.POINTER(C.c_double)]
+        L.orc_scalar_stats.restype = C.c_int64
+        L.orc_scene_transform.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_int,
+                                          C.POINTER(Transform), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), fp, fp]
+        L.orc_scene_transform.restype = C.c_int
+        L.orc_histogram.argtypes = [C.POINTER(Box), C.c_int, C.POINTER(Transform), C.c_float,
+                                    C.c_float, C.c_int, C.c_void_p]
+        L.orc_histogram.restype = None
         L.orc_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_fnv1a64.restype = C.c_uint64
         _lib = L
@@ -368,3 +377,31 @@ def quantize_rgb8(src: np.ndarray, w: int, h: int) -> np.ndarray:
 def fnv1a64(arr: np.ndarray) -> int:
     arr = np.ascontiguousarray(arr)
     return int(lib().orc_fnv1a64(arr.ctypes.data, arr.nbytes))
+
+
+def scalar_stats(boxes: Sequence[Box]):
+    """(min, max, min_positive, finite_count) over the boxes' cells."""
+    arr = (Box * max(len(boxes), 1))(*boxes)
+    stats = (C.c_double * 3)()
+    n = lib().orc_scalar_stats(arr, len(boxes), stats)
+    return stats[0], stats[1], stats[2], int(n)
+
+
+def scene_transform(stats, finite_count, log_scale=False, normalize_to_data_range=True):
+    """Returns (status, Transform, processed_min, processed_max, processed_range, scalar_range)."""
+    st = (C.c_double * 3)(*map(float, stats))
+    tr = Transform()
+    pmin, pmax = C.c_double(), C.c_double()
+    pr, sr = (C.c_float * 2)(), (C.c_float * 2)()
+    status = lib().orc_scene_transform(st, int(finite_count), int(log_scale),
+                                       int(normalize_to_data_range), C.byref(tr), C.byref(pmin),
+                                       C.byref(pmax), pr, sr)
+    return status, tr, pmin.value, pmax.value, (pr[0], pr[1]), (sr[0], sr[1])
+
+
+def histogram(boxes: Sequence[Box], transform: Transform, range_min, range_max, bin_count):
+    arr = (Box * max(len(boxes), 1))(*boxes)
+    counts = np.zeros(bin_count, dtype=np.uint64)
+    lib().orc_histogram(arr, len(boxes), C.byref(transform), float(range_min), float(range_max),
+                        int(bin_count), counts.ctypes.data)
+    return counts
