@@ -134,6 +134,12 @@ SIGNATURES = {
     "avr_classify_plan": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_tight_bounds": (C.c_int, [C.POINTER(Box), C.c_int, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
+    "avr_bbox_overlay": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(Camera), C.c_int, C.c_int, C.c_int, _i64, _i64, _vp,
+                                    _vp]),
     "avr_scene_scalar_stats": (C.c_int, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "avr_scene_transform_from_stats": (C.c_int, [C.POINTER(C.c_double), _i64, C.c_int, C.c_int,
                                                   C.POINTER(ScalarTransform),

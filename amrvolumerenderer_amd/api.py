@@ -176,6 +176,32 @@ def save_ppm(rgb8, filename: str) -> bool:
     return True
 
 
+def save_png(rgb8, filename: str) -> bool:
+    """SavePNG (Common/SavePNG.cpp:24-81): 8-bit RGB, non-interlaced, rows top-down -- the same
+    pixel bytes as the PPM.  The reference hands the rows to libpng; the compressed stream
+    depends on libpng's filter heuristics and zlib's settings, so parity is on the decoded
+    pixels, not the file bytes.  Rows are stored with filter type 0 (None)."""
+    import struct
+    import zlib
+    height, width = int(rgb8.shape[0]), int(rgb8.shape[1])
+    rows = rgb8.cpu().numpy() if hasattr(rgb8, "cpu") else rgb8
+    raw = b"".join(b"\x00" + rows[y].tobytes() for y in range(height))
+
+    def chunk(tag: bytes, payload: bytes) -> bytes:
+        return (struct.pack(">I", len(payload)) + tag + payload
+                + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF))
+
+    try:
+        with open(filename, "wb") as fh:
+            fh.write(b"\x89PNG\r\n\x1a\n")
+            fh.write(chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0)))
+            fh.write(chunk(b"IDAT", zlib.compress(raw, 6)))
+            fh.write(chunk(b"IEND", b""))
+    except OSError:
+        return False
+    return True
+
+
 def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 0,
                  n_ranks: int = 1, process_group=None) -> int:
     """renderScene with an explicit camera (VolumeRenderer.cpp:1062-1101 -> renderSingleTrial):
@@ -187,8 +213,6 @@ def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 
         raise ValueError("render_scene needs an explicit camera (automatic placement is part of "
                          "the frame driver that is out of scope, VolumeRenderer.cpp:974-1023)")
     extension = os.path.splitext(options.output_filename)[1].lower()
-    if extension == ".png":
-        raise RuntimeError("PNG output is not built (SURVEY.md 8(f-3)); use a .ppm file name")
     renderer = FrameRenderer(ctx, scene.all_boxes, scene.local_boxes, scene.scalar_transform,
                              scene.bounds, scene.scalar_range, rank, n_ranks, process_group,
                              color_map=options.color_map)
@@ -197,7 +221,9 @@ def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 
                                                options.visibility_graph), options.camera)
     renderer.synchronize()
     if rank == 0:
-        if not save_ppm(rgb8, options.output_filename):
+        # any other extension falls back to PPM (VolumeRenderer.cpp:1316-1327)
+        writer = save_png if extension == ".png" else save_ppm
+        if not writer(rgb8, options.output_filename):
             return 1
     return 0
 

@@ -615,6 +615,34 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
   });
 }
 
+int avr_tight_bounds(const avr_box* all_boxes, int n_boxes, const double fallback_min[3],
+                     const double fallback_max[3], double out_min[3], double out_max[3]) {
+  return guarded([&]() -> int {
+    require(n_boxes >= 0 && (n_boxes == 0 || all_boxes != nullptr), "invalid box list");
+    require(fallback_min != nullptr && fallback_max != nullptr && out_min != nullptr &&
+                out_max != nullptr, "null argument");
+    avr::tight_bounds(all_boxes, n_boxes, fallback_min, fallback_max, out_min, out_max);
+    return AVR_OK;
+  });
+}
+
+int avr_bbox_overlay(avr_context* ctx, const double bounds_min[3], const double bounds_max[3],
+                     const avr_camera* camera, int sqrt_antialiasing, int width, int height,
+                     int64_t pixel_begin, int64_t pixel_end, float* image, uint8_t* rgb8) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(bounds_min != nullptr && bounds_max != nullptr && camera != nullptr, "null argument");
+    if (width <= 0 || height <= 0) return AVR_OK;  // VolumeRenderer.cpp:145-147
+    require(pixel_begin >= 0 && pixel_begin <= pixel_end &&
+                pixel_end <= static_cast<int64_t>(width) * height, "invalid pixel range");
+    if (pixel_end == pixel_begin) return AVR_OK;
+    require(image != nullptr, "null image");
+    avr::OverlayPlan plan;
+    avr::plan_overlay(bounds_min, bounds_max, *camera, sqrt_antialiasing, width, height, &plan);
+    return avr::launch_overlay(plan, width, pixel_begin, pixel_end, image, rgb8, ctx->stream);
+  });
+}
+
 int avr_scene_scalar_stats(avr_context* ctx, const avr_scene* scene, double stats_host[3],
                            int64_t* finite_count_host) {
   return guarded([&]() -> int {

@@ -637,6 +637,94 @@ void scene_transform_from_stats(const double stats[3], int64_t finite_count, boo
   }
 }
 
+void tight_bounds(const avr_box* boxes, int n_boxes, const double fallback_min[3],
+                  const double fallback_max[3], double out_min[3], double out_max[3]) {
+  if (n_boxes <= 0) {
+    for (int c = 0; c < 3; ++c) {
+      out_min[c] = fallback_min[c];
+      out_max[c] = fallback_max[c];
+    }
+    return;
+  }
+  for (int c = 0; c < 3; ++c) {
+    double lo = std::numeric_limits<float>::max(), hi = -std::numeric_limits<float>::max();
+    for (int b = 0; b < n_boxes; ++b) {
+      lo = std::min(lo, boxes[b].min_corner[c]);
+      hi = std::max(hi, boxes[b].max_corner[c]);
+    }
+    out_min[c] = static_cast<double>(static_cast<float>(lo));  // reduced as MPI_FLOAT
+    out_max[c] = static_cast<double>(static_cast<float>(hi));
+  }
+}
+
+void plan_overlay(const double bounds_min[3], const double bounds_max[3], const avr_camera& camera,
+                  int sqrt_antialiasing, int width, int height, OverlayPlan* plan) {
+  std::memset(plan, 0, sizeof(*plan));
+  plan->pixel_radius = 0.5f * static_cast<float>(std::max(sqrt_antialiasing, 1));
+  if (width <= 0 || height <= 0) return;
+  const float aspect = static_cast<float>(width) / static_cast<float>(std::max(height, 1));
+  const CameraBasis basis = camera_basis(camera);
+  const float tan_half_fov = std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f);
+  struct Corner {
+    float x = 0.0f, y = 0.0f;
+    bool valid = false;
+  };
+  std::array<Corner, 8> corners;
+  const float width_scale = (width > 1) ? static_cast<float>(width - 1) : 0.0f;
+  const float height_scale = (height > 1) ? static_cast<float>(height - 1) : 0.0f;
+  const Vec3d eye = from(camera.eye);
+  for (int index = 0; index < 8; ++index) {
+    const Vec3d world{(index & 1) ? bounds_max[0] : bounds_min[0],
+                      (index & 2) ? bounds_max[1] : bounds_min[1],
+                      (index & 4) ? bounds_max[2] : bounds_min[2]};
+    const Vec3d relative = sub(world, eye);
+    const float depth = static_cast<float>(dot(relative, basis.forward));
+    if (!(depth > 0.0f) || !std::isfinite(depth)) continue;
+    const float x_cam = static_cast<float>(dot(relative, basis.right));
+    const float y_cam = static_cast<float>(dot(relative, basis.up));
+    const float ndc_x = x_cam / (depth * tan_half_fov * aspect);
+    const float ndc_y = y_cam / (depth * tan_half_fov);
+    if (!std::isfinite(ndc_x) || !std::isfinite(ndc_y)) continue;
+    corners[static_cast<std::size_t>(index)].x = (ndc_x * 0.5f + 0.5f) * width_scale;
+    corners[static_cast<std::size_t>(index)].y = (ndc_y * 0.5f + 0.5f) * height_scale;
+    corners[static_cast<std::size_t>(index)].valid = true;
+  }
+  static constexpr int kEdges[12][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}, {4, 5}, {5, 7},
+                                        {7, 6}, {6, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  const float influence_radius = plan->pixel_radius + 0.5f;
+  for (const auto& pair : kEdges) {
+    const Corner& start = corners[static_cast<std::size_t>(pair[0])];
+    const Corner& end = corners[static_cast<std::size_t>(pair[1])];
+    if (!start.valid || !end.valid) continue;
+    OverlayEdge& edge = plan->edges[plan->n_edges];
+    edge.sx = start.x;
+    edge.sy = start.y;
+    edge.ex = end.x;
+    edge.ey = end.y;
+    edge.dx = end.x - start.x;
+    edge.dy = end.y - start.y;
+    edge.len_sq = edge.dx * edge.dx + edge.dy * edge.dy;
+    if (!(edge.len_sq > 0.0f)) {
+      const int px = static_cast<int>(std::lround(start.x));
+      const int py = static_cast<int>(std::lround(start.y));
+      if (px < 0 || px >= width || py < 0 || py >= height) continue;
+      edge.point = 1;
+      edge.x_begin = edge.x_end = px;
+      edge.y_begin = edge.y_end = py;
+    } else {
+      const float min_x = std::min(start.x, end.x) - influence_radius;
+      const float max_x = std::max(start.x, end.x) + influence_radius;
+      const float min_y = std::min(start.y, end.y) - influence_radius;
+      const float max_y = std::max(start.y, end.y) + influence_radius;
+      edge.x_begin = std::max(0, static_cast<int>(std::floor(min_x)));
+      edge.x_end = std::min(width - 1, static_cast<int>(std::ceil(max_x)));
+      edge.y_begin = std::max(0, static_cast<int>(std::floor(min_y)));
+      edge.y_end = std::min(height - 1, static_cast<int>(std::ceil(max_y)));
+    }
+    ++plan->n_edges;
+  }
+}
+
 int layer_order(const float* hints, const int32_t* owner, const int32_t* local_index, int n_layers,
                 int32_t* order_out, int32_t* run_end_out) {
   std::vector<int32_t> ids(static_cast<std::size_t>(std::max(n_layers, 0)));

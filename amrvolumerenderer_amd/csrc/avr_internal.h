@@ -174,6 +174,27 @@ void scene_transform_from_stats(const double stats[3], int64_t finite_count, boo
                                 double processed[2], float processed_range[2],
                                 float scalar_range[2]);
 
+// Wireframe overlay (avr_overlay.hip): the 12 edges of the bounds box projected by the host.
+struct OverlayEdge {
+  float sx, sy, ex, ey;   // projected end points (pixels)
+  float dx, dy, len_sq;   // end - start, squared length
+  int32_t x_begin, x_end, y_begin, y_end;  // pixel rectangle the reference loops over
+  int32_t point;          // degenerate edge: a single full-coverage sample
+};
+struct OverlayPlan {
+  OverlayEdge edges[12];
+  int32_t n_edges;
+  float pixel_radius;
+};
+// renderBoundingBoxLayer's host part (VolumeRenderer.cpp:139-232, 265-288).
+void plan_overlay(const double bounds_min[3], const double bounds_max[3], const avr_camera& camera,
+                  int sqrt_antialiasing, int width, int height, OverlayPlan* plan);
+// computeTightBounds (VolumeRenderer.cpp:791-848) over replicated box metadata.
+void tight_bounds(const avr_box* boxes, int n_boxes, const double fallback_min[3],
+                  const double fallback_max[3], double out_min[3], double out_max[3]);
+int launch_overlay(const OverlayPlan& plan, int width, int64_t pixel_begin, int64_t pixel_end,
+                   float* image, uint8_t* rgb8, void* stream);
+
 void set_error(const std::string& message);
 
 }  // namespace avr

@@ -12,7 +12,10 @@ allgather of layer counts / depth hints (:329)   host, from replicated box metad
 one direct-send round per run (:400-446)         one all-to-all per frame (RCCL over xGMI)
 receiver blend chain                             HIP fold kernel over runs in global order
 Gather to rank 0 (:1293)                         dist.gather of the pieces
-AA downsample, 8-bit conversion (:479, SavePPM)  HIP kernels on rank 0
+AA downsample (:479)                             HIP kernel on rank 0
+wireframe of the tight bounds (:139, :1311)      HIP kernel; without antialiasing each rank
+                                                   overlays its own piece before the gather
+8-bit conversion (SavePPM)                       fused into the fold / overlay kernel
 """
 from __future__ import annotations
 
@@ -37,6 +40,10 @@ class RenderParameters:
     box_transparency: float = 0.0
     antialiasing: int = 1
     use_visibility_graph: bool = True
+    # The reference always draws the wireframe of the tight bounds over the final image
+    # (VolumeRenderer.cpp:1311-1314).  SURVEY.md 8(d)'s frames/s metric times paint + composite +
+    # gather + downsample + quantise, so the bench switches it off.
+    draw_bounds: bool = True
 
 
 def validate_render_parameters(p: RenderParameters) -> int:
@@ -90,6 +97,9 @@ class FrameRenderer:
         # coarsest min spacing over all ranks == MPI_Allreduce(MAX) of VolumeRenderer.cpp:1166
         self.reference_sample_distance = runtime.reference_sample_distance(
             self.all_boxes, bounds.min_corner, bounds.max_corner)
+        # computeTightBounds (:791-848): the MPI min/max over all ranks' boxes == over all_boxes
+        self.tight_bounds = runtime.tight_bounds(self.all_boxes, bounds.min_corner,
+                                                 bounds.max_corner)
         self._send: List[Optional[torch.Tensor]] = [None, None]   # double-buffered send layout
         self._send_free: List[Optional[torch.cuda.Event]] = [None, None]
         self._frame = 0
@@ -149,8 +159,14 @@ class FrameRenderer:
             # 8-bit conversion is per pixel, so without antialiasing it is done on each rank's
             # piece before the gather (3 bytes per pixel on the wire instead of 20)
             early_rgb8 = (root == 1)
-            piece, piece_rgb8 = self.compositor.compose(plan, send, want_rgb8=early_rgb8,
-                                                          on_ops_stream=True)
+            overlay_piece = early_rgb8 and p.draw_bounds
+            piece, piece_rgb8 = self.compositor.compose(
+                plan, send, want_rgb8=early_rgb8 and not overlay_piece, on_ops_stream=True)
+            if overlay_piece:
+                # pixels are independent: each rank overlays its own piece (and converts it)
+                piece_rgb8 = comm.bbox_overlay(
+                    piece.reshape(-1), *self.tight_bounds, camera, 1, p.width, p.height,
+                    plan.piece_begin, plan.piece_end, want_rgb8=True)
             released = torch.cuda.Event()
             released.record(comm.stream)
             self._send_free[slot] = released
@@ -168,6 +184,9 @@ class FrameRenderer:
                 full = self.compositor.gather(plan, piece, dst=0)
                 if full is not None:
                     image = comm.downsample(full.reshape(-1), p.width, p.height, root)
+                    if p.draw_bounds:
+                        comm.bbox_overlay(image.reshape(-1), *self.tight_bounds, camera, 1,
+                                          p.width, p.height)
                     rgb8 = comm.quantize_rgb8(image.reshape(-1), p.width, p.height)
         return image, rgb8
 

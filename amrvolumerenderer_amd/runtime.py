@@ -64,6 +64,16 @@ def reference_sample_distance(boxes: Sequence[AmrBox], bounds_min, bounds_max) -
     return out.value
 
 
+def tight_bounds(boxes: Sequence[AmrBox], fallback_min, fallback_max):
+    """computeTightBounds (VolumeRenderer/VolumeRenderer.cpp:791-848) over replicated metadata."""
+    arr = (_capi.Box * max(len(boxes), 1))(*[b.to_c() for b in boxes])
+    fmin = (C.c_double * 3)(*map(float, fallback_min))
+    fmax = (C.c_double * 3)(*map(float, fallback_max))
+    omin, omax = (C.c_double * 3)(), (C.c_double * 3)()
+    _capi.check(_capi.lib().avr_tight_bounds(arr, len(boxes), fmin, fmax, omin, omax))
+    return tuple(omin), tuple(omax)
+
+
 def layer_order(hints, owner, local_index) -> Tuple[np.ndarray, np.ndarray]:
     """Global layer order and run ends (DirectSend/Base/DirectSendBase.cpp:363-410)."""
     hints = np.ascontiguousarray(hints, dtype=np.float32)
@@ -297,6 +307,29 @@ class Context:
             C.c_void_p(out.data_ptr())))
         self.publish()
         return out
+
+    def bbox_overlay(self, image: torch.Tensor, bounds_min, bounds_max,
+                     camera: CameraParameters, sqrt_antialiasing: int, width: int, height: int,
+                     pixel_begin: int = 0, pixel_end: Optional[int] = None,
+                     want_rgb8: bool = False) -> Optional[torch.Tensor]:
+        """avr_bbox_overlay: the wireframe of the bounds blended in place over the pixels
+        [pixel_begin, pixel_end) held by `image` (renderBoundingBoxLayer,
+        VolumeRenderer.cpp:139-335); optionally also returns those pixels as RGB8."""
+        self._check_tensor(image, torch.float32, "image")
+        pixel_end = width * height if pixel_end is None else pixel_end
+        if image.numel() != (pixel_end - pixel_begin) * 5:
+            raise ValueError("image does not hold the pixel range")
+        bmin = (C.c_double * 3)(*map(float, bounds_min))
+        bmax = (C.c_double * 3)(*map(float, bounds_max))
+        ccam = camera.to_c()
+        rgb8 = self.empty(pixel_end - pixel_begin, 3, dtype=torch.uint8) if want_rgb8 else None
+        self.join()
+        _capi.check(_capi.lib().avr_bbox_overlay(
+            self._handle, bmin, bmax, C.byref(ccam), int(sqrt_antialiasing), width, height,
+            pixel_begin, pixel_end, C.c_void_p(image.data_ptr()),
+            C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None))
+        self.publish()
+        return rgb8
 
     def quantize_rgb8(self, src: torch.Tensor, w: int, h: int) -> torch.Tensor:
         self._check_tensor(src, torch.float32, "src")

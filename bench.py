@@ -184,7 +184,8 @@ def main():
                              spec.scalar_range, rank, world, group,
                              stage_through_host=args.rehearse_on_one_gpu)
     rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
-                               antialiasing=args.antialiasing)
+                               antialiasing=args.antialiasing,
+                               draw_bounds=False)  # not part of the metric
     cameras = ([scenes.orbit_camera(v, args.orbit) for v in range(args.orbit)]
                if args.orbit > 0 else [scenes.default_camera()])
 

@@ -302,6 +302,23 @@ int avr_downsample_depthsort(avr_context *ctx, const float *src, int target_w, i
 int avr_quantize_rgb8(avr_context *ctx, const float *src, int w, int h, int stride,
                       uint8_t *dst);
 
+/* ---- wireframe overlay ------------------------------------------------- */
+
+/* computeTightBounds (VolumeRenderer/VolumeRenderer.cpp:791-848) over the (replicated) box
+ * metadata: component-wise min / max of the corners, rounded to float as the reference's
+ * MPI_FLOAT reduction does; the fallback bounds when there is no box.  Host only. */
+int avr_tight_bounds(const avr_box *all_boxes, int n_boxes, const double fallback_min[3],
+                     const double fallback_max[3], double out_min[3], double out_max[3]);
+
+/* renderBoundingBoxLayer (VolumeRenderer/VolumeRenderer.cpp:139-335): white anti-aliased
+ * wireframe of [bounds_min, bounds_max] blended, in the reference's edge order, over the pixels
+ * [pixel_begin, pixel_end) of a width x height depth-sort image (image = those pixels, 5 floats
+ * each, in place).  Pixels are independent, so a rank can overlay its own piece.  If rgb8 is
+ * non-NULL the overlaid pixels are also written as RGB8 (3 bytes per pixel, same order). */
+int avr_bbox_overlay(avr_context *ctx, const double bounds_min[3], const double bounds_max[3],
+                     const avr_camera *camera, int sqrt_antialiasing, int width, int height,
+                     int64_t pixel_begin, int64_t pixel_end, float *image, uint8_t *rgb8);
+
 /* ---- scene statistics -------------------------------------------------- */
 
 /* reduceLocalScalarStats (VolumeRenderer/SceneBuilder.cpp:53-97) over the scene's boxes: one

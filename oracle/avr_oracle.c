@@ -1183,6 +1183,158 @@ void orc_histogram(const orc_box *boxes, int n_boxes, const orc_transform *trans
   }
 }
 
+/* ========================================================================================= */
+/* Wireframe overlay                                                       */
+/* ========================================================================================= */
+
+void orc_tight_bounds(const orc_box *boxes, int n_boxes, const double fallback_min[3],
+                      const double fallback_max[3], double out_min[3], double out_max[3]) {
+  if (n_boxes <= 0) {
+    for (int c = 0; c < 3; ++c) {
+      out_min[c] = fallback_min[c];
+      out_max[c] = fallback_max[c];
+    }
+    return;
+  }
+  for (int c = 0; c < 3; ++c) {
+    double lo = 3.402823466e+38, hi = -3.402823466e+38; /* Vec3(numeric_limits<float>::max()) */
+    for (int b = 0; b < n_boxes; ++b) {
+      if (boxes[b].min_corner[c] < lo) lo = boxes[b].min_corner[c];
+      if (boxes[b].max_corner[c] > hi) hi = boxes[b].max_corner[c];
+    }
+    out_min[c] = (double)(float)lo; /* reduced as MPI_FLOAT */
+    out_max[c] = (double)(float)hi;
+  }
+}
+
+typedef struct {
+  double world[3];
+  float x, y, depth;
+  int valid;
+} screen_corner;
+
+void orc_bbox_overlay(const double bounds_min[3], const double bounds_max[3],
+                      const orc_camera *cam, int sqrt_antialiasing, float *image, int width,
+                      int height) {
+  if (width <= 0 || height <= 0) return;
+  const float aspect = (float)width / (float)((height > 1) ? height : 1);
+  double d[3] = {cam->look_at[0] - cam->eye[0], cam->look_at[1] - cam->eye[1],
+                 cam->look_at[2] - cam->eye[2]};
+  double forward[3], right[3], up[3];
+  safe_normalize(d, forward);
+  v3_cross(forward, cam->up, right);
+  const double rl = v3_len(right);
+  if (rl > 0.0 && isfinite(rl)) {
+    right[0] /= rl;
+    right[1] /= rl;
+    right[2] /= rl;
+  } else {
+    right[0] = 1.0;
+    right[1] = 0.0;
+    right[2] = 0.0;
+  }
+  v3_cross(right, forward, up);
+  const float tan_half_fov = tanf(cam->fov_y_degrees * 0.5f * kPi / 180.0f);
+
+  screen_corner corners[8];
+  const float width_scale = (width > 1) ? (float)(width - 1) : 0.0f;
+  const float height_scale = (height > 1) ? (float)(height - 1) : 0.0f;
+  for (int index = 0; index < 8; ++index) {
+    screen_corner p;
+    memset(&p, 0, sizeof(p));
+    p.depth = INFINITY;
+    p.world[0] = (index & 1) ? bounds_max[0] : bounds_min[0];
+    p.world[1] = (index & 2) ? bounds_max[1] : bounds_min[1];
+    p.world[2] = (index & 4) ? bounds_max[2] : bounds_min[2];
+    const double rel[3] = {p.world[0] - cam->eye[0], p.world[1] - cam->eye[1],
+                           p.world[2] - cam->eye[2]};
+    const float depth = (float)v3_dot(rel, forward);
+    if (!(depth > 0.0f) || !isfinite(depth)) {
+      corners[index] = p;
+      continue;
+    }
+    const float x_cam = (float)v3_dot(rel, right);
+    const float y_cam = (float)v3_dot(rel, up);
+    const float ndc_x = x_cam / (depth * tan_half_fov * aspect);
+    const float ndc_y = y_cam / (depth * tan_half_fov);
+    if (!isfinite(ndc_x) || !isfinite(ndc_y)) {
+      corners[index] = p;
+      continue;
+    }
+    p.x = (ndc_x * 0.5f + 0.5f) * width_scale;
+    p.y = (ndc_y * 0.5f + 0.5f) * height_scale;
+    p.depth = depth;
+    p.valid = 1;
+    corners[index] = p;
+  }
+
+  static const int edges[12][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}, {4, 5}, {5, 7},
+                                   {7, 6}, {6, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  const float overlay_depth = -3.402823466e+38f; /* numeric_limits<float>::lowest() */
+  const float pixel_radius = 0.5f * (float)((sqrt_antialiasing > 1) ? sqrt_antialiasing : 1);
+  const float influence_radius = pixel_radius + 0.5f;
+  const float coverage_scale = 0.6f;
+
+#define BLEND_SAMPLE(px_, py_, coverage_)                                   \
+  do {                                                                      \
+    const int bx_ = (px_), by_ = (py_);                                     \
+    if (bx_ < 0 || bx_ >= width || by_ < 0 || by_ >= height) break;         \
+    const float cc_ = clampf((coverage_), 0.0f, 1.0f);                      \
+    if (cc_ <= 0.0f) break;                                                 \
+    float *buf_ = image + ((size_t)by_ * width + bx_) * 5;                  \
+    const float sa_ = cc_;                                                  \
+    const float sr_ = 1.0f * sa_, sg_ = 1.0f * sa_, sb_ = 1.0f * sa_;       \
+    buf_[0] = sr_ + buf_[0] * (1.0f - sa_);                                 \
+    buf_[1] = sg_ + buf_[1] * (1.0f - sa_);                                 \
+    buf_[2] = sb_ + buf_[2] * (1.0f - sa_);                                 \
+    buf_[3] = sa_ + buf_[3] * (1.0f - sa_);                                 \
+    buf_[4] = overlay_depth;                                                \
+  } while (0)
+
+  for (int e = 0; e < 12; ++e) {
+    const screen_corner *start = &corners[edges[e][0]];
+    const screen_corner *end = &corners[edges[e][1]];
+    if (!start->valid || !end->valid) continue;
+    const float min_x = minf(start->x, end->x) - influence_radius;
+    const float max_x = maxf(start->x, end->x) + influence_radius;
+    const float min_y = minf(start->y, end->y) - influence_radius;
+    const float max_y = maxf(start->y, end->y) + influence_radius;
+    const int fx = (int)floorf(min_x), cx = (int)ceilf(max_x);
+    const int fy = (int)floorf(min_y), cy = (int)ceilf(max_y);
+    const int x_begin = (fx > 0) ? fx : 0;
+    const int x_end = (cx < width - 1) ? cx : width - 1;
+    const int y_begin = (fy > 0) ? fy : 0;
+    const int y_end = (cy < height - 1) ? cy : height - 1;
+    const float edge_dx = end->x - start->x;
+    const float edge_dy = end->y - start->y;
+    const float len_sq = edge_dx * edge_dx + edge_dy * edge_dy;
+    if (!(len_sq > 0.0f)) {
+      BLEND_SAMPLE((int)lroundf(start->x), (int)lroundf(start->y), 1.0f);
+      continue;
+    }
+    for (int py = y_begin; py <= y_end; ++py) {
+      const float sample_y = (float)py + 0.5f;
+      for (int px = x_begin; px <= x_end; ++px) {
+        const float sample_x = (float)px + 0.5f;
+        const float apx = sample_x - start->x;
+        const float apy = sample_y - start->y;
+        float t = (apx * edge_dx + apy * edge_dy) / len_sq;
+        t = clampf(t, 0.0f, 1.0f);
+        const float closest_x = start->x + (end->x - start->x) * t;
+        const float closest_y = start->y + (end->y - start->y) * t;
+        const float dist_x = sample_x - closest_x;
+        const float dist_y = sample_y - closest_y;
+        const float distance = sqrtf(dist_x * dist_x + dist_y * dist_y);
+        const float coverage =
+            clampf((pixel_radius + 0.5f - distance) * coverage_scale, 0.0f, 1.0f);
+        if (coverage <= 0.0f) continue;
+        BLEND_SAMPLE(px, py, coverage);
+      }
+    }
+  }
+#undef BLEND_SAMPLE
+}
+
 uint64_t orc_fnv1a64(const void *data, uint64_t n_bytes) {
   const unsigned char *p = (const unsigned char *)data;
   uint64_t h = 0xcbf29ce484222325ULL;

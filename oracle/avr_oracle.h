@@ -166,6 +166,20 @@ int orc_scene_transform(const double stats[3], int64_t finite_count, int log_sca
 void orc_histogram(const orc_box *boxes, int n_boxes, const orc_transform *transform,
                    float range_min, float range_max, int bin_count, uint64_t *counts);
 
+/* ---- wireframe overlay of the tight bounds ---------------------------------- */
+
+/* computeTightBounds (VolumeRenderer/VolumeRenderer.cpp:791-848): component-wise min / max of
+ * the box corners, reduced in float; `fallback` when there is no box. */
+void orc_tight_bounds(const orc_box *boxes, int n_boxes, const double fallback_min[3],
+                      const double fallback_max[3], double out_min[3], double out_max[3]);
+
+/* renderBoundingBoxLayer (VolumeRenderer/VolumeRenderer.cpp:139-335): white anti-aliased
+ * wireframe of the box [bounds_min, bounds_max] blended over the w x h depth-sort image in
+ * place (12 edges in the reference's order, depth := lowest float). */
+void orc_bbox_overlay(const double bounds_min[3], const double bounds_max[3],
+                      const orc_camera *camera, int sqrt_antialiasing, float *image, int w,
+                      int h);
+
 /* 64-bit FNV-1a over a byte buffer (used to compare with hashes recorded in SURVEY.md). */
 uint64_t orc_fnv1a64(const void *data, uint64_t n_bytes);
 

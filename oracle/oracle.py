@@ -139,6 +139,12 @@ def lib():
         L.orc_histogram.argtypes = [C.POINTER(Box), C.c_int, C.POINTER(Transform), C.c_float,
                                     C.c_float, C.c_int, C.c_void_p]
         L.orc_histogram.restype = None
+        dp = C.POINTER(C.c_double)
+        L.orc_tight_bounds.argtypes = [C.POINTER(Box), C.c_int, dp, dp, dp, dp]
+        L.orc_tight_bounds.restype = None
+        L.orc_bbox_overlay.argtypes = [dp, dp, C.POINTER(Camera), C.c_int, C.c_void_p, C.c_int,
+                                       C.c_int]
+        L.orc_bbox_overlay.restype = None
         L.orc_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_fnv1a64.restype = C.c_uint64
         _lib = L
@@ -405,3 +411,24 @@ def histogram(boxes: Sequence[Box], transform: Transform, range_min, range_max, 
     lib().orc_histogram(arr, len(boxes), C.byref(transform), float(range_min), float(range_max),
                         int(bin_count), counts.ctypes.data)
     return counts
+
+
+def tight_bounds(boxes: Sequence[Box], fallback_min, fallback_max):
+    arr = (Box * max(len(boxes), 1))(*boxes)
+    fmin = (C.c_double * 3)(*map(float, fallback_min))
+    fmax = (C.c_double * 3)(*map(float, fallback_max))
+    omin, omax = (C.c_double * 3)(), (C.c_double * 3)()
+    lib().orc_tight_bounds(arr, len(boxes), fmin, fmax, omin, omax)
+    return tuple(omin), tuple(omax)
+
+
+def bbox_overlay(image: np.ndarray, w: int, h: int, bounds_min, bounds_max, camera: Camera,
+                 sqrt_antialiasing: int = 1) -> np.ndarray:
+    """Returns a copy of the w x h depth-sort image with the wireframe blended over it."""
+    out = np.array(_f32(image).reshape(-1), copy=True)
+    assert out.size == w * h * 5
+    bmin = (C.c_double * 3)(*map(float, bounds_min))
+    bmax = (C.c_double * 3)(*map(float, bounds_max))
+    lib().orc_bbox_overlay(bmin, bmax, C.byref(camera), int(sqrt_antialiasing), out.ctypes.data,
+                           w, h)
+    return out.reshape(h, w, 5)

@@ -9,6 +9,56 @@ from amrvolumerenderer_amd.types import CameraParameters, ColorMapControlPoint
 from helpers import assert_bit_equal
 
 
+def decode_png_rgb8(data: bytes) -> np.ndarray:
+    """Minimal PNG reader for 8-bit RGB, non-interlaced files (all five filter types)."""
+    import struct
+    import zlib
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, width, height = 8, b"", 0, 0
+    while at < len(data):
+        (length,), tag = struct.unpack(">I", data[at:at + 4]), data[at + 4:at + 8]
+        payload = data[at + 8:at + 8 + length]
+        (crc,) = struct.unpack(">I", data[at + 8 + length:at + 12 + length])
+        assert crc == zlib.crc32(tag + payload) & 0xFFFFFFFF
+        if tag == b"IHDR":
+            width, height, depth, colour, comp, flt, lace = struct.unpack(">IIBBBBB", payload)
+            assert (depth, colour, comp, flt, lace) == (8, 2, 0, 0, 0)
+        elif tag == b"IDAT":
+            idat += payload
+        at += 12 + length
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(height, 1 + width * 3)
+    out = np.zeros((height, width * 3), np.int32)
+    for y in range(height):
+        ftype, line = raw[y, 0], raw[y, 1:].astype(np.int32)
+        prev = out[y - 1] if y else np.zeros(width * 3, np.int32)
+        if ftype == 0:
+            out[y] = line
+        elif ftype == 2:
+            out[y] = (line + prev) & 255
+        else:
+            for x in range(width * 3):
+                a = out[y, x - 3] if x >= 3 else 0
+                b, c = prev[x], (prev[x - 3] if x >= 3 else 0)
+                if ftype == 1:
+                    pred = a
+                elif ftype == 3:
+                    pred = (a + b) // 2
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                out[y, x] = (line[x] + pred) & 255
+    return out.astype(np.uint8).reshape(height, width, 3)
+
+
+def test_png_writer_round_trips(tmp_path):
+    rng = np.random.default_rng(5)
+    rgb8 = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    path = tmp_path / "x.png"
+    assert api.save_png(rgb8, str(path))
+    assert np.array_equal(decode_png_rgb8(path.read_bytes()), rgb8)
+    assert not api.save_png(rgb8, str(tmp_path / "missing-dir" / "x.png"))
+
+
 def test_option_validation_matches_reference_errors():
     ok = api.RenderOptions(camera=scenes.default_camera())
     api.validate_options(ok)
@@ -109,7 +159,7 @@ def test_compose_layered_single_rank_and_render_scene(O, ctx, tmp_path):
     from amrvolumerenderer_amd.images import (ImageRGBAFloatColorDepthSort, LayeredVolumeImage,
                                               compose_layered)
     from helpers import device_box
-    from test_frame_plan import painted_scene
+    from test_frame_plan import oracle_overlay, painted_scene
     W, H = 72, 48
     spec = scenes.make_amr_scene(32, 2, 8, "smooth")
     cam = scenes.default_camera()
@@ -135,6 +185,12 @@ def test_compose_layered_single_rank_and_render_scene(O, ctx, tmp_path):
     data = out.read_bytes()
     header = f"P6\n{W} {H}\n255\n".encode()
     assert data.startswith(header)
-    assert data[len(header):] == O.quantize_rgb8(want, W, H).tobytes()
-    with pytest.raises(RuntimeError):
-        api.render_scene(ctx, scene, api.RenderOptions(camera=cam, output_filename="x.png"))
+    want8 = O.quantize_rgb8(oracle_overlay(O, spec, cells, cam, want, W, H), W, H)
+    assert data[len(header):] == want8.tobytes()
+    assert not np.array_equal(want8, O.quantize_rgb8(want, W, H))  # the wireframe is visible
+
+    # .png: same pixels (SavePNG.cpp:50-73: 8-bit RGB rows, top-down)
+    png = tmp_path / "frame.png"
+    options.output_filename = str(png)
+    assert api.render_scene(ctx, scene, options) == 0
+    assert np.array_equal(decode_png_rgb8(png.read_bytes()), want8.reshape(H, W, 3))

@@ -28,7 +28,7 @@ def _worker(rank, world, port, policy, antialiasing, out_path):
         from amrvolumerenderer_amd import runtime, scenes
         from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
         from helpers import device_box
-        from test_frame_plan import local_indices, painted_scene
+        from test_frame_plan import local_indices, oracle_overlay, painted_scene
 
         root = int(round(antialiasing ** 0.5))
         spec = scenes.make_amr_scene(32, 2, 8, "smooth")
@@ -52,6 +52,9 @@ def _worker(rank, world, port, policy, antialiasing, out_path):
                                            world)
             if root > 1:
                 want = O.downsample(want, W, H, root).reshape(-1, 5)
+            # RenderParameters.draw_bounds defaults to the reference's behaviour: every rank
+            # overlays its own piece (or rank 0 the downsampled image)
+            want = oracle_overlay(O, spec, cells, cam, want, W, H)
             ok = np.array_equal(image.cpu().numpy().reshape(-1, 5).view(np.uint32),
                                 want.view(np.uint32))
             ok8 = np.array_equal(rgb8.cpu().numpy(), O.quantize_rgb8(want, W, H))

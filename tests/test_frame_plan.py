@@ -22,6 +22,14 @@ def painted_scene(O, spec, cam, W, H, transparency):
     return cells, layers, hints, ref
 
 
+def oracle_overlay(O, spec, cells, cam, image, W, H):
+    """The reference's frame tail after the downsample (VolumeRenderer.cpp:1192-1193, 1311-1314):
+    wireframe of the tight bounds, radius scale 1."""
+    oboxes = [O.make_box(c, m.min_corner, m.max_corner) for c, m in zip(cells, spec.boxes)]
+    tight = O.tight_bounds(oboxes, spec.bounds.min_corner, spec.bounds.max_corner)
+    return O.bbox_overlay(image, W, H, tight[0], tight[1], oracle_camera(O, cam), 1).reshape(-1, 5)
+
+
 def local_indices(owners, n_ranks):
     local = np.zeros(len(owners), np.int32)
     for r in range(n_ranks):

@@ -12,7 +12,7 @@ from amrvolumerenderer_amd.types import make_params
 
 import plan_helpers as PH
 from helpers import assert_bit_equal, device_box
-from test_frame_plan import local_indices, painted_scene
+from test_frame_plan import local_indices, oracle_overlay, painted_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -66,8 +66,8 @@ def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency):
     assert np.array_equal(got8, O.quantize_rgb8(want, W, H)[::-1].reshape(-1, 3))
 
 
-@pytest.mark.parametrize("antialiasing", [1, 4])
-def test_frame_renderer_single_rank(O, ctx, antialiasing):
+@pytest.mark.parametrize("antialiasing,draw_bounds", [(1, False), (4, False), (1, True), (4, True)])
+def test_frame_renderer_single_rank(O, ctx, antialiasing, draw_bounds):
     root = int(round(antialiasing ** 0.5))
     W, H = 64, 40
     spec = scenes.make_amr_scene(32, 2, 8, "smooth")
@@ -77,6 +77,8 @@ def test_frame_renderer_single_rank(O, ctx, antialiasing):
     want, _, _ = O.compose_layered(layers, hints, owners, np.arange(len(cells)), 1)
     if root > 1:
         want = O.downsample(want, W, H, root).reshape(-1, 5)
+    if draw_bounds:  # VolumeRenderer.cpp:1311-1314: tight bounds, radius scale 1, after the AA
+        want = oracle_overlay(O, spec, cells, cam, want, W, H)
     want8 = O.quantize_rgb8(want, W, H)
 
     meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
@@ -84,7 +86,8 @@ def test_frame_renderer_single_rank(O, ctx, antialiasing):
              zip(cells, spec.boxes)]
     renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
     assert np.float32(renderer.reference_sample_distance) == np.float32(ref)
-    image, rgb8 = renderer.render(RenderParameters(W, H, 0.5, antialiasing), cam, want_image=True)
+    image, rgb8 = renderer.render(
+        RenderParameters(W, H, 0.5, antialiasing, draw_bounds=draw_bounds), cam, want_image=True)
     renderer.synchronize()
     assert_bit_equal(image.cpu().numpy(), want, "frame image")
     assert np.array_equal(rgb8.cpu().numpy(), want8)
