@@ -10,6 +10,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "avr_internal.h"
@@ -36,9 +37,40 @@ void hip_check(hipError_t err, const char* what) {
   }
 }
 
+// Host waits poll the event instead of blocking in hipEventSynchronize / hipStreamSynchronize:
+// a blocking wait that outlasts the runtime's spin phase sleeps on an interrupt, and waking from
+// it was measured to take milliseconds on this platform -- by then a pipelined renderer's queue
+// has run dry (5-7 ms stalls every few frames at 1.3 ms per frame, tools/host_stalls.py).
+void wait_event(hipEvent_t event, const char* what) {
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t status = hipEventQuery(event);
+    if (status == hipSuccess) return;
+    if (status != hipErrorNotReady) hip_check(status, what);
+    if (spins > 64) std::this_thread::yield();
+  }
+}
+
+// Waits until everything queued on `stream` so far has finished.
+void wait_stream(hipStream_t stream, const char* what) {
+  hipEvent_t event = nullptr;
+  hip_check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
+  const hipError_t recorded = hipEventRecord(event, stream);
+  if (recorded != hipSuccess) {
+    (void)hipEventDestroy(event);
+    hip_check(recorded, what);
+  }
+  try {
+    wait_event(event, what);
+  } catch (...) {
+    (void)hipEventDestroy(event);
+    throw;
+  }
+  (void)hipEventDestroy(event);
+}
+
 // Per-call descriptors (box table, transfer-function tables, run tables, ...) travel to the
 // device in ONE asynchronous copy per call: they are packed into a pinned host block and copied
-// to its device twin.  A ring of blocks lets the host run several calls ahead of the GPU
+// to its device twin by a small kernel.  A ring of blocks lets the host run several calls ahead of the GPU
 // without waiting (a block is re-used only after the copy that read it has completed).
 class StagingRing {
  public:
@@ -64,7 +96,7 @@ class StagingRing {
       hip_check(hipEventCreateWithFlags(&current_->done, hipEventDisableTiming), "hipEventCreate");
     }
     if (current_->pending) {
-      hip_check(hipEventSynchronize(current_->done), "hipEventSynchronize(staging)");
+      wait_event(current_->done, "hipEventQuery(staging)");
       current_->pending = false;
     }
     const size_t need = bytes + static_cast<size_t>(items + 1) * kAlign;
@@ -76,7 +108,9 @@ class StagingRing {
       size_t cap = 1 << 16;
       while (cap < need) cap *= 2;
       hip_check(hipMalloc(&current_->dev, cap), "hipMalloc(staging)");
-      hip_check(hipHostMalloc(&current_->host, cap, hipHostMallocDefault), "hipHostMalloc(staging)");
+      hip_check(hipHostMalloc(&current_->host, cap, hipHostMallocMapped), "hipHostMalloc(staging)");
+      hip_check(hipHostGetDevicePointer(&current_->host_mapped, current_->host, 0),
+                "hipHostGetDevicePointer(staging)");
       current_->capacity = cap;
     }
     used_ = 0;
@@ -94,11 +128,14 @@ class StagingRing {
     return device;
   }
 
-  // One copy for the whole batch, ordered on `stream` before the kernels that read it.
+  // One copy for the whole batch, ordered on `stream` before the kernels that read it.  The
+  // copy is a kernel reading the pinned block through its device mapping: hipMemcpyAsync from
+  // pinned memory was measured to block the host until the stream had drained, every few frames
+  // (5-7 ms with five 1.3 ms frames queued; tools/host_stalls.py), and a launch never does.
   void commit(hipStream_t stream) {
     if (used_ != 0) {
-      hip_check(hipMemcpyAsync(current_->dev, current_->host, used_, hipMemcpyHostToDevice, stream),
-                "hipMemcpyAsync(staging)");
+      const int status = launch_upload(current_->host_mapped, current_->dev, used_, stream);
+      if (status != AVR_OK) throw HipFailure(g_last_error);
     }
     hip_check(hipEventRecord(current_->done, stream), "hipEventRecord(staging)");
     current_->pending = true;
@@ -108,7 +145,7 @@ class StagingRing {
   void drain() {
     for (Slot& slot : slots_) {
       if (slot.pending) {
-        hip_check(hipEventSynchronize(slot.done), "hipEventSynchronize(staging)");
+        wait_event(slot.done, "hipEventQuery(staging)");
         slot.pending = false;
       }
     }
@@ -118,6 +155,7 @@ class StagingRing {
   struct Slot {
     void* dev = nullptr;
     void* host = nullptr;
+    void* host_mapped = nullptr;  // device address of `host`
     size_t capacity = 0;
     hipEvent_t done = nullptr;
     bool pending = false;
@@ -148,7 +186,7 @@ struct avr_scene {
   }
   uint8_t* classified_slot(int slot, size_t bytes, hipStream_t stream) {
     if (bytes > classified_capacity[slot]) {
-      avr::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+      avr::wait_stream(stream, "classified_slot");
       if (classified[slot] != nullptr) (void)hipFree(classified[slot]);
       classified[slot] = nullptr;
       classified_capacity[slot] = 0;
@@ -165,6 +203,7 @@ struct avr_context {
   hipStream_t stream = nullptr;
   avr::StagingRing staging;
   avr_scene scratch_scene;         // classified storage of avr_paint_box
+  std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
 };
 
 
@@ -220,7 +259,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   require(slot == 0 || slot == 1, "classified slot must be 0 or 1");
   avr::FramePlan local;
   avr::FramePlan& plan = cached ? *cached : local;
-  if (plan.boxes.size() != static_cast<size_t>(n_boxes) || plan.supertile_order.empty()) {
+  if (plan.boxes.size() != static_cast<size_t>(n_boxes) || !plan.ready) {
     avr::plan_frame(boxes, n_boxes, transform, params, camera, &plan);
   }
   if (n_runs == 0) return AVR_OK;
@@ -233,6 +272,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   launch.n_classify_tiles = plan.classify_tile_begin.back();
   launch.classified = scene->classified_slot(slot, plan.classified_bytes, ctx->stream);
 
+  std::vector<avr::MarchItemDev>& items = ctx->march_items;  // scratch, reused across frames
   size_t bytes = plan.boxes.size() * sizeof(avr::BoxDev);
   if (phases & kClassify) bytes += plan.classify_tile_begin.size() * sizeof(uint32_t);
   if (phases & kMarch) {
@@ -251,8 +291,9 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     for (int i = 0; i < n_order; ++i) {
       require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
     }
+    avr::build_march_items(plan, box_order, run_end, n_runs, run_rects, &items);
     bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
-             plan.supertile_order.size() * sizeof(uint32_t) +
+             items.size() * sizeof(avr::MarchItemDev) +
              run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev);
   }
   avr::StagingRing& staging = ctx->staging;
@@ -274,8 +315,8 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.run_blocks_dev = staging.add(run_blocks.data(), run_blocks.size());
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
-    launch.supertile_order_dev =
-        staging.add(plan.supertile_order.data(), plan.supertile_order.size());
+    launch.items_dev = staging.add(items.data(), items.size());
+    launch.n_items = static_cast<uint32_t>(items.size());
     launch.only_mode = plan.boxes.empty() ? -1 : plan.boxes[0].index_mode;
     for (const avr::BoxDev& dev : plan.boxes) {
       if (dev.index_mode != launch.only_mode) launch.only_mode = -1;
@@ -340,7 +381,7 @@ int avr_context_set_stream(avr_context* ctx, void* hip_stream) {
 int avr_context_synchronize(avr_context* ctx) {
   return guarded([&]() -> int {
     bind_device(ctx);
-    avr::hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    avr::wait_stream(ctx->stream, "avr_context_synchronize");
     return AVR_OK;
   });
 }
@@ -671,7 +712,7 @@ int avr_scene_scalar_stats(avr_context* ctx, const avr_scene* scene, double stat
       if (status == AVR_OK) {
         avr::hip_check(hipMemcpyAsync(&result, out_dev, sizeof(result), hipMemcpyDeviceToHost,
                                       ctx->stream), "hipMemcpyAsync");
-        avr::hip_check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        avr::wait_stream(ctx->stream, "avr_scene_scalar_stats");
       }
     } catch (...) {
       (void)hipFree(scratch);

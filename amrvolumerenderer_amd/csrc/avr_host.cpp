@@ -507,19 +507,9 @@ float reference_sample_distance(const avr_box* boxes, int n_boxes, const double 
   return std::max(coarsest * 0.5f, 1e-5f);
 }
 
-uint32_t supertile_slots(int width, int height) {
-  const int tiles_x = (width + kTile - 1) / kTile;
-  const int tiles_y = (height + kTile - 1) / kTile;
-  uint32_t side = 1;
-  while (static_cast<int>(side) < std::max(tiles_x, tiles_y)) side <<= 1;
-  const uint32_t padded_tiles = side * side;  // Morton range covering the tile grid
-  const uint32_t slots = (padded_tiles + kSuperTileTiles - 1) / kSuperTileTiles;
-  return ((slots + kXcds - 1) / kXcds) * kXcds;
-}
-
 namespace {
 
-// Morton index of super-tile (sx, sy): the tile sequence number of its first tile / 64.
+// Morton index of super-tile (sx, sy): the tile sequence number of its first tile / 4.
 uint32_t interleave16(uint32_t v) {
   v &= 0xffffu;
   v = (v | (v << 8)) & 0x00ff00ffu;
@@ -529,43 +519,68 @@ uint32_t interleave16(uint32_t v) {
   return v;
 }
 
-// Orders the screen super-tiles by an estimate of their march cost (rays x samples per ray of
-// the boxes projecting onto them), most expensive first.  The order only decides WHEN a
+}  // namespace
+
+// Items are ordered by an estimate of their march cost (rays x samples per ray of the run's
+// boxes projecting onto the super-tile), most expensive first.  The order only decides WHEN a
 // workgroup runs (heavy ones first, so the cheap ones fill the tail), never what it computes.
-void order_supertiles(const FramePlan& plan, std::vector<uint32_t>* order) {
-  const FrameConsts& fc = plan.consts;
-  const uint32_t slots = supertile_slots(fc.width, fc.height);
+void build_march_items(const FramePlan& plan, const int32_t* box_order, const int32_t* run_end,
+                       int n_runs, const std::vector<RunRectDev>& run_rects,
+                       std::vector<MarchItemDev>* items) {
   const int span = kTile * kSuperTileSide;  // pixels per super-tile side
-  const int sx_count = (fc.width + span - 1) / span;
-  const int sy_count = (fc.height + span - 1) / span;
-  std::vector<double> cost(slots, 0.0);
-  for (const BoxDev& box : plan.boxes) {
-    if (box.rect[2] < box.rect[0] || box.rect[3] < box.rect[1]) continue;
-    const double ex = static_cast<double>(box.maxc[0]) - box.minc[0];
-    const double ey = static_cast<double>(box.maxc[1]) - box.minc[1];
-    const double ez = static_cast<double>(box.maxc[2]) - box.minc[2];
-    const double steps = std::sqrt(ex * ex + ey * ey + ez * ez) /
-                         std::max(static_cast<double>(box.sample_dist), 1e-30);
-    if (!std::isfinite(steps)) continue;
-    for (int sy = box.rect[1] / span; sy <= box.rect[3] / span && sy < sy_count; ++sy) {
-      for (int sx = box.rect[0] / span; sx <= box.rect[2] / span && sx < sx_count; ++sx) {
-        const int x0 = std::max(box.rect[0], sx * span), x1 = std::min(box.rect[2], sx * span + span - 1);
-        const int y0 = std::max(box.rect[1], sy * span), y1 = std::min(box.rect[3], sy * span + span - 1);
-        const uint32_t slot = (interleave16(static_cast<uint32_t>(sx)) |
-                               (interleave16(static_cast<uint32_t>(sy)) << 1));
-        if (slot < slots && x1 >= x0 && y1 >= y0) {
-          cost[slot] += steps * static_cast<double>(x1 - x0 + 1) * static_cast<double>(y1 - y0 + 1);
+  items->clear();
+  std::vector<float> cost;       // per item
+  std::vector<float> run_cost;   // dense over the current run's super-tile rectangle
+  int position = 0;
+  for (int run = 0; run < n_runs; ++run) {
+    const int end = run_end[run];
+    const RunRectDev& rr = run_rects[static_cast<size_t>(run)];
+    if (rr.x1 < rr.x0 || rr.y1 < rr.y0) {
+      position = end;
+      continue;
+    }
+    const int sx0 = rr.x0 / span, sx1 = rr.x1 / span, sy0 = rr.y0 / span, sy1 = rr.y1 / span;
+    const int nsx = sx1 - sx0 + 1;
+    run_cost.assign(static_cast<size_t>(nsx) * (sy1 - sy0 + 1), 0.0f);
+    for (; position < end; ++position) {
+      const BoxDev& box = plan.boxes[static_cast<size_t>(box_order[position])];
+      if (box.rect[2] < box.rect[0] || box.rect[3] < box.rect[1]) continue;
+      const float ex = box.maxc[0] - box.minc[0];
+      const float ey = box.maxc[1] - box.minc[1];
+      const float ez = box.maxc[2] - box.minc[2];
+      const float steps = std::sqrt(ex * ex + ey * ey + ez * ez) / std::max(box.sample_dist, 1e-30f);
+      if (!std::isfinite(steps)) continue;
+      const int bx0 = std::max(box.rect[0], rr.x0), bx1 = std::min(box.rect[2], rr.x1);
+      const int by0 = std::max(box.rect[1], rr.y0), by1 = std::min(box.rect[3], rr.y1);
+      for (int sy = by0 / span; sy <= by1 / span; ++sy) {
+        const int y0 = std::max(by0, sy * span), y1 = std::min(by1, sy * span + span - 1);
+        for (int sx = bx0 / span; sx <= bx1 / span; ++sx) {
+          const int x0 = std::max(bx0, sx * span), x1 = std::min(bx1, sx * span + span - 1);
+          run_cost[static_cast<size_t>(sy - sy0) * nsx + (sx - sx0)] +=
+              steps * static_cast<float>((x1 - x0 + 1) * (y1 - y0 + 1));
         }
       }
     }
+    for (int sy = sy0; sy <= sy1; ++sy) {
+      for (int sx = sx0; sx <= sx1; ++sx) {
+        const uint32_t slot = interleave16(static_cast<uint32_t>(sx)) |
+                              (interleave16(static_cast<uint32_t>(sy)) << 1);
+        items->push_back(MarchItemDev{slot, static_cast<uint32_t>(run)});
+        cost.push_back(run_cost[static_cast<size_t>(sy - sy0) * nsx + (sx - sx0)]);
+      }
+    }
   }
-  order->resize(slots);
-  for (uint32_t i = 0; i < slots; ++i) (*order)[i] = i;
-  std::stable_sort(order->begin(), order->end(),
+  // sort by cost, most expensive first (ties: generation order = run, then rows of super-tiles)
+  std::vector<uint32_t> index(items->size());
+  for (uint32_t i = 0; i < index.size(); ++i) index[i] = i;
+  std::stable_sort(index.begin(), index.end(),
                    [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+  std::vector<MarchItemDev> sorted;
+  sorted.reserve(((items->size() + kXcds - 1) / kXcds) * kXcds);
+  for (uint32_t i : index) sorted.push_back((*items)[i]);
+  while (sorted.size() % kXcds != 0) sorted.push_back(MarchItemDev{kNoMarchItem, 0});
+  items->swap(sorted);
 }
-
-}  // namespace
 
 void plan_cells(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
                 FramePlan* plan) {
@@ -898,7 +913,7 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
     dev.mesh_eps = std::sqrt(ex * ex + ey * ey + ez * ez) * 0.0001f;
     screen_rect(box, camera, basis, fc, dev.rect);
   }
-  order_supertiles(*plan, &plan->supertile_order);
+  plan->ready = true;
 }
 
 }  // namespace avr

@@ -81,17 +81,30 @@ struct FramePlan {
   int n_tables = 0;
   std::vector<uint32_t> classify_tile_begin;  // n_boxes + 1: prefix sum of classify workgroups
   uint64_t classified_bytes = 0;              // size of the frame's classified buffer
-  std::vector<uint32_t> supertile_order;      // screen super-tiles, most expensive first
+  bool ready = false;                         // set by plan_frame
 };
 
+// One unit of march work: a screen super-tile of one run.  Runs are independent (each has its
+// own layer, started from the empty pixel), so a rank's runs are marched by different
+// workgroups; a frame's critical path is then one run's rays, not all of a rank's boxes.
+struct MarchItemDev {
+  uint32_t slot;  // Morton index of the super-tile; kNoMarchItem = padding
+  uint32_t run;
+};
+constexpr uint32_t kNoMarchItem = 0xffffffffu;
+
 // Screen tiling of the march kernel: workgroup = 16 x 16 pixels, super-tile = 2 x 2 workgroups
-// (Morton order inside), super-tiles dealt round-robin to the 8 XCDs in `supertile_order`.
+// (Morton order inside); the (super-tile, run) items are dealt round-robin to the 8 XCDs in the
+// host's cost order.
 constexpr int kTile = 16;
 constexpr int kSuperTileSide = 2;
 constexpr int kSuperTileTiles = kSuperTileSide * kSuperTileSide;
 constexpr int kXcds = 8;
-// Number of super-tile slots of a w x h image (multiple of kXcds).
-uint32_t supertile_slots(int width, int height);
+// The march items of a frame: for every run the super-tiles its screen rectangle touches, most
+// expensive first (estimated samples), padded with kNoMarchItem to a multiple of kXcds.
+void build_march_items(const FramePlan& plan, const int32_t* box_order, const int32_t* run_end,
+                       int n_runs, const std::vector<RunRectDev>& run_rects,
+                       std::vector<MarchItemDev>* items);
 
 // ---- host prologue (avr_host.cpp) ---------------------------------------------------------
 void build_color_table(float alpha_scale, float normalization_factor, const float scalar_range[2],
@@ -127,11 +140,15 @@ struct RenderLaunch {
   const uint32_t* tile_begin_dev;   // n_boxes + 1 prefix of classify workgroups
   int n_boxes;
   uint32_t n_classify_tiles;
-  const uint32_t* supertile_order_dev;  // supertile_slots(width, height) entries
+  const MarchItemDev* items_dev;  // n_items entries (multiple of kXcds)
+  uint32_t n_items;
   int only_mode;                        // the IndexMode shared by every box, or -1
 };
 // classify pass (cells -> table indices) and march; the march reads what the classify pass of
 // the same frame wrote into `classified`
+// Copies `bytes` (rounded up to 16; both blocks are that large) from device-mapped pinned host
+// memory to device memory.
+int launch_upload(const void* host_mapped, void* dev, size_t bytes, void* stream);
 int launch_classify(const RenderLaunch& launch, void* stream);
 int launch_march(const RenderLaunch& launch, void* stream);
 int launch_blend(int kind, const void* top, const void* bottom, void* out, int64_t n, void* stream);

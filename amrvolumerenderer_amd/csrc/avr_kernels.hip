@@ -16,6 +16,9 @@
 //   downsample / quantize / encode / decode   frame tail
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include <cmath>
 #include <cstdint>
 
@@ -131,44 +134,58 @@ __device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_
 // per axis (VolumePainter.cpp:846-867).  `fx` = pos - min >= 0 for an inside sample, so
 // truncation equals floor and only the upper clamp can bind on the multiply paths; the
 // exact-divide path restates the reference literally.
+// (qx, qy, qz) = (pos - min) * (1 / spacing), already computed by the caller.  CLAMP = false:
+// the caller knows the truncated quotients are <= n - 1 (see the interior loop of march_box).
+template <int MODE, bool CLAMP>
+__device__ __forceinline__ uint32_t offset_from_quotients(const BoxDev& box, uint32_t row_pitch,
+                                                          uint32_t plane_pitch, float qx, float qy,
+                                                          float qz, float fx, float fy, float fz) {
+  int i = static_cast<int>(qx);
+  int j = static_cast<int>(qy);
+  int k = static_cast<int>(qz);
+  if (CLAMP) {
+    i = (i > box.nx - 1) ? box.nx - 1 : i;
+    j = (j > box.ny - 1) ? box.ny - 1 : j;
+    k = (k > box.nz - 1) ? box.nz - 1 : k;
+  }
+  if (MODE == kReciprocal) {
+    // q is within 2^-22 * q of the correctly rounded quotient; the floors can differ only
+    // when q sits this close to an integer ("Exact index without the divide")
+    const float ex = fabsf(qx - rintf(qx));
+    const float ey = fabsf(qy - rintf(qy));
+    const float ez = fabsf(qz - rintf(qz));
+    if (fminf(fminf(ex, ey), ez) <= box.near_tol) {
+      int ei = static_cast<int>(floorf(fx / box.dx));
+      int ej = static_cast<int>(floorf(fy / box.dy));
+      int ek = static_cast<int>(floorf(fz / box.dz));
+      i = (ei < 0) ? 0 : ((ei >= box.nx) ? box.nx - 1 : ei);
+      j = (ej < 0) ? 0 : ((ej >= box.ny) ? box.ny - 1 : ej);
+      k = (ek < 0) ? 0 : ((ek >= box.nz) ? box.nz - 1 : ek);
+    }
+  }
+  return bricklet_offset(i, j, k, row_pitch, plane_pitch);
+}
+
 template <int MODE>
 __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, uint32_t row_pitch,
                                                 uint32_t plane_pitch, float fx, float fy,
                                                 float fz) {
-  int i = 0, j = 0, k = 0;
-  bool exact = (MODE == kExactDivide);
-  if (MODE != kExactDivide) {
-    const float qx = fx * box.inv_dx;
-    const float qy = fy * box.inv_dy;
-    const float qz = fz * box.inv_dz;
-    i = static_cast<int>(qx);
-    j = static_cast<int>(qy);
-    k = static_cast<int>(qz);
-    i = (i > box.nx - 1) ? box.nx - 1 : i;
-    j = (j > box.ny - 1) ? box.ny - 1 : j;
-    k = (k > box.nz - 1) ? box.nz - 1 : k;
-    if (MODE == kReciprocal) {
-      // q is within 2^-22 * q of the correctly rounded quotient; the floors can differ only
-      // when q sits this close to an integer ("Exact index without the divide")
-      const float ex = fabsf(qx - rintf(qx));
-      const float ey = fabsf(qy - rintf(qy));
-      const float ez = fabsf(qz - rintf(qz));
-      exact = fminf(fminf(ex, ey), ez) <= box.near_tol;
-    }
-  }
-  if (exact) {
+  if (MODE == kExactDivide) {  // the reference, literally
     int ei = static_cast<int>(floorf(fx / box.dx));
     int ej = static_cast<int>(floorf(fy / box.dy));
     int ek = static_cast<int>(floorf(fz / box.dz));
     ei = (ei < 0) ? 0 : ((ei >= box.nx) ? box.nx - 1 : ei);
     ej = (ej < 0) ? 0 : ((ej >= box.ny) ? box.ny - 1 : ej);
     ek = (ek < 0) ? 0 : ((ek >= box.nz) ? box.nz - 1 : ek);
-    i = ei;
-    j = ej;
-    k = ek;
+    return bricklet_offset(ei, ej, ek, row_pitch, plane_pitch);
   }
-  return bricklet_offset(i, j, k, row_pitch, plane_pitch);
+  return offset_from_quotients<MODE, true>(box, row_pitch, plane_pitch, fx * box.inv_dx,
+                                           fy * box.inv_dy, fz * box.inv_dz, fx, fy, fz);
 }
+
+// Two floats handled by one packed instruction (v_pk_mul_f32 / v_pk_add_f32: each half is an
+// ordinary IEEE binary32 operation, so results equal the scalar expressions bit for bit).
+typedef float float_pair __attribute__((ext_vector_type(2)));
 
 // The march of one ray through one box (VolumePainter.cpp:811-921 + host epilogue :939-955).
 // Returns the layer pixel the reference would store for this box.
@@ -217,6 +234,17 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     const float bx = ray.ox + ray.dx * safe_end, by = ray.oy + ray.dy * safe_end,
                 bz = ray.oz + ray.dz * safe_end;
     interior = AVR_INSIDE(ax, ay, az) && AVR_INSIDE(bx, by, bz);
+    if (MODE != kExactDivide) {
+      // (pos - min) * inv_d is monotone in pos as well, so the truncated quotients of all
+      // interior samples lie between those of the two end points: if both are <= n - 1 the
+      // upper clamp (:846-867) never binds inside the loop.  (A ray whose entry point rounds
+      // onto the max face takes the general loop.)
+      const int ia = static_cast<int>((ax - min_x) * box.inv_dx), ib = static_cast<int>((bx - min_x) * box.inv_dx);
+      const int ja = static_cast<int>((ay - min_y) * box.inv_dy), jb = static_cast<int>((by - min_y) * box.inv_dy);
+      const int ka = static_cast<int>((az - min_z) * box.inv_dz), kb = static_cast<int>((bz - min_z) * box.inv_dz);
+      interior = interior && ia < box.nx && ib < box.nx && ja < box.ny && jb < box.ny &&
+                 ka < box.nz && kb < box.nz;
+    }
   }
   if (interior) {
     // Four steps per trip while all four lie below safe_end: the four cell bytes and the four
@@ -231,22 +259,34 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
       const float d3 = d2 + step;
       const float d4 = d3 + step;
       if (!(d4 < safe_end)) break;
-      const uint32_t off1 = cell_offset<MODE>(box, row_pitch, plane_pitch,
-                                              (ray.ox + ray.dx * d1) - min_x,
-                                              (ray.oy + ray.dy * d1) - min_y,
-                                              (ray.oz + ray.dz * d1) - min_z);
-      const uint32_t off2 = cell_offset<MODE>(box, row_pitch, plane_pitch,
-                                              (ray.ox + ray.dx * d2) - min_x,
-                                              (ray.oy + ray.dy * d2) - min_y,
-                                              (ray.oz + ray.dz * d2) - min_z);
-      const uint32_t off3 = cell_offset<MODE>(box, row_pitch, plane_pitch,
-                                              (ray.ox + ray.dx * d3) - min_x,
-                                              (ray.oy + ray.dy * d3) - min_y,
-                                              (ray.oz + ray.dz * d3) - min_z);
-      const uint32_t off4 = cell_offset<MODE>(box, row_pitch, plane_pitch,
-                                              (ray.ox + ray.dx * d4) - min_x,
-                                              (ray.oy + ray.dy * d4) - min_y,
-                                              (ray.oz + ray.dz * d4) - min_z);
+      uint32_t off1, off2, off3, off4;
+      if (MODE == kExactDivide) {
+        off1 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d1) - min_x,
+                                 (ray.oy + ray.dy * d1) - min_y, (ray.oz + ray.dz * d1) - min_z);
+        off2 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d2) - min_x,
+                                 (ray.oy + ray.dy * d2) - min_y, (ray.oz + ray.dz * d2) - min_z);
+        off3 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d3) - min_x,
+                                 (ray.oy + ray.dy * d3) - min_y, (ray.oz + ray.dz * d3) - min_z);
+        off4 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d4) - min_x,
+                                 (ray.oy + ray.dy * d4) - min_y, (ray.oz + ray.dz * d4) - min_z);
+      } else {
+        // the same expressions as the scalar path, two samples per packed instruction
+        const float_pair d12 = {d1, d2}, d34 = {d3, d4};
+        const float_pair fx12 = (ray.ox + ray.dx * d12) - min_x, fx34 = (ray.ox + ray.dx * d34) - min_x;
+        const float_pair fy12 = (ray.oy + ray.dy * d12) - min_y, fy34 = (ray.oy + ray.dy * d34) - min_y;
+        const float_pair fz12 = (ray.oz + ray.dz * d12) - min_z, fz34 = (ray.oz + ray.dz * d34) - min_z;
+        const float_pair qx12 = fx12 * box.inv_dx, qx34 = fx34 * box.inv_dx;
+        const float_pair qy12 = fy12 * box.inv_dy, qy34 = fy34 * box.inv_dy;
+        const float_pair qz12 = fz12 * box.inv_dz, qz34 = fz34 * box.inv_dz;
+        off1 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx12.x, qy12.x,
+                                                  qz12.x, fx12.x, fy12.x, fz12.x);
+        off2 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx12.y, qy12.y,
+                                                  qz12.y, fx12.y, fy12.y, fz12.y);
+        off3 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx34.x, qy34.x,
+                                                  qz34.x, fx34.x, fy34.x, fz34.x);
+        off4 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx34.y, qy34.y,
+                                                  qz34.y, fx34.y, fy34.y, fz34.y);
+      }
       const int idx1 = cells[off1];
       const int idx2 = cells[off2];
       const int idx3 = cells[off3];
@@ -269,8 +309,12 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
         const bool stops_early = (a1 >= 1.0f) || (a2 >= 1.0f) || (a3 >= 1.0f);
         if (__builtin_amdgcn_ballot_w64(stops_early) == 0) {
           const float w4 = s4.w * (1.0f - a3);
-          acc_r = (((acc_r + s1.x * w1) + s2.x * w2) + s3.x * w3) + s4.x * w4;
-          acc_g = (((acc_g + s1.y * w1) + s2.y * w2) + s3.y * w3) + s4.y * w4;
+          const float_pair rg1 = {s1.x, s1.y}, rg2 = {s2.x, s2.y}, rg3 = {s3.x, s3.y},
+                           rg4 = {s4.x, s4.y};
+          float_pair acc_rg = {acc_r, acc_g};
+          acc_rg = (((acc_rg + rg1 * w1) + rg2 * w2) + rg3 * w3) + rg4 * w4;
+          acc_r = acc_rg.x;
+          acc_g = acc_rg.y;
           acc_b = (((acc_b + s1.z * w1) + s2.z * w2) + s3.z * w3) + s4.z * w4;
           acc_a = a3 + w4;
         } else {
@@ -368,9 +412,32 @@ render_runs_kernel(
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
     const int n_runs, const int n_pieces, const RunRectDev* __restrict__ run_rects,
     const RunBlockDev* __restrict__ run_blocks, const int tiles_x, const int tiles_y,
-    const uint32_t* __restrict__ supertile_order, float* __restrict__ out,
+    const MarchItemDev* __restrict__ items, float* __restrict__ out,
     unsigned long long* samples_out) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
+
+  // ---- XCD-aware work assignment ------------------------------------------------------------
+  // Work item = one super-tile (2 x 2 workgroups in Morton order) of one run.  Workgroups are
+  // dealt round-robin over the 8 XCDs (block b -> XCD b % 8) and every XCD takes whole items, so
+  // the workgroups resident on one XCD at a time cover compact patches of the screen and re-use
+  // the same bricklets from that XCD's L2; items come in the host's cost order, most expensive
+  // first, so the long rays start early and the cheap tiles fill the tail.
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b % kXcds;
+  const unsigned within = b / kXcds;
+  const MarchItemDev item = items[(within / kSuperTileTiles) * kXcds + xcd];
+  if (item.slot == kNoMarchItem) return;
+  const unsigned seq = item.slot * kSuperTileTiles + (within % kSuperTileTiles);
+  const int tile_x = static_cast<int>(compact_bits(seq));
+  const int tile_y = static_cast<int>(compact_bits(seq >> 1));
+  if (tile_x >= tiles_x || tile_y >= tiles_y) return;
+  const int run = static_cast<int>(item.run);
+  // Outside the run's screen rectangle nothing is stored (and no box of the run can be hit).
+  const RunRectDev rect = run_rects[run];
+  if (rect.x1 < tile_x * kTile || rect.x0 > tile_x * kTile + kTile - 1 ||
+      rect.y1 < tile_y * kTile || rect.y0 > tile_y * kTile + kTile - 1) {
+    return;
+  }
 
   // ---- stage the transfer-function tables in LDS (one per AMR sampling level) -------------
   {
@@ -379,21 +446,6 @@ render_runs_kernel(
     for (int e = threadIdx.x; e < total; e += kBlockThreads) lds_tables[e] = src[e];
   }
   __syncthreads();
-
-  // ---- XCD-aware tile assignment ------------------------------------------------------------
-  // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8).  Every XCD gets
-  // whole super-tiles (2 x 2 workgroups in Morton order), so the workgroups resident on one
-  // XCD at a time cover a compact patch of the screen and re-use the same bricklets from that
-  // XCD's L2; super-tiles are taken in the host's cost order, most expensive first, so the
-  // long rays start early and the cheap tiles fill the tail.
-  const unsigned b = blockIdx.x;
-  const unsigned xcd = b % kXcds;
-  const unsigned within = b / kXcds;
-  const unsigned slot = supertile_order[(within / kSuperTileTiles) * kXcds + xcd];
-  const unsigned seq = slot * kSuperTileTiles + (within % kSuperTileTiles);
-  const int tile_x = static_cast<int>(compact_bits(seq));
-  const int tile_y = static_cast<int>(compact_bits(seq >> 1));
-  if (tile_x >= tiles_x || tile_y >= tiles_y) return;
 
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -411,11 +463,10 @@ render_runs_kernel(
   const float inv_dz = 1.0f / ray.dz;
 
   unsigned fetches = 0;
-  int position = 0;
-  for (int run = 0; run < n_runs; ++run) {
+  {
     const int end = run_end[run];
     Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};  // cleared layer pixel: exact blend identity
-    for (; position < end; ++position) {
+    for (int position = (run > 0) ? run_end[run - 1] : 0; position < end; ++position) {
       const BoxDev& box = boxes[order[position]];
       // wave-uniform cull against the box's conservative screen rectangle
       if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + 7 || box.rect[3] < wave_y0 ||
@@ -462,10 +513,8 @@ render_runs_kernel(
         acc = blend_depthsort(acc, layer);
       }
     }
-    // The run's layer is stored only inside the run's screen rectangle (outside it no box of
-    // the run can be hit, so the pixel is the empty layer pixel), in the block of the
+    // The run's layer is stored only inside the run's screen rectangle, in the block of the
     // DirectSend piece the pixel belongs to.
-    const RunRectDev rect = run_rects[run];
     if (live && px >= rect.x0 && px <= rect.x1 && py >= rect.y0 && py <= rect.y1) {
       const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
       int64_t piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
@@ -488,6 +537,14 @@ render_runs_kernel(
       total += __shfl_down(total, offset, 64);
     }
     if (lane == 0 && total != 0) atomicAdd(samples_out, total);
+  }
+}
+
+// Descriptor upload: pinned host block (read over PCIe through its device mapping) -> HBM.
+__global__ void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    dst[i] = src[i];
   }
 }
 
@@ -788,42 +845,83 @@ __global__ void fold_runs_kernel(const float* const* __restrict__ slices, int n_
 // Receiver side of the layered compose for one DirectSend piece (DirectSendBase.cpp:400-446):
 // per pixel, the runs that cover it are blended in global order.  Starting from the cleared
 // pixel instead of the first run's pixel gives the same bits (exact identity of the blend).
-__global__ void fold_plan_kernel(const int width, const int64_t piece_begin,
-                                 const int64_t piece_end, const int n_runs,
-                                 const RunRectDev* __restrict__ rects,
-                                 const RunBlockDev* __restrict__ blocks,
-                                 const float* __restrict__ recv, float* __restrict__ out_piece,
-                                 uint8_t* __restrict__ out_rgb8) {
-  const int64_t n = piece_end - piece_begin;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
-       q += stride) {
-    const int64_t p = piece_begin + q;
-    const int px = static_cast<int>(p % width);
-    const int py = static_cast<int>(p / width);
-    Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};
-    for (int g = 0; g < n_runs; ++g) {
+//
+// One workgroup = up to 256 consecutive pixels of one image row.  The runs are scanned in chunks
+// of 256 (one run per thread): those whose rectangle touches the workgroup's row segment are
+// compacted -- order preserved -- into an LDS list with their source row address, and the pixels
+// then blend only the listed runs.
+struct FoldEntry {
+  int32_t x0, x1;
+  int64_t base;  // float offset of pixel x = 0 of this row inside the run's block
+};
+
+__global__ __launch_bounds__(256) void fold_plan_kernel(
+    const int width, const int64_t piece_begin, const int64_t piece_end, const int n_runs,
+    const RunRectDev* __restrict__ rects, const RunBlockDev* __restrict__ blocks,
+    const float* __restrict__ recv, float* __restrict__ out_piece,
+    uint8_t* __restrict__ out_rgb8, const int first_row, const int chunks_per_row) {
+  __shared__ FoldEntry list[256];
+  __shared__ int wave_count[4];
+  const int tid = static_cast<int>(threadIdx.x);
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int row = first_row + static_cast<int>(blockIdx.x) / chunks_per_row;
+  const int seg_x0 = (static_cast<int>(blockIdx.x) % chunks_per_row) * 256;
+  const int seg_x1 = min(seg_x0 + 255, width - 1);
+  const int px = seg_x0 + tid;
+  const int64_t p = static_cast<int64_t>(row) * width + px;
+  const bool live = (px < width) && (p >= piece_begin) && (p < piece_end);
+
+  Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};
+  for (int chunk = 0; chunk < n_runs; chunk += 256) {
+    const int g = chunk + tid;
+    bool touches = false;
+    FoldEntry entry = {0, -1, 0};
+    if (g < n_runs) {
       const RunRectDev rect = rects[g];
-      if (px < rect.x0 || px > rect.x1 || py < rect.y0 || py > rect.y1) continue;
-      const RunBlockDev block = blocks[g];
-      const float* src = recv + block.offset +
-                         (static_cast<int64_t>(py - block.first_row) * (rect.x1 - rect.x0 + 1) +
-                          (px - rect.x0)) * 5;
-      const Layer5 layer = {src[0], src[1], src[2], src[3], src[4]};
-      acc = blend_depthsort(acc, layer);
+      touches = rect.x0 <= seg_x1 && rect.x1 >= seg_x0 && rect.y0 <= row && rect.y1 >= row;
+      if (touches) {
+        const RunBlockDev block = blocks[g];
+        entry.x0 = rect.x0;
+        entry.x1 = rect.x1;
+        entry.base = block.offset + (static_cast<int64_t>(row - block.first_row) *
+                                         (rect.x1 - rect.x0 + 1) - rect.x0) * 5;
+      }
     }
-    float* d = out_piece + q * 5;
-    d[0] = acc.r;
-    d[1] = acc.g;
-    d[2] = acc.b;
-    d[3] = acc.a;
-    d[4] = acc.d;
-    if (out_rgb8 != nullptr) {
-      uint8_t* b = out_rgb8 + q * 3;
-      b[0] = static_cast<uint8_t>(component_as_byte(acc.r));
-      b[1] = static_cast<uint8_t>(component_as_byte(acc.g));
-      b[2] = static_cast<uint8_t>(component_as_byte(acc.b));
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(touches);
+    if (lane == 0) wave_count[wave] = __popcll(mask);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int c = wave_count[w];
+      before += (w < wave) ? c : 0;
+      total += c;
     }
+    if (touches) list[before + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
+    __syncthreads();
+    for (int e = 0; e < total; ++e) {
+      const FoldEntry run = list[e];  // same address for all lanes: LDS broadcast
+      if (live && px >= run.x0 && px <= run.x1) {
+        const float* src = recv + run.base + static_cast<int64_t>(px) * 5;
+        const Layer5 layer = {src[0], src[1], src[2], src[3], src[4]};
+        acc = blend_depthsort(acc, layer);
+      }
+    }
+    __syncthreads();  // the list is rewritten by the next chunk
+  }
+  if (!live) return;
+  const int64_t q = p - piece_begin;
+  float* d = out_piece + q * 5;
+  d[0] = acc.r;
+  d[1] = acc.g;
+  d[2] = acc.b;
+  d[3] = acc.a;
+  d[4] = acc.d;
+  if (out_rgb8 != nullptr) {
+    uint8_t* b = out_rgb8 + q * 3;
+    b[0] = static_cast<uint8_t>(component_as_byte(acc.r));
+    b[1] = static_cast<uint8_t>(component_as_byte(acc.g));
+    b[2] = static_cast<uint8_t>(component_as_byte(acc.b));
   }
 }
 
@@ -894,6 +992,15 @@ int check_launch(const char* what) {
 
 }  // namespace
 
+int launch_upload(const void* host_mapped, void* dev, size_t bytes, void* stream_v) {
+  const size_t n = (bytes + 15) / 16;
+  if (n == 0) return AVR_OK;
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 1024));
+  hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_v),
+                     static_cast<const uint4*>(host_mapped), static_cast<uint4*>(dev), n);
+  return check_launch("upload_kernel");
+}
+
 int launch_classify(const RenderLaunch& L, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   if (L.n_classify_tiles == 0) return AVR_OK;
@@ -915,14 +1022,15 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const int tiles_x = (L.consts.width + kTile - 1) / kTile;
   const int tiles_y = (L.consts.height + kTile - 1) / kTile;
-  const unsigned blocks = supertile_slots(L.consts.width, L.consts.height) * kSuperTileTiles;
+  const unsigned blocks = L.n_items * kSuperTileTiles;
+  if (blocks == 0) return AVR_OK;
   const size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
   const bool stats = L.samples_out != nullptr;
 #define AVR_LAUNCH(STATS, ONLY)                                                                 \
   hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \
                      lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,      \
                      L.n_tables, L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces,              \
-                     L.run_rects_dev, L.run_blocks_dev, tiles_x, tiles_y, L.supertile_order_dev, \
+                     L.run_rects_dev, L.run_blocks_dev, tiles_x, tiles_y, L.items_dev,           \
                      L.out_layers, L.samples_out)
   if (L.only_mode == kPow2Multiply) {
     if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
@@ -995,9 +1103,18 @@ int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream_v)
 int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
   const int64_t n = L.piece_end - L.piece_begin;
   if (n <= 0) return AVR_OK;
-  hipLaunchKernelGGL(fold_plan_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+  const int first_row = static_cast<int>(L.piece_begin / L.width);
+  const int last_row = static_cast<int>((L.piece_end - 1) / L.width);
+  const int chunks_per_row = (L.width + 255) / 256;
+  const int64_t blocks = static_cast<int64_t>(last_row - first_row + 1) * chunks_per_row;
+  if (blocks > 0x7fffffffLL) {
+    set_error("fold_plan_kernel: image too large");
+    return AVR_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL(fold_plan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_v), L.width, L.piece_begin, L.piece_end,
-                     L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.recv, L.out_piece, L.out_rgb8);
+                     L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.recv, L.out_piece, L.out_rgb8,
+                     first_row, chunks_per_row);
   return check_launch("fold_plan_kernel");
 }
 

@@ -82,11 +82,12 @@ class FrameRenderer:
         self.scalar_range = tuple(scalar_range)
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
-        # Second context = second HIP stream: frame i's exchange, fold and gather run there while
-        # frame i+1 is classified and marched on ctx.stream (frames are independent).
+        # Three HIP streams, frames are independent: frame i+1 is classified on
+        # classify_ctx.stream while frame i is marched on ctx.stream (the march's tail leaves CUs
+        # idle that the bandwidth-bound classify pass fills) and frame i-1 is exchanged, folded
+        # and gathered on comm_ctx.stream.  Two classified volumes and two send buffers rotate.
         self.comm_ctx = runtime.Context(ctx.device_index)
-        # (Running the classify pass of frame i+1 on a third stream beside frame i's march was
-        # measured and gains nothing: the two kernels just share the CUs -- DESIGN.md section 3.)
+        self.classify_ctx = runtime.Context(ctx.device_index)
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
         if n_local != len(self.local_boxes):
@@ -102,6 +103,10 @@ class FrameRenderer:
                                                  bounds.max_corner)
         self._send: List[Optional[torch.Tensor]] = [None, None]   # double-buffered send layout
         self._send_free: List[Optional[torch.cuda.Event]] = [None, None]
+        self._classified_free: List[Optional[torch.cuda.Event]] = [None, None]
+        # when a list, paint() appends (classify_begin, classify_end, march_begin, march_end)
+        # timing events of every frame (bench.py's live kernel durations)
+        self.kernel_events: Optional[list] = None
         self._frame = 0
         self.last_plan: Optional[FramePlan] = None
 
@@ -121,14 +126,35 @@ class FrameRenderer:
     # -- one frame ------------------------------------------------------------------------------
     def paint(self, plan: FramePlan, samples: Optional[torch.Tensor] = None,
               slot: int = 0) -> torch.Tensor:
-        """Classify + march of this rank's runs into the sparse send buffer `slot`."""
+        """Classify (classify_ctx.stream) + march (ctx.stream) of this rank's runs into the sparse
+        send buffer `slot`; classified volume `slot` carries the table indices between them."""
         need = max(plan.send_floats, 1)
         if self._send[slot] is None or self._send[slot].numel() < need:
             self._send[slot] = self.ctx.empty(need)
-        return self.scene.render_plan(plan, out=self._send[slot], samples=samples,
-                                      sync_streams=False)
+        ctx, cls = self.ctx, self.classify_ctx
+        timed = self.kernel_events is not None
+        if self._classified_free[slot] is not None:
+            cls.stream.wait_event(self._classified_free[slot])  # the frame before last read it
+        if timed:
+            c0 = torch.cuda.Event(enable_timing=True)
+            c0.record(cls.stream)
+        self.scene.classify_plan(cls, plan, slot)
+        classified = torch.cuda.Event(enable_timing=timed)
+        classified.record(cls.stream)
+        ctx.stream.wait_event(classified)
+        if timed:
+            m0 = torch.cuda.Event(enable_timing=True)
+            m0.record(ctx.stream)
+        self.scene.march_plan(ctx, plan, slot, self._send[slot], samples)
+        marched = torch.cuda.Event(enable_timing=timed)
+        marched.record(ctx.stream)
+        self._classified_free[slot] = marched
+        if timed:
+            self.kernel_events.append((c0, classified, m0, marched))
+        return self._send[slot]
 
     def synchronize(self) -> None:
+        self.classify_ctx.synchronize()
         self.ctx.synchronize()
         self.comm_ctx.synchronize()
 
@@ -147,6 +173,7 @@ class FrameRenderer:
         slot = self._frame & 1
         self._frame += 1
         ctx.join()  # cell data / earlier torch work on the caller's stream
+        self.classify_ctx.join()
         if self._send_free[slot] is not None:
             # the frame before last read this send buffer on the other stream
             ctx.stream.wait_event(self._send_free[slot])

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Plays each rank of an N-rank frame on ONE GPU without the collectives: plan -> paint ->
+fold (over a receive buffer of empty pixels of the planned size).  Reports, per rank, the GPU
+time of the paint and fold stages, the bytes the rank would send / receive, and the host time of
+one pipelined frame.  An estimate tool for ownership policies -- not a bench line."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from amrvolumerenderer_amd import runtime, scenes
+from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters, build_scene_on_device
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="config4")
+ap.add_argument("--ranks", type=int, default=8)
+ap.add_argument("--ownership", default="morton")
+ap.add_argument("--size", type=int, default=2048)
+ap.add_argument("--frames", type=int, default=20)
+ap.add_argument("--only-rank", type=int, default=-1)
+ap.add_argument("--transparency", type=float, default=0.97)
+ap.add_argument("--pipeline", type=int, default=0,
+                help="also time this many unsynchronised frames (the renderer's three-stream "
+                     "pipeline without the collectives)")
+args = ap.parse_args()
+
+spec = getattr(scenes, args.config)("smooth")
+scenes.assign_owners(spec, args.ranks, args.ownership)
+cam = scenes.default_camera()
+p = RenderParameters(args.size, args.size, args.transparency, 1, draw_bounds=False)
+print(f"{args.config} {args.ranks} ranks, ownership {args.ownership}, {args.size}^2")
+worst = 0.0
+for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
+    ctx = runtime.Context(0)
+    all_boxes, local = build_scene_on_device(ctx, spec, rank)
+    r = FrameRenderer(ctx, all_boxes, local, spec.transform, spec.bounds, spec.scalar_range, rank,
+                      args.ranks, None)
+    params, _ = r.make_params(p)
+    plan = r.plan(params, cam)
+    recv = torch.zeros(max(plan.recv_floats, 5), device=ctx.device).view(-1, 5)
+    recv[:, 4] = float("inf")
+    recv = recv.reshape(-1)
+    counter = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    r.paint(plan, counter, 0)
+    ctx.synchronize()
+    samples = int(counter.item())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_paint = t_fold = 0.0
+    host = 0.0
+    for it in range(args.frames + 3):
+        if it == 3:
+            t_paint = t_fold = host = 0.0
+        t0 = time.perf_counter()
+        plan = r.plan(params, cam)
+        with torch.cuda.stream(ctx.stream):
+            ev[0].record(ctx.stream)
+            send = r.paint(plan, None, it & 1)
+            ev[1].record(ctx.stream)
+            piece, rgb = ctx.fold_plan(plan, recv, True, sync_streams=False)
+            ev[2].record(ctx.stream)
+        host += time.perf_counter() - t0
+        ctx.synchronize()
+        t_paint += ev[0].elapsed_time(ev[1])
+        t_fold += ev[1].elapsed_time(ev[2])
+        last = plan
+    n = args.frames
+    worst = max(worst, t_paint / n)
+    print(f"rank {rank}: boxes {len(local):3d} paint {t_paint / n:6.3f} ms  fold {t_fold / n:6.3f} ms  "
+          f"send {last.send_floats * 4 / 1e6:6.2f} MB recv {last.recv_floats * 4 / 1e6:6.2f} MB  "
+          f"runs {len(last.runs())}  host {1e3 * host / n:6.3f} ms  samples {samples / 1e6:7.1f} M")
+    if args.pipeline:
+        F = args.pipeline
+        comm = r.comm_ctx
+
+        def two_streams():
+            free = [None, None]
+            for it in range(F):
+                plan = r.plan(params, cam)
+                slot = it & 1
+                if free[slot] is not None:
+                    ctx.stream.wait_event(free[slot])
+                with torch.cuda.stream(ctx.stream):
+                    send = r.paint(plan, None, slot)
+                    done = torch.cuda.Event()
+                    done.record(ctx.stream)
+                with torch.cuda.stream(comm.stream):
+                    comm.stream.wait_event(done)
+                    comm.fold_plan(plan, recv, True, sync_streams=False)
+                    free[slot] = torch.cuda.Event()
+                    free[slot].record(comm.stream)
+
+        for name, fn in (("3 streams", two_streams),):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / F
+            print(f"    pipelined, {name:15s}: {1e3 * dt:6.3f} ms / frame")
+    del r, local, all_boxes, recv
+    torch.cuda.empty_cache()
+print(f"slowest paint {worst:.3f} ms")
