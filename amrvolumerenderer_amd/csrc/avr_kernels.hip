@@ -124,9 +124,16 @@ __device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_
   //   = i + (i>>3)*120  +  j*8 + (j>>2)*(bx*128 - 32)  +  k*32 + (k>>2)*(by*bx*128 - 128)
   // with row_pitch = bx*128 - 32 and plane_pitch = by*bx*128 - 128, both < 2^24 (host check),
   // so every product is a 24-bit multiply (full-rate v_mad_u32_u24).
-  uint32_t offset = __umul24(static_cast<uint32_t>(i) >> 3, 120u) + static_cast<uint32_t>(i);
-  offset += __umul24(static_cast<uint32_t>(j) >> 2, row_pitch) + (static_cast<uint32_t>(j) << 3);
-  offset += __umul24(static_cast<uint32_t>(k) >> 2, plane_pitch) + (static_cast<uint32_t>(k) << 5);
+  // Three shifts, two shift-adds and three 24-bit multiply-adds (the compiler otherwise splits
+  // the multiply-adds into v_mul_u32_u24 + v_add3_u32: ten instructions instead of eight).
+  const uint32_t ui = static_cast<uint32_t>(i), uj = static_cast<uint32_t>(j),
+                 uk = static_cast<uint32_t>(k);
+  uint32_t offset;
+  asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(offset) : "v"(uj), "v"(ui));
+  asm("v_lshl_add_u32 %0, %1, 5, %0" : "+v"(offset) : "v"(uk));
+  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(ui >> 3), "v"(120u));
+  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(uj >> 2), "s"(row_pitch));
+  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(uk >> 2), "s"(plane_pitch));
   return offset;
 }
 

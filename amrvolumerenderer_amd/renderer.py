@@ -172,15 +172,13 @@ class FrameRenderer:
         ctx, comm = self.ctx, self.comm_ctx
         slot = self._frame & 1
         self._frame += 1
-        ctx.join()  # cell data / earlier torch work on the caller's stream
+        # cell data / earlier torch work on the caller's stream is read by the classify pass only
         self.classify_ctx.join()
         if self._send_free[slot] is not None:
             # the frame before last read this send buffer on the other stream
             ctx.stream.wait_event(self._send_free[slot])
-        with torch.cuda.stream(ctx.stream):
-            send = self.paint(plan, samples, slot)
-            painted = torch.cuda.Event()
-            painted.record(ctx.stream)
+        send = self.paint(plan, samples, slot)
+        painted = self._classified_free[slot]  # recorded on ctx.stream after the march
         with torch.cuda.stream(comm.stream):
             comm.stream.wait_event(painted)
             # 8-bit conversion is per pixel, so without antialiasing it is done on each rank's
@@ -193,7 +191,7 @@ class FrameRenderer:
                 # pixels are independent: each rank overlays its own piece (and converts it)
                 piece_rgb8 = comm.bbox_overlay(
                     piece.reshape(-1), *self.tight_bounds, camera, 1, p.width, p.height,
-                    plan.piece_begin, plan.piece_end, want_rgb8=True)
+                    plan.piece_begin, plan.piece_end, want_rgb8=True, sync_streams=False)
             released = torch.cuda.Event()
             released.record(comm.stream)
             self._send_free[slot] = released
@@ -213,7 +211,7 @@ class FrameRenderer:
                     image = comm.downsample(full.reshape(-1), p.width, p.height, root)
                     if p.draw_bounds:
                         comm.bbox_overlay(image.reshape(-1), *self.tight_bounds, camera, 1,
-                                          p.width, p.height)
+                                          p.width, p.height, sync_streams=False)
                     rgb8 = comm.quantize_rgb8(image.reshape(-1), p.width, p.height)
         return image, rgb8
 

@@ -311,7 +311,7 @@ class Context:
     def bbox_overlay(self, image: torch.Tensor, bounds_min, bounds_max,
                      camera: CameraParameters, sqrt_antialiasing: int, width: int, height: int,
                      pixel_begin: int = 0, pixel_end: Optional[int] = None,
-                     want_rgb8: bool = False) -> Optional[torch.Tensor]:
+                     want_rgb8: bool = False, sync_streams: bool = True) -> Optional[torch.Tensor]:
         """avr_bbox_overlay: the wireframe of the bounds blended in place over the pixels
         [pixel_begin, pixel_end) held by `image` (renderBoundingBoxLayer,
         VolumeRenderer.cpp:139-335); optionally also returns those pixels as RGB8."""
@@ -323,12 +323,14 @@ class Context:
         bmax = (C.c_double * 3)(*map(float, bounds_max))
         ccam = camera.to_c()
         rgb8 = self.empty(pixel_end - pixel_begin, 3, dtype=torch.uint8) if want_rgb8 else None
-        self.join()
+        if sync_streams:
+            self.join()
         _capi.check(_capi.lib().avr_bbox_overlay(
             self._handle, bmin, bmax, C.byref(ccam), int(sqrt_antialiasing), width, height,
             pixel_begin, pixel_end, C.c_void_p(image.data_ptr()),
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None))
-        self.publish()
+        if sync_streams:
+            self.publish()
         return rgb8
 
     def quantize_rgb8(self, src: torch.Tensor, w: int, h: int) -> torch.Tensor:
