@@ -134,6 +134,12 @@ SIGNATURES = {
     "avr_classify_plan": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_visibility_graph_create": (C.c_int, [C.POINTER(Box), C.POINTER(C.c_int32), C.c_int,
+                                               C.c_int, C.POINTER(_vp)]),
+    "avr_visibility_graph_destroy": (None, [_vp]),
+    "avr_visibility_order": (C.c_int, [_vp, C.POINTER(Camera), C.c_float, C.c_int, C.c_char_p,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]),
     "avr_tight_bounds": (C.c_int, [C.POINTER(Box), C.c_int, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),

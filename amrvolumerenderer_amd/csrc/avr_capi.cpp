@@ -656,6 +656,45 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
   });
 }
 
+int avr_visibility_graph_create(const avr_box* all_boxes, const int32_t* owner, int n_boxes,
+                                int n_ranks, avr_visibility_graph** out_graph) {
+  return guarded([&]() -> int {
+    require(out_graph != nullptr, "null out_graph");
+    *out_graph = nullptr;
+    require(n_ranks >= 1, "n_ranks must be positive");
+    require(n_boxes >= 0 && (n_boxes == 0 || (all_boxes != nullptr && owner != nullptr)),
+            "invalid box list");
+    for (int b = 0; b < n_boxes; ++b) {
+      require(owner[b] >= 0 && owner[b] < n_ranks, "box owner out of range");
+    }
+    *out_graph = avr::visibility_graph_create(all_boxes, owner, n_boxes, n_ranks);
+    return AVR_OK;
+  });
+}
+
+void avr_visibility_graph_destroy(avr_visibility_graph* graph) {
+  avr::visibility_graph_destroy(graph);
+}
+
+int avr_visibility_order(avr_visibility_graph* graph, const avr_camera* camera, float aspect,
+                         int use_visibility_graph, const char* dot_prefix,
+                         int32_t* rank_order_out, int* succeeded_out, int* n_splits_out) {
+  return guarded([&]() -> int {
+    require(graph != nullptr && camera != nullptr && rank_order_out != nullptr, "null argument");
+    if (succeeded_out != nullptr) *succeeded_out = 1;
+    if (n_splits_out != nullptr) *n_splits_out = 0;
+    if (!use_visibility_graph) {
+      const int n = avr::visibility_rank_count(graph);
+      for (int r = 0; r < n; ++r) rank_order_out[r] = r;
+      return AVR_OK;
+    }
+    const bool ok = avr::visibility_order(graph, *camera, aspect, dot_prefix, rank_order_out,
+                                          n_splits_out);
+    if (succeeded_out != nullptr) *succeeded_out = ok ? 1 : 0;
+    return AVR_OK;
+  });
+}
+
 int avr_tight_bounds(const avr_box* all_boxes, int n_boxes, const double fallback_min[3],
                      const double fallback_max[3], double out_min[3], double out_max[3]) {
   return guarded([&]() -> int {

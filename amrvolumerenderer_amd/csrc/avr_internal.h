@@ -212,6 +212,28 @@ void tight_bounds(const avr_box* boxes, int n_boxes, const double fallback_min[3
 int launch_overlay(const OverlayPlan& plan, int width, int64_t pixel_begin, int64_t pixel_end,
                    float* image, uint8_t* rgb8, void* stream);
 
+// ---- visibility ordering (avr_visibility.cpp) -----------------------------------------------
+struct VisBox {
+  float lo[3], hi[3];
+  int owner;
+  float min_depth, max_depth;
+};
+struct VisPair {
+  int i, j, axis;
+  int b_below_a;  // 0: a.max == b.min on `axis` (a below b); 1: b.max == a.min
+};
+void visibility_pairs(const std::vector<VisBox>& boxes, std::vector<VisPair>* pairs);
+}  // namespace avr
+struct avr_visibility_graph;
+namespace avr {
+avr_visibility_graph* visibility_graph_create(const avr_box* all_boxes, const int32_t* owner,
+                                              int n_boxes, int n_ranks);
+void visibility_graph_destroy(avr_visibility_graph* graph);
+int visibility_rank_count(const avr_visibility_graph* graph);
+// Fills rank_order[n_ranks]; returns false (and the default order) when the graph ordering fails.
+bool visibility_order(avr_visibility_graph* graph, const avr_camera& camera, float aspect,
+                      const char* dot_prefix, int32_t* rank_order, int* n_splits);
+
 void set_error(const std::string& message);
 
 }  // namespace avr

@@ -44,6 +44,7 @@ class RenderParameters:
     # (VolumeRenderer.cpp:1311-1314).  SURVEY.md 8(d)'s frames/s metric times paint + composite +
     # gather + downsample + quantise, so the bench switches it off.
     draw_bounds: bool = True
+    write_visibility_graph: bool = False
 
 
 def validate_render_parameters(p: RenderParameters) -> int:
@@ -98,6 +99,8 @@ class FrameRenderer:
         # coarsest min spacing over all ranks == MPI_Allreduce(MAX) of VolumeRenderer.cpp:1166
         self.reference_sample_distance = runtime.reference_sample_distance(
             self.all_boxes, bounds.min_corner, bounds.max_corner)
+        # rank order of the compositing group (VolumeRenderer.cpp:1235-1241); trivial for one rank
+        self.visibility = runtime.VisibilityGraph(self.all_boxes, n_ranks) if n_ranks > 1 else None
         # computeTightBounds (:791-848): the MPI min/max over all ranks' boxes == over all_boxes
         self.tight_bounds = runtime.tight_bounds(self.all_boxes, bounds.min_corner,
                                                  bounds.max_corner)
@@ -167,6 +170,12 @@ class FrameRenderer:
         (None, None).  The results are produced on comm_ctx.stream: call synchronize() (or order
         your stream after it) before reading them."""
         params, root = self.make_params(p)
+        if group_order is None and self.visibility is not None:
+            # aspect as VolumeRenderer.cpp:1114 computes it (float division of the image size)
+            aspect = float(np.float32(p.width) / np.float32(max(p.height, 1)))
+            group_order = self.visibility.order(
+                camera, aspect, p.use_visibility_graph,
+                "visibility_graph_" if (p.write_visibility_graph and self.rank == 0) else None)
         plan = self.plan(params, camera, group_order)
         self.last_plan = plan
         ctx, comm = self.ctx, self.comm_ctx

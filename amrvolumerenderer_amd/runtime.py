@@ -64,6 +64,48 @@ def reference_sample_distance(boxes: Sequence[AmrBox], bounds_min, bounds_max) -
     return out.value
 
 
+class VisibilityGraph:
+    """avr_visibility_graph: the rank order of the compositing group for a camera
+    (BuildVisibilityOrderedGroup, Common/VisibilityOrdering.cpp:63-632) over the replicated box
+    metadata.  Host only."""
+
+    def __init__(self, all_boxes: Sequence[AmrBox], n_ranks: int):
+        self.n_ranks = int(n_ranks)
+        arr = (_capi.Box * max(len(all_boxes), 1))(*[b.to_c() for b in all_boxes])
+        owners = (C.c_int32 * max(len(all_boxes), 1))(*[int(b.owner) for b in all_boxes])
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_visibility_graph_create(arr, owners, len(all_boxes),
+                                                            self.n_ranks, C.byref(handle)))
+        self._handle = handle
+        self.last_succeeded = True
+        self.last_splits = 0
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _capi.lib().avr_visibility_graph_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def order(self, camera: CameraParameters, aspect: float, use_visibility_graph: bool = True,
+              dot_prefix: Optional[str] = None) -> List[int]:
+        """The ranks in group order.  A failed ordering returns the default order and clears
+        last_succeeded (the reference warns once and continues)."""
+        out = (C.c_int32 * self.n_ranks)()
+        ok, splits = C.c_int(1), C.c_int(0)
+        ccam = camera.to_c()
+        _capi.check(_capi.lib().avr_visibility_order(
+            self._handle, C.byref(ccam), C.c_float(aspect), int(bool(use_visibility_graph)),
+            dot_prefix.encode() if dot_prefix else None, out, C.byref(ok), C.byref(splits)))
+        self.last_succeeded = bool(ok.value)
+        self.last_splits = int(splits.value)
+        return list(out)
+
+
 def tight_bounds(boxes: Sequence[AmrBox], fallback_min, fallback_max):
     """computeTightBounds (VolumeRenderer/VolumeRenderer.cpp:791-848) over replicated metadata."""
     arr = (_capi.Box * max(len(boxes), 1))(*[b.to_c() for b in boxes])

@@ -302,6 +302,34 @@ int avr_downsample_depthsort(avr_context *ctx, const float *src, int target_w, i
 int avr_quantize_rgb8(avr_context *ctx, const float *src, int w, int h, int stride,
                       uint8_t *dst);
 
+/* ---- visibility ordering ------------------------------------------------ */
+
+/* BuildVisibilityOrderedGroup (Common/VisibilityOrdering.cpp:63-632; called from
+ * VolumeRenderer/VolumeRenderer.cpp:1235-1241): the order of the ranks in the MPI group handed to
+ * Compositor::compose, from a topological sort of the face-adjacency graph of all boxes oriented
+ * by the view direction (cycles are broken by splitting a box).  Host only.
+ *
+ * The graph object holds the replicated box metadata (what the reference allgathers every
+ * frame: corners as floats and owners, rank-major) and the camera-independent list of
+ * face-adjacent pairs.  owner[b] = owning rank of all_boxes[b]; the relative order of a rank's
+ * boxes is their localBoxes order. */
+typedef struct avr_visibility_graph avr_visibility_graph;
+int avr_visibility_graph_create(const avr_box *all_boxes, const int32_t *owner, int n_boxes,
+                                int n_ranks, avr_visibility_graph **out_graph);
+void avr_visibility_graph_destroy(avr_visibility_graph *graph);
+
+/* rank_order_out[n_ranks] = rank at each position of the ordered group.
+ * use_visibility_graph == 0 or a failed ordering yields the default order 0..n-1
+ * (*succeeded_out = 0 on failure, where the reference prints its warning).  aspect = width /
+ * height as float (VolumeRenderer.cpp:1114).  dot_prefix (may be NULL): every graph iteration is
+ * also written to "<dot_prefix><counter>.dot" in the reference's format
+ * (writeVisibilityGraph, VisibilityOrdering.cpp:318-350; the reference's prefix is
+ * "visibility_graph_", written by rank 0).  n_splits_out (may be NULL): boxes split to break
+ * cycles. */
+int avr_visibility_order(avr_visibility_graph *graph, const avr_camera *camera, float aspect,
+                         int use_visibility_graph, const char *dot_prefix,
+                         int32_t *rank_order_out, int *succeeded_out, int *n_splits_out);
+
 /* ---- wireframe overlay ------------------------------------------------- */
 
 /* computeTightBounds (VolumeRenderer/VolumeRenderer.cpp:791-848) over the (replicated) box
