@@ -119,9 +119,13 @@ class DirectSendCompositor:
     (runtime.Context on a GPU; the CPU tests plug in a stand-in built on the oracle);
     `process_group` is a torch.distributed group (RCCL "nccl" backend on GPUs)."""
 
-    def __init__(self, ops, process_group=None, stage_through_host: bool = False):
+    def __init__(self, ops, process_group=None, stage_through_host: bool = False,
+                 force_collectives: bool = False):
         self.ops = ops
         self.process_group = process_group
+        # issue the all-to-all and the gather even for a single rank (a one-rank RCCL group on
+        # one GPU exercises the real collective path: tests/test_distributed_gpu.py)
+        self.force_collectives = force_collectives
         # rehearsal mode: a gloo group with device tensors (several ranks sharing one GPU);
         # collectives then run on host copies.  Never used with the RCCL backend.
         self.stage_through_host = stage_through_host
@@ -130,7 +134,7 @@ class DirectSendCompositor:
         """One all-to-all: block for peer s -> rank s."""
         import torch
         import torch.distributed as dist
-        if plan.n_ranks == 1:
+        if plan.n_ranks == 1 and not self.force_collectives:
             return send_buffer
         if self.stage_through_host:
             host_recv = torch.empty(max(plan.recv_floats, 1), dtype=send_buffer.dtype)
@@ -159,7 +163,7 @@ class DirectSendCompositor:
         [piece_len, C] (the float image or its RGB8 bytes)."""
         import torch
         import torch.distributed as dist
-        if plan.n_ranks == 1:
+        if plan.n_ranks == 1 and not self.force_collectives:
             return piece
         if self.stage_through_host and piece.device.type != "cpu":
             device = piece.device
@@ -172,6 +176,20 @@ class DirectSendCompositor:
         from . import runtime
         ranges = [runtime.piece_range(plan.n_pixels, k, plan.n_ranks) for k in range(plan.n_ranks)]
         max_len = max(e - b for b, e in ranges)
+        if all(e - b == max_len for b, e in ranges):
+            # equal pieces (the image size is a multiple of the rank count): every rank's piece
+            # is received straight into its place in the full image
+            if plan.rank != dst:
+                dist.gather(piece, None, dst=dst, group=self.process_group)
+                return None
+            full = torch.empty((plan.n_pixels,) + tuple(piece.shape[1:]), dtype=piece.dtype,
+                               device=piece.device)
+            parts = []
+            for r in range(plan.n_ranks):
+                b, e = ranges[plan.piece_of_rank[r]]
+                parts.append(full[b:e])
+            dist.gather(piece, parts, dst=dst, group=self.process_group)
+            return full
         padded = piece
         if piece.shape[0] != max_len:  # equal-size gather; only the last piece can be longer
             padded = torch.zeros((max_len,) + tuple(piece.shape[1:]), dtype=piece.dtype,

@@ -72,7 +72,7 @@ class FrameRenderer:
                  local_boxes: Sequence[AmrBox], transform: ScalarTransform,
                  bounds: VolumeBounds, scalar_range=(0.0, 1.0), rank: int = 0,
                  n_ranks: int = 1, process_group=None, color_map=None,
-                 stage_through_host: bool = False):
+                 stage_through_host: bool = False, force_collectives: bool = False):
         self.ctx = ctx
         self.rank = rank
         self.n_ranks = n_ranks
@@ -89,7 +89,8 @@ class FrameRenderer:
         # and gathered on comm_ctx.stream.  Two classified volumes and two send buffers rotate.
         self.comm_ctx = runtime.Context(ctx.device_index)
         self.classify_ctx = runtime.Context(ctx.device_index)
-        self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host)
+        self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host,
+                                               force_collectives)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
         if n_local != len(self.local_boxes):
             raise ValueError("local_boxes does not match the ownership of all_boxes")

@@ -79,3 +79,62 @@ def test_three_ranks_on_one_gpu(tmp_path, policy, antialiasing):
     ok, ok8 = out.read_text().split()
     assert ok == "1", "rank 0's frame differs from the oracle's 3-rank compose"
     assert ok8 == "1", "RGB8 bytes differ"
+
+
+def _rccl_worker(rank, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from oracle import oracle as O
+        from amrvolumerenderer_amd import runtime, scenes
+        from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+        from helpers import device_box
+        from test_frame_plan import oracle_overlay, painted_scene
+
+        results = []
+        for antialiasing, (w, h) in ((1, (120, 72)), (4, (60, 36)), (1, (75, 43))):
+            root = int(round(antialiasing ** 0.5))
+            spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+            cam = scenes.orbit_camera(5)
+            cells, layers, hints, ref = painted_scene(O, spec, cam, w * root, h * root, 0.85)
+            ctx = runtime.Context(0)
+            meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+            local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level)
+                     for c, m in zip(cells, spec.boxes)]
+            renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds,
+                                     spec.scalar_range, 0, 1, dist.group.WORLD,
+                                     force_collectives=True)
+            frames = [renderer.render(RenderParameters(w, h, 0.85, antialiasing), cam,
+                                      want_image=True) for _ in range(3)]  # pipelined burst
+            renderer.synchronize()
+            want, _, _ = O.compose_layered(layers, hints, [0] * len(layers),
+                                           np.arange(len(layers)), 1)
+            if root > 1:
+                want = O.downsample(want, w, h, root).reshape(-1, 5)
+            want = oracle_overlay(O, spec, cells, cam, want, w, h)
+            for image, rgb8 in frames:
+                results.append(np.array_equal(image.cpu().numpy().reshape(-1, 5).view(np.uint32),
+                                              want.view(np.uint32)))
+                results.append(np.array_equal(rgb8.cpu().numpy(), O.quantize_rgb8(want, w, h)))
+        t = torch.ones(1, device="cuda:0")
+        dist.all_reduce(t)
+        dist.barrier()
+        with open(out_path, "w") as fh:
+            fh.write(" ".join(str(int(r)) for r in results))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_with_one_rank(tmp_path):
+    """The RCCL code path itself (all_to_all_single with split lists, gather of uint8 and float
+    pieces into views, three streams, process-group stream ordering) on a one-rank "nccl" group:
+    the only RCCL configuration a one-GPU box can run."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_rccl_worker, args=(_free_port(), str(out)), nprocs=1, join=True)
+    flags = out.read_text().split()
+    assert flags and all(f == "1" for f in flags), flags
