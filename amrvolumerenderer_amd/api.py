@@ -49,6 +49,7 @@ class SceneGeometry:
     scalar_transform: ScalarTransform
     bounds: VolumeBounds
     scalar_range: Tuple[float, float] = (0.0, 1.0)
+    processed_scalar_range: Optional[Tuple[float, float]] = None   # after log scaling, if any
 
 
 def build_scene_geometry(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
@@ -59,7 +60,7 @@ def build_scene_geometry(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence
     one streaming pass over the local cells (min, max, min positive, finite count), the
     MIN / MAX / SUM reductions over ranks (:327-344, :368-385) and the scalar transform.
     The geometric part (world corners, global rescale, padded bounds) needs amrex::Geometry and
-    is the caller's: boxes arrive with their corners."""
+    is plotfile.load_plotfile_geometry's: boxes arrive here with their corners."""
     import torch
     import torch.distributed as dist
     from . import runtime
@@ -74,9 +75,10 @@ def build_scene_geometry(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence
         dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=process_group)
         dist.all_reduce(count, op=dist.ReduceOp.SUM, group=process_group)
         lo, lo_pos, hi, finite = mins[0].item(), mins[1].item(), maxs[0].item(), int(count.item())
-    transform, _, scalar_range = runtime.scene_transform_from_stats(
+    transform, processed_range, scalar_range = runtime.scene_transform_from_stats(
         (lo, hi, lo_pos), finite, log_scale_input, normalize_to_data_range)
-    return SceneGeometry(list(all_boxes), list(local_boxes), transform, bounds, scalar_range)
+    return SceneGeometry(list(all_boxes), list(local_boxes), transform, bounds, scalar_range,
+                         processed_range)
 
 
 def compute_histogram(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
@@ -160,6 +162,16 @@ def validate_options(options: RenderOptions) -> None:
         cam = options.camera
         if not _finite(cam.eye) or not _finite(cam.look_at) or not _finite(cam.up):
             raise ValueError("camera vectors must be finite")
+        forward = [float(cam.look_at[a]) - float(cam.eye[a]) for a in range(3)]
+        if not math.sqrt(sum(v * v for v in forward)) > 0.0:
+            raise ValueError("camera eye and look-at must be distinct")
+        up = [float(v) for v in cam.up]
+        if not math.sqrt(sum(v * v for v in up)) > 0.0:
+            raise ValueError("camera up vector must be non-zero")
+        cross = (forward[1] * up[2] - forward[2] * up[1], forward[2] * up[0] - forward[0] * up[2],
+                 forward[0] * up[1] - forward[1] * up[0])
+        if not math.sqrt(sum(v * v for v in cross)) > 1e-6:
+            raise ValueError("camera up vector must not be parallel to the view direction")
         if not (0.0 < cam.fov_y_degrees < 180.0):
             raise ValueError("camera_fov_y must be in (0, 180) degrees")
         if not (cam.near_plane > 0.0 and cam.far_plane > cam.near_plane):
@@ -202,23 +214,127 @@ def save_png(rgb8, filename: str) -> bool:
     return True
 
 
+def _libm_float(name: str):
+    """float f(float) of the host libm (std::sin / cos / tan / log on a float argument)."""
+    import ctypes
+    import ctypes.util
+    lib = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    fn = getattr(lib, name)
+    fn.restype = ctypes.c_float
+    fn.argtypes = [ctypes.c_float]
+    return lambda x: fn(float(x))
+
+
+class _Mt19937:
+    """std::mt19937 (the 32-bit Mersenne Twister of the C++ standard, [rand.predef])."""
+
+    def __init__(self, seed: int):
+        self.state = [0] * 624
+        self.state[0] = seed & 0xFFFFFFFF
+        for i in range(1, 624):
+            prev = self.state[i - 1]
+            self.state[i] = (1812433253 * (prev ^ (prev >> 30)) + i) & 0xFFFFFFFF
+        self.index = 624
+
+    def __call__(self) -> int:
+        if self.index >= 624:
+            st = self.state
+            for i in range(624):
+                y = (st[i] & 0x80000000) | (st[(i + 1) % 624] & 0x7FFFFFFF)
+                st[i] = st[(i + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            self.index = 0
+        y = self.state[self.index]
+        self.index += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+
+def _uniform_float(rng: _Mt19937, a, b):
+    """libstdc++'s std::uniform_real_distribution<float>(a, b)(mt19937): generate_canonical
+    takes one 32-bit draw, converts it to float, divides by 2^32 and steps a result of 1.0 down
+    to the float below; then canonical * (b - a) + a, all in float."""
+    import numpy as np
+    f32 = np.float32
+    canonical = f32(f32(rng()) / f32(4294967296.0))
+    if canonical >= f32(1.0):
+        canonical = np.nextafter(f32(1.0), f32(0.0))
+    return f32(f32(canonical * f32(f32(b) - f32(a))) + f32(a))
+
+
+def automatic_camera(bounds: VolumeBounds, camera_seed: int = 91021,
+                     up_vector: Optional[Sequence[float]] = None) -> CameraParameters:
+    """The camera renderScene places when none is given (VolumeRenderer.cpp:974-1023): on a
+    sphere around the bounds' centre, azimuth and altitude drawn from std::mt19937(cameraSeed).
+    Float arithmetic and the host libm's sin / cos / tan as in the reference's host code."""
+    import numpy as np
+    f32 = np.float32
+    k_pi = f32(3.14159265358979323846)
+    k_two_pi = f32(f32(2.0) * k_pi)
+    # amrex::RealVect is double: 0.5f * (min + max) promotes to double
+    center = [0.5 * (bounds.min_corner[a] + bounds.max_corner[a]) for a in range(3)]
+    half = [0.5 * (bounds.max_corner[a] - bounds.min_corner[a]) for a in range(3)]
+    radius = f32(math.sqrt(half[0] * half[0] + half[1] * half[1] + half[2] * half[2]))
+    if radius <= f32(0.0):
+        radius = f32(1.0)
+    fov_y = f32(k_pi * f32(0.25))
+    max_altitude = f32(k_pi * f32(0.25))
+    half_fov = f32(fov_y * f32(0.5))
+    sinf, cosf, tanf = _libm_float("sinf"), _libm_float("cosf"), _libm_float("tanf")
+    min_distance = f32(radius / f32(tanf(half_fov))) if half_fov > 0 else radius
+    safety = max(f32(f32(0.25) * radius), f32(0.5))
+    distance = f32(min_distance + safety)
+    rng = _Mt19937(camera_seed)
+    azimuth = _uniform_float(rng, f32(0.0), k_two_pi)
+    altitude = _uniform_float(rng, -max_altitude, max_altitude)
+    cos_altitude, sin_altitude = f32(cosf(altitude)), f32(sinf(altitude))
+    sin_azimuth, cos_azimuth = f32(sinf(azimuth)), f32(cosf(azimuth))
+    eye = (center[0] + float(f32(f32(distance * cos_altitude) * sin_azimuth)),
+           center[1] + float(f32(distance * sin_altitude)),
+           center[2] + float(f32(f32(distance * cos_altitude) * cos_azimuth)))
+
+    def normalize(v):
+        length = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        if length > 0.0 and math.isfinite(length):
+            return (v[0] / length, v[1] / length, v[2] / length)
+        return (0.0, 0.0, -1.0)
+
+    def cross_length(a, b):
+        c = (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+        return math.sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2])
+
+    up = tuple(float(v) for v in up_vector) if up_vector is not None else (0.0, 1.0, 0.0)
+    view_dir = normalize(tuple(center[a] - eye[a] for a in range(3)))
+    if cross_length(view_dir, up) <= float(f32(1e-4)):
+        up = (0.0, 0.0, 1.0)
+        if cross_length(view_dir, up) <= float(f32(1e-4)):
+            up = (1.0, 0.0, 0.0)
+    up = normalize(up)
+    return CameraParameters(eye, tuple(center), up,
+                            float(f32(f32(fov_y * f32(180.0)) / k_pi)), float(f32(0.1)),
+                            float(f32(distance * f32(4.0))))
+
+
 def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 0,
                  n_ranks: int = 1, process_group=None) -> int:
-    """renderScene with an explicit camera (VolumeRenderer.cpp:1062-1101 -> renderSingleTrial):
-    paints, composites, gathers and writes the image on rank 0.  Returns 0 on success like the
-    reference."""
+    """renderScene (VolumeRenderer.cpp:947-1101 -> renderSingleTrial) with an explicit camera or
+    the automatic one: paints, composites, gathers and writes the image on rank 0.  Returns 0 on
+    success like the reference."""
     from .renderer import FrameRenderer, RenderParameters
     validate_options(options)
-    if options.camera is None:
-        raise ValueError("render_scene needs an explicit camera (automatic placement is part of "
-                         "the frame driver that is out of scope, VolumeRenderer.cpp:974-1023)")
+    camera = options.camera
+    if camera is None:
+        camera = automatic_camera(scene.bounds, up_vector=options.up_vector)
     extension = os.path.splitext(options.output_filename)[1].lower()
     renderer = FrameRenderer(ctx, scene.all_boxes, scene.local_boxes, scene.scalar_transform,
                              scene.bounds, scene.scalar_range, rank, n_ranks, process_group,
                              color_map=options.color_map)
-    _, rgb8 = renderer.render(RenderParameters(options.width, options.height,
-                                               options.box_transparency, options.antialiasing,
-                                               options.visibility_graph), options.camera)
+    _, rgb8 = renderer.render(
+        RenderParameters(options.width, options.height, options.box_transparency,
+                         options.antialiasing, options.visibility_graph,
+                         write_visibility_graph=options.write_visibility_graph), camera)
     renderer.synchronize()
     if rank == 0:
         # any other extension falls back to PPM (VolumeRenderer.cpp:1316-1327)
@@ -240,8 +356,9 @@ def render(plotfile: str, width: int = 512, height: int = 512, box_transparency:
            camera_near: Optional[float] = None, camera_far: Optional[float] = None,
            color_map: Optional[Sequence[Sequence[float]]] = None) -> int:
     """The reference's python entry (python/amrVolumeRenderer/module.cpp:275-303), same keyword
-    names and defaults.  Arguments are validated as the reference validates them; the plotfile
-    itself cannot be read yet (no AMReX plotfile reader in this round)."""
+    names and defaults: validates the arguments as the reference does, reads the plotfile
+    (plotfile.py), renders on cuda:0 and writes the image.  Multi-rank use: call run() with the
+    rank, world size and process group."""
     camera = None
     if camera_eye is not None or camera_look_at is not None:
         if camera_eye is None or camera_look_at is None:
@@ -270,7 +387,84 @@ def render(plotfile: str, width: int = 512, height: int = 512, box_transparency:
     from .renderer import validate_render_parameters, RenderParameters
     validate_render_parameters(RenderParameters(width, height, box_transparency, antialiasing))
     if not plotfile:
-        raise ValueError("plotfile path must not be empty")
-    raise NotImplementedError(
-        "reading AMReX plotfiles (VolumeRenderer.cpp:588-714) is outside this round's scope "
-        "(SURVEY.md 8(f-1)); build a SceneGeometry and call render_scene()")
+        raise RuntimeError("plotfile path is required")
+    if not os.path.exists(plotfile):
+        raise RuntimeError(f"plotfile path '{plotfile}' does not exist")
+    return run(plotfile, options, variable or "")
+
+
+def run(plotfile: str, options: RenderOptions, variable_name: str = "", ctx=None, rank: int = 0,
+        n_ranks: int = 1, process_group=None) -> int:
+    """VolumeRenderer::run(RunOptions) after its argument checks (VolumeRenderer.cpp:1469-1576):
+    load the plotfile, apply a scalar-range override and convert the colour map's physical
+    values to normalised ones, then renderScene."""
+    import numpy as np
+    from . import plotfile as pf
+    from . import runtime
+    f32 = np.float32
+    if ctx is None:
+        ctx = runtime.Context(0)
+    has_override = options.scalar_range is not None
+    scene = pf.load_plotfile_geometry(ctx, plotfile, variable_name, options.min_level,
+                                      options.max_level, options.log_scale_input,
+                                      not has_override, rank, n_ranks, process_group)
+    if scene.processed_scalar_range is None:
+        raise RuntimeError("Internal error: processed scalar range unavailable for color mapping.")
+    processed_min, processed_max = (f32(v) for v in scene.processed_scalar_range)
+    span = f32(processed_max - processed_min)
+    if not (span > 0.0) or not np.isfinite(span):
+        raise RuntimeError("Failed to establish a finite scalar range for color mapping.")
+    logf = _libm_float("logf")
+
+    def to_processed(physical) -> np.float32:
+        physical = f32(physical)
+        if not np.isfinite(physical):
+            raise ValueError("color_map scalar values must be finite.")
+        if options.log_scale_input:
+            if not (physical > 0.0):
+                raise ValueError("color_map scalar values must be positive when log scaling is "
+                                 "enabled.")
+            return f32(logf(physical))
+        return physical
+
+    norm_min, norm_max = processed_min, processed_max
+    if has_override:
+        norm_min = to_processed(options.scalar_range[0])
+        norm_max = to_processed(options.scalar_range[1])
+        if not (norm_min < norm_max):
+            raise ValueError("scalar_range must contain two values with min < max.")
+    norm_span = f32(norm_max - norm_min)
+    if not (norm_span > 0.0) or not np.isfinite(norm_span):
+        raise RuntimeError("Failed to establish a finite scalar range for color mapping.")
+    if has_override:
+        # SetSceneNormalizationRange (SceneBuilder.cpp:427-443), amrex::Real arithmetic
+        lo, hi = float(norm_min), float(norm_max)
+        transform = scene.scalar_transform
+        transform.normalize_to_unit_range = True
+        transform.normalization_min = lo
+        transform.inverse_normalization_span = 1.0 / (hi - lo)
+        scene.scalar_range = (0.0, 1.0)
+    if options.color_map is not None:
+        converted = []
+        for point in options.color_map:
+            value = f32(f32(to_processed(point.value) - norm_min) / norm_span)
+            if not np.isfinite(value):
+                raise ValueError("color_map produced a non-finite normalized scalar value.")
+            value = min(max(value, f32(0.0)), f32(1.0))
+            converted.append(ColorMapControlPoint(float(value), point.red, point.green,
+                                                  point.blue, point.alpha))
+        options = _replace(options, color_map=converted)
+    if options.camera is not None:
+        cam = options.camera
+        length = math.sqrt(sum(float(v) ** 2 for v in cam.up))
+        up = tuple(float(v) / length for v in cam.up) if (length > 0.0 and math.isfinite(length)) \
+            else (0.0, 0.0, -1.0)
+        options = _replace(options, camera=CameraParameters(cam.eye, cam.look_at, up,
+                                                            cam.fov_y_degrees, cam.near_plane,
+                                                            cam.far_plane))
+    return render_scene(ctx, scene, options, rank, n_ranks, process_group)
+
+
+def _replace(options: RenderOptions, **changes) -> RenderOptions:
+    import dataclasses
+    return dataclasses.replace(options, **changes)
