@@ -150,14 +150,24 @@ def validate_options(options: RenderOptions) -> None:
         lo, hi = options.scalar_range
         if not _finite((lo, hi)) or not (lo < hi):
             raise ValueError("scalar_range must contain two values with min < max.")
-    if options.color_map is not None:
-        if len(options.color_map) == 0:
-            raise ValueError("color_map must contain at least one control point")
+    if options.color_map is not None:  # validateColorMap (VolumeRendererApi.cpp:163-196)
+        if len(options.color_map) < 2:
+            raise ValueError("color map must provide at least two control points")
+        previous = -math.inf
         for p in options.color_map:
             vals = (p.value, p.red, p.green, p.blue, p.alpha) if isinstance(
                 p, ColorMapControlPoint) else tuple(p)
-            if len(vals) != 5 or not _finite(vals):
-                raise ValueError("color_map entries are finite (value, red, green, blue, alpha)")
+            if len(vals) != 5:
+                raise ValueError("color_map entries are (value, red, green, blue, alpha)")
+            if not math.isfinite(float(vals[0])):
+                raise ValueError("color map control point values must be finite")
+            if float(vals[0]) <= previous:
+                raise ValueError("color map control point values must be strictly increasing")
+            previous = float(vals[0])
+            for name, component in zip(("red", "green", "blue", "alpha"), vals[1:]):
+                if not math.isfinite(float(component)) or not (0.0 <= float(component) <= 1.0):
+                    raise ValueError(f"color map {name} components must be finite and within "
+                                     "[0, 1]")
     if options.camera is not None:
         cam = options.camera
         if not _finite(cam.eye) or not _finite(cam.look_at) or not _finite(cam.up):

@@ -82,13 +82,20 @@ def test_option_validation_matches_reference_errors():
 
 
 def test_python_render_kwargs_surface():
-    with pytest.raises(NotImplementedError):
-        api.render("plt00000", width=64, height=64, color_map=[(0.0, 0, 0, 1, 0.1)])
+    with pytest.raises(RuntimeError):   # the path does not exist (VolumeRenderer.cpp:1464-1467)
+        api.render("plt00000", width=64, height=64,
+                   color_map=[(0.0, 0, 0, 1, 0.1), (1.0, 1, 0, 0, 0.9)])
+    with pytest.raises(ValueError):      # a colour map needs two control points
+        api.render("plt00000", color_map=[(0.0, 0, 0, 1, 0.1)])
+    with pytest.raises(ValueError):      # strictly increasing values
+        api.render("plt00000", color_map=[(0.5, 0, 0, 1, 0.1), (0.5, 1, 0, 0, 0.9)])
+    with pytest.raises(ValueError):      # components within [0, 1]
+        api.render("plt00000", color_map=[(0.0, 0, 0, 1.5, 0.1), (1.0, 1, 0, 0, 0.9)])
     with pytest.raises(ValueError):
         api.render("plt00000", antialiasing=3)            # not a perfect square
     with pytest.raises(ValueError):
         api.render("plt00000", camera_eye=(0, 0, 1))       # eye without look_at
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError):   # "plotfile path is required" is a runtime_error
         api.render("", width=64)
     with pytest.raises(ValueError):
         api.render("plt00000", color_map=[(0.0, 1.0)])
