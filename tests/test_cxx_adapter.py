@@ -51,3 +51,36 @@ def test_adapter_single_rank_compose(O, avr_lib, tmp_path):
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     want, _, _ = O.compose_layered(layers, hints, [0] * len(layers), list(range(len(layers))), 1)
     assert_bit_equal(got, want, "C++ single-rank compose")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,policy", [(1, "morton"), (3, "morton"), (4, "round_robin")])
+def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, policy):
+    """The whole frame of INTEGRATION.md section 3 driven from C++ over the C ABI alone
+    (avr::RankFrame: visibility order, frame plan, classify + march, all-to-all as device copies,
+    fold, per-piece overlay + bytes): every rank of the frame is played in one process."""
+    import struct
+    from amrvolumerenderer_amd import scenes
+    from test_frame_plan import local_indices, oracle_overlay, painted_scene
+    subprocess.run(["make", "-C", CXX, "adapter_test"], check=True, stdout=subprocess.DEVNULL)
+    W, H, transparency = 96, 64, 0.8
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cam = scenes.default_camera()
+    cells, layers, hints, _ = painted_scene(O, spec, cam, W, H, transparency)
+    scenes.assign_owners(spec, n_ranks, policy)
+    owners = [b.owner for b in spec.boxes]
+    with open(tmp_path / "scene.bin", "wb") as fh:
+        fh.write(struct.pack("<i", len(cells)))
+        for c, b in zip(cells, spec.boxes):
+            fh.write(struct.pack("<6d", *b.min_corner, *b.max_corner))
+            fh.write(struct.pack("<4i", c.shape[2], c.shape[1], c.shape[0], b.owner))
+            fh.write(np.ascontiguousarray(c, dtype="<f8").tobytes())
+    subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
+                    str(transparency), str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin")],
+                   check=True)
+    want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
+    want = oracle_overlay(O, spec, cells, cam, want, W, H)
+    got = np.fromfile(tmp_path / "image.bin", dtype=np.float32)
+    assert_bit_equal(got, want, "C++ multi-rank frame")
+    got8 = np.fromfile(tmp_path / "rgb8.bin", dtype=np.uint8).reshape(H, W, 3)
+    assert np.array_equal(got8[::-1], O.quantize_rgb8(want, W, H))
