@@ -204,6 +204,7 @@ struct avr_context {
   avr::StagingRing staging;
   avr_scene scratch_scene;         // classified storage of avr_paint_box
   std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
+  int march_workgroups_per_cu = 0;             // 0 = uncapped
 };
 
 
@@ -317,6 +318,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
     launch.items_dev = staging.add(items.data(), items.size());
     launch.n_items = static_cast<uint32_t>(items.size());
+    launch.workgroups_per_cu = ctx->march_workgroups_per_cu;
     launch.only_mode = plan.boxes.empty() ? -1 : plan.boxes[0].index_mode;
     for (const avr::BoxDev& dev : plan.boxes) {
       if (dev.index_mode != launch.only_mode) launch.only_mode = -1;
@@ -374,6 +376,15 @@ int avr_context_set_stream(avr_context* ctx, void* hip_stream) {
     ctx->staging.drain();
     // NULL: back to the context's own stream (created on first use)
     ctx->stream = (hip_stream != nullptr) ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return AVR_OK;
+  });
+}
+
+int avr_context_set_march_occupancy(avr_context* ctx, int workgroups_per_cu) {
+  return guarded([&]() -> int {
+    require(ctx != nullptr, "null context");
+    require(workgroups_per_cu >= 0 && workgroups_per_cu <= 8, "workgroups_per_cu must be in [0, 8]");
+    ctx->march_workgroups_per_cu = (workgroups_per_cu == 8) ? 0 : workgroups_per_cu;
     return AVR_OK;
   });
 }

@@ -143,6 +143,7 @@ struct RenderLaunch {
   const MarchItemDev* items_dev;  // n_items entries (multiple of kXcds)
   uint32_t n_items;
   int only_mode;                        // the IndexMode shared by every box, or -1
+  int workgroups_per_cu;                // resident march workgroups per CU (0 = uncapped)
 };
 // classify pass (cells -> table indices) and march; the march reads what the classify pass of
 // the same frame wrote into `classified`

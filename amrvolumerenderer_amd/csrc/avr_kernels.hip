@@ -1031,7 +1031,13 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
   const int tiles_y = (L.consts.height + kTile - 1) / kTile;
   const unsigned blocks = L.n_items * kSuperTileTiles;
   if (blocks == 0) return AVR_OK;
-  const size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
+  size_t lds_bytes = static_cast<size_t>(L.n_tables) * kTableSize * sizeof(float4);
+  if (L.workgroups_per_cu > 0) {
+    // Occupancy cap through the LDS allocation: n workgroups of 160 KiB / n minus a share of the
+    // 10 KiB left for the co-resident kernel's own LDS (classify_kernel stages 2 KiB per workgroup).
+    const size_t share = (150 * 1024 / static_cast<size_t>(L.workgroups_per_cu)) & ~size_t{1023};
+    lds_bytes = std::max(lds_bytes, share);
+  }
   const bool stats = L.samples_out != nullptr;
 #define AVR_LAUNCH(STATS, ONLY)                                                                 \
   hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \

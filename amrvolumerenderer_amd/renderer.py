@@ -72,7 +72,8 @@ class FrameRenderer:
                  local_boxes: Sequence[AmrBox], transform: ScalarTransform,
                  bounds: VolumeBounds, scalar_range=(0.0, 1.0), rank: int = 0,
                  n_ranks: int = 1, process_group=None, color_map=None,
-                 stage_through_host: bool = False, force_collectives: bool = False):
+                 stage_through_host: bool = False, force_collectives: bool = False,
+                 march_workgroups_per_cu: Optional[int] = None):
         self.ctx = ctx
         self.rank = rank
         self.n_ranks = n_ranks
@@ -89,6 +90,14 @@ class FrameRenderer:
         # and gathered on comm_ctx.stream.  Two classified volumes and two send buffers rotate.
         self.comm_ctx = runtime.Context(ctx.device_index)
         self.classify_ctx = runtime.Context(ctx.device_index)
+        # With one rank the march leaves 3 of a CU's 8 workgroup slots (and some LDS) to the
+        # classify pass of the next frame, so that the VALU-bound and the HBM-bound kernel really
+        # share the CUs: config-4 frame 1.25 -> 1.12 ms.  A rank's share of an N-rank frame is many
+        # short runs whose tail, not their throughput, sets the time; there the cap costs
+        # (N = 4: 0.355 -> 0.387 ms, N = 8: 0.223 -> 0.237 ms; N = 2 neutral), so it is off.
+        if march_workgroups_per_cu is None:
+            march_workgroups_per_cu = 5 if n_ranks == 1 else 0
+        ctx.set_march_occupancy(march_workgroups_per_cu)
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host,
                                                force_collectives)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)

@@ -208,6 +208,11 @@ class Context:
     def synchronize(self) -> None:
         _capi.check(_capi.lib().avr_context_synchronize(self._handle))
 
+    def set_march_occupancy(self, workgroups_per_cu: int) -> None:
+        """avr_context_set_march_occupancy: resident march workgroups per CU (0 = uncapped)."""
+        _capi.check(_capi.lib().avr_context_set_march_occupancy(self._handle,
+                                                                int(workgroups_per_cu)))
+
     # -- helpers ----------------------------------------------------------------------------
     def _check_tensor(self, t: torch.Tensor, dtype, what: str) -> None:
         if not isinstance(t, torch.Tensor) or t.device != self.device:

@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the bounded cpu_baseline sample")
     ap.add_argument("--orbit", type=int, default=0, help="average over this many orbit views")
+    ap.add_argument("--march-occupancy", type=int, default=None,
+                    help="resident march workgroups per CU (0 = uncapped; default: 5 for one "
+                         "rank, uncapped otherwise); see DESIGN.md")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share cuda:0 and talk over gloo through host copies "
                          "(exercises the N>1 code path on a 1-GPU box; not a measurement)")
@@ -182,7 +185,8 @@ def main():
     torch.cuda.synchronize()
     renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
                              spec.scalar_range, rank, world, group,
-                             stage_through_host=args.rehearse_on_one_gpu)
+                             stage_through_host=args.rehearse_on_one_gpu,
+                             march_workgroups_per_cu=args.march_occupancy)
     rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
                                antialiasing=args.antialiasing,
                                draw_bounds=False)  # not part of the metric

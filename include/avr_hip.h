@@ -107,6 +107,14 @@ void avr_context_destroy(avr_context *ctx);
 int avr_context_set_stream(avr_context *ctx, void *hip_stream);
 int avr_context_synchronize(avr_context *ctx);
 
+/* Resident march workgroups per CU for the launches of this context: 0 (default) = as many as
+ * fit (8), 1..7 = capped (the launch reserves 160 KiB / n of LDS per workgroup).  A pipelined
+ * renderer that classifies the next frame on another stream while this context marches sets 5:
+ * the march is VALU-bound and the classify pass HBM-bound, and only when the march leaves wave
+ * slots and LDS free do the two kernels really share a CU ("Three streams").  Never
+ * changes results. */
+int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
+
 /* ---- host-side per-frame quantities (no device work) ------------------------------------- */
 
 /* buildColorTable (Common/VolumePainter.cpp:442-516): 256 RGBA entries to host memory. */

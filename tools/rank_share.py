@@ -22,6 +22,7 @@ ap.add_argument("--size", type=int, default=2048)
 ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--only-rank", type=int, default=-1)
 ap.add_argument("--transparency", type=float, default=0.97)
+ap.add_argument("--march-occupancy", type=int, default=None)
 ap.add_argument("--pipeline", type=int, default=0,
                 help="also time this many unsynchronised frames (the renderer's three-stream "
                      "pipeline without the collectives)")
@@ -37,7 +38,7 @@ for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
     ctx = runtime.Context(0)
     all_boxes, local = build_scene_on_device(ctx, spec, rank)
     r = FrameRenderer(ctx, all_boxes, local, spec.transform, spec.bounds, spec.scalar_range, rank,
-                      args.ranks, None)
+                      args.ranks, None, march_workgroups_per_cu=args.march_occupancy)
     params, _ = r.make_params(p)
     plan = r.plan(params, cam)
     recv = torch.zeros(max(plan.recv_floats, 5), device=ctx.device).view(-1, 5)
