@@ -6,19 +6,23 @@
 // forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 //
 // Kernels:
-//   render_runs_kernel  one thread per pixel; marches the rank's boxes in global layer order,
-//                       folds each same-owner run with the depth-sort blend in registers and
-//                       writes one layer per run in DirectSend "send layout".
+//   classify_kernel     streams every f64 cell of the frame's boxes once and stores its
+//                       transfer-function table index as a byte in 8x4x4 bricklets
+//                       (the per-cell part of VolumePainter.cpp:870-883)
+//   render_runs_kernel  one workgroup per (16x16-pixel tile, run), one thread per pixel: marches
+//                       the run's boxes in global layer order, folds them with the depth-sort
+//                       blend in registers and stores the run's layer in DirectSend "send layout"
 //                       (VolumePainter.cpp:735-955 + VolumeRenderer.cpp:1201-1219 +
 //                        DirectSendBase.cpp:413-426)
+//   fold_plan_kernel    receiver side: blends the received run blocks of a pixel piece in global
+//                       order, optional RGB8 (DirectSendBase.cpp:400-446, Color.hpp:66-91)
 //   blend_*             Features::blend of the three image types (element-wise)
-//   fold_runs_kernel    receiver-side left fold over runs (DirectSendBase.cpp:400-446)
+//   fold_runs_kernel    left fold over dense run layers
 //   downsample / quantize / encode / decode   frame tail
+//   upload_kernel       per-call descriptors, pinned host block -> HBM
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
-
 #include <cmath>
 #include <cstdint>
 
