@@ -73,7 +73,8 @@ class FrameRenderer:
                  bounds: VolumeBounds, scalar_range=(0.0, 1.0), rank: int = 0,
                  n_ranks: int = 1, process_group=None, color_map=None,
                  stage_through_host: bool = False, force_collectives: bool = False,
-                 march_workgroups_per_cu: Optional[int] = None):
+                 march_workgroups_per_cu: Optional[int] = None,
+                 stream_priorities: Sequence[int] = (-1, -1, 0)):
         self.ctx = ctx
         self.rank = rank
         self.n_ranks = n_ranks
@@ -85,11 +86,17 @@ class FrameRenderer:
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
         # Three HIP streams, frames are independent: frame i+1 is classified on
-        # classify_ctx.stream while frame i is marched on ctx.stream (the march's tail leaves CUs
+        # classify_ctx.stream while frame i is marched on march_ctx.stream (the march's tail leaves CUs
         # idle that the bandwidth-bound classify pass fills) and frame i-1 is exchanged, folded
         # and gathered on comm_ctx.stream.  Two classified volumes and two send buffers rotate.
-        self.comm_ctx = runtime.Context(ctx.device_index)
-        self.classify_ctx = runtime.Context(ctx.device_index)
+        # The march and the compositing streams are high-priority, the classify stream is not.
+        # What matters is that the two classes never share a hardware queue: HIP multiplexes
+        # its streams onto a few HSA queues in creation order, and when the classify and the
+        # march stream landed on the same queue the two kernels ran strictly one after the other
+        # (config-4 frame 1.40 ms instead of 1.12; measured with all three at default priority).
+        self.march_ctx = runtime.Context(ctx.device_index, priority=stream_priorities[0])
+        self.comm_ctx = runtime.Context(ctx.device_index, priority=stream_priorities[1])
+        self.classify_ctx = runtime.Context(ctx.device_index, priority=stream_priorities[2])
         # With one rank the march leaves 3 of a CU's 8 workgroup slots (and some LDS) to the
         # classify pass of the next frame, so that the VALU-bound and the HBM-bound kernel really
         # share the CUs: config-4 frame 1.25 -> 1.12 ms.  A rank's share of an N-rank frame is many
@@ -97,7 +104,7 @@ class FrameRenderer:
         # (N = 4: 0.355 -> 0.387 ms, N = 8: 0.223 -> 0.237 ms; N = 2 neutral), so it is off.
         if march_workgroups_per_cu is None:
             march_workgroups_per_cu = 5 if n_ranks == 1 else 0
-        ctx.set_march_occupancy(march_workgroups_per_cu)
+        self.march_ctx.set_march_occupancy(march_workgroups_per_cu)
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host,
                                                force_collectives)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
@@ -139,12 +146,12 @@ class FrameRenderer:
     # -- one frame ------------------------------------------------------------------------------
     def paint(self, plan: FramePlan, samples: Optional[torch.Tensor] = None,
               slot: int = 0) -> torch.Tensor:
-        """Classify (classify_ctx.stream) + march (ctx.stream) of this rank's runs into the sparse
+        """Classify (classify_ctx.stream) + march (march_ctx.stream) of this rank's runs into the sparse
         send buffer `slot`; classified volume `slot` carries the table indices between them."""
         need = max(plan.send_floats, 1)
         if self._send[slot] is None or self._send[slot].numel() < need:
             self._send[slot] = self.ctx.empty(need)
-        ctx, cls = self.ctx, self.classify_ctx
+        ctx, cls = self.march_ctx, self.classify_ctx
         timed = self.kernel_events is not None
         if self._classified_free[slot] is not None:
             cls.stream.wait_event(self._classified_free[slot])  # the frame before last read it
@@ -168,7 +175,7 @@ class FrameRenderer:
 
     def synchronize(self) -> None:
         self.classify_ctx.synchronize()
-        self.ctx.synchronize()
+        self.march_ctx.synchronize()
         self.comm_ctx.synchronize()
 
     def render(self, p: RenderParameters, camera: CameraParameters,
@@ -188,7 +195,7 @@ class FrameRenderer:
                 "visibility_graph_" if (p.write_visibility_graph and self.rank == 0) else None)
         plan = self.plan(params, camera, group_order)
         self.last_plan = plan
-        ctx, comm = self.ctx, self.comm_ctx
+        ctx, comm = self.march_ctx, self.comm_ctx
         slot = self._frame & 1
         self._frame += 1
         # cell data / earlier torch work on the caller's stream is read by the classify pass only

@@ -172,7 +172,9 @@ class Context:
     """One rendering context per rank (= per GPU).  Owns a HIP stream (a torch stream, so
     torch allocations / collectives can be ordered against the kernels)."""
 
-    def __init__(self, device: Optional[int] = None):
+    def __init__(self, device: Optional[int] = None, priority: int = 0):
+        """priority: 0 = default, -1 = high (torch.cuda.Stream's convention): work queued on a
+        high-priority stream is dispatched before work of default streams."""
         if not torch.cuda.is_available():
             raise _capi.AvrNoDevice("no HIP device visible to PyTorch; the renderer has no CPU "
                                     "fallback")
@@ -181,7 +183,7 @@ class Context:
         handle = C.c_void_p()
         _capi.check(_capi.lib().avr_context_create(self.device_index, C.byref(handle)))
         self._handle = handle
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = torch.cuda.Stream(device=self.device, priority=priority)
         _capi.check(_capi.lib().avr_context_set_stream(self._handle,
                                                        C.c_void_p(self.stream.cuda_stream)))
 

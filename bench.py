@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the bounded cpu_baseline sample")
     ap.add_argument("--orbit", type=int, default=0, help="average over this many orbit views")
+    ap.add_argument("--priorities", default="-1,-1,0",
+                    help="HIP stream priorities of the march, compositing and classify streams")
     ap.add_argument("--march-occupancy", type=int, default=None,
                     help="resident march workgroups per CU (0 = uncapped; default: 5 for one "
                          "rank, uncapped otherwise); see DESIGN.md")
@@ -186,7 +188,8 @@ def main():
     renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
                              spec.scalar_range, rank, world, group,
                              stage_through_host=args.rehearse_on_one_gpu,
-                             march_workgroups_per_cu=args.march_occupancy)
+                             march_workgroups_per_cu=args.march_occupancy,
+                             stream_priorities=tuple(int(v) for v in args.priorities.split(",")))
     rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
                                antialiasing=args.antialiasing,
                                draw_bounds=False)  # not part of the metric
@@ -223,11 +226,11 @@ def main():
 
     # ---- timed region: EXACTLY `steps` frames ----------------------------------------------
     # the two paint kernels' own durations are taken with HIP events on the streams they are
-    # launched on (classify on classify_ctx.stream, march on ctx.stream)
+    # launched on (classify on classify_ctx.stream, march on march_ctx.stream)
     params, _ = renderer.make_params(rparams)
     renderer.kernel_events = []
     epoch = torch.cuda.Event(enable_timing=True)
-    epoch.record(ctx.stream)
+    epoch.record(renderer.march_ctx.stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):

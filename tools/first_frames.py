@@ -13,7 +13,7 @@ cam = scenes.default_camera()
 torch.cuda.synchronize()
 for trial in range(3):
     r.kernel_events = []
-    ref = torch.cuda.Event(enable_timing=True); ref.record(ctx.stream)
+    ref = torch.cuda.Event(enable_timing=True); ref.record(r.march_ctx.stream)
     t0 = time.perf_counter()
     hostt = []
     for i in range(12):

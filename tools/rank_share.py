@@ -23,6 +23,7 @@ ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--only-rank", type=int, default=-1)
 ap.add_argument("--transparency", type=float, default=0.97)
 ap.add_argument("--march-occupancy", type=int, default=None)
+ap.add_argument("--priorities", default="-1,-1,0", help="march,comm,classify stream priorities")
 ap.add_argument("--pipeline", type=int, default=0,
                 help="also time this many unsynchronised frames (the renderer's three-stream "
                      "pipeline without the collectives)")
@@ -38,7 +39,9 @@ for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
     ctx = runtime.Context(0)
     all_boxes, local = build_scene_on_device(ctx, spec, rank)
     r = FrameRenderer(ctx, all_boxes, local, spec.transform, spec.bounds, spec.scalar_range, rank,
-                      args.ranks, None, march_workgroups_per_cu=args.march_occupancy)
+                      args.ranks, None, march_workgroups_per_cu=args.march_occupancy,
+                      stream_priorities=tuple(int(v) for v in args.priorities.split(",")))
+    mctx = r.march_ctx
     params, _ = r.make_params(p)
     plan = r.plan(params, cam)
     recv = torch.zeros(max(plan.recv_floats, 5), device=ctx.device).view(-1, 5)
@@ -46,7 +49,7 @@ for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
     recv = recv.reshape(-1)
     counter = torch.zeros(1, dtype=torch.int64, device=ctx.device)
     r.paint(plan, counter, 0)
-    ctx.synchronize()
+    r.synchronize()
     samples = int(counter.item())
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t_paint = t_fold = 0.0
@@ -56,14 +59,14 @@ for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
             t_paint = t_fold = host = 0.0
         t0 = time.perf_counter()
         plan = r.plan(params, cam)
-        with torch.cuda.stream(ctx.stream):
-            ev[0].record(ctx.stream)
+        with torch.cuda.stream(mctx.stream):
+            ev[0].record(r.classify_ctx.stream)
             send = r.paint(plan, None, it & 1)
-            ev[1].record(ctx.stream)
-            piece, rgb = ctx.fold_plan(plan, recv, True, sync_streams=False)
-            ev[2].record(ctx.stream)
+            ev[1].record(mctx.stream)
+            piece, rgb = mctx.fold_plan(plan, recv, True, sync_streams=False)
+            ev[2].record(mctx.stream)
         host += time.perf_counter() - t0
-        ctx.synchronize()
+        r.synchronize()
         t_paint += ev[0].elapsed_time(ev[1])
         t_fold += ev[1].elapsed_time(ev[2])
         last = plan
@@ -82,11 +85,11 @@ for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
                 plan = r.plan(params, cam)
                 slot = it & 1
                 if free[slot] is not None:
-                    ctx.stream.wait_event(free[slot])
-                with torch.cuda.stream(ctx.stream):
+                    mctx.stream.wait_event(free[slot])
+                with torch.cuda.stream(mctx.stream):
                     send = r.paint(plan, None, slot)
                     done = torch.cuda.Event()
-                    done.record(ctx.stream)
+                    done.record(mctx.stream)
                 with torch.cuda.stream(comm.stream):
                     comm.stream.wait_event(done)
                     comm.fold_plan(plan, recv, True, sync_streams=False)
