@@ -17,12 +17,16 @@ from test_frame_plan import local_indices, oracle_overlay, painted_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_ranks,policy,size,transparency", [
-    (1, "morton", (96, 64), 0.9), (2, "morton", (75, 43), 0.8), (4, "round_robin", (75, 43), 0.8),
-    (8, "morton", (128, 128), 0.0), (3, "block", (50, 70), 0.97)])
-def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency):
+@pytest.mark.parametrize("n_ranks,policy,size,transparency,scene_shape", [
+    (1, "morton", (96, 64), 0.9, (32, 2, 8)), (2, "morton", (75, 43), 0.8, (32, 2, 8)),
+    (4, "round_robin", (75, 43), 0.8, (32, 2, 8)), (8, "morton", (128, 128), 0.0, (32, 2, 8)),
+    (3, "block", (50, 70), 0.97, (32, 2, 8)),
+    # 960 boxes dealt round-robin: several hundred runs (the fold scans its run list in chunks
+    # of 256) and many (tile, run) march items per rank
+    (6, "round_robin", (64, 48), 0.9, (32, 2, 4))])
+def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency, scene_shape):
     W, H = size
-    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    spec = scenes.make_amr_scene(*scene_shape, "smooth")
     cam = scenes.default_camera()
     cells, layers, hints, ref = painted_scene(O, spec, cam, W, H, transparency)
     scenes.assign_owners(spec, n_ranks, policy)
@@ -51,6 +55,8 @@ def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency):
         plans.append(plan)
         sends.append(send)
 
+    if scene_shape[2] == 4:
+        assert plans[0].n_runs_total > 256
     recvs = PH.route(plans, sends)
     got = np.zeros((W * H, 5), np.float32)
     got8 = np.zeros((W * H, 3), np.uint8)
