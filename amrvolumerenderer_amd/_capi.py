@@ -118,6 +118,8 @@ SIGNATURES = {
                                  C.POINTER(PaintParams), C.POINTER(Camera), _vp, _vp]),
     "avr_scene_create": (C.c_int, [_vp, C.POINTER(Box), C.c_int, C.POINTER(ScalarTransform),
                                     C.POINTER(_vp)]),
+    "avr_scene_set_classification_cache": (C.c_int, [_vp, C.c_int]),
+    "avr_scene_invalidate": (C.c_int, [_vp]),
     "avr_scene_destroy": (None, [_vp]),
     "avr_render_runs": (C.c_int, [_vp, _vp, C.POINTER(PaintParams), C.POINTER(Camera), _ip,
                                    C.c_int, _ip, C.c_int, C.c_int, _vp, _vp]),

@@ -178,6 +178,10 @@ struct avr_scene {
   void* classified[2] = {nullptr, nullptr};
   size_t classified_capacity[2] = {0, 0};
   int device = 0;
+  // optional re-use of a slot's classified volume across frames (avr_scene_set_classification_cache):
+  // what the classify pass of the slot's current contents depended on
+  bool cache_classification = false;
+  std::vector<uint64_t> classified_key[2];
 
   ~avr_scene() {
     for (void* buffer : classified) {
@@ -190,6 +194,7 @@ struct avr_scene {
       if (classified[slot] != nullptr) (void)hipFree(classified[slot]);
       classified[slot] = nullptr;
       classified_capacity[slot] = 0;
+      classified_key[slot].clear();
       avr::hip_check(hipMalloc(&classified[slot], bytes), "hipMalloc(classified)");
       classified_capacity[slot] = bytes;
     }
@@ -272,6 +277,39 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   launch.n_boxes = n_boxes;
   launch.n_classify_tiles = plan.classify_tile_begin.back();
   launch.classified = scene->classified_slot(slot, plan.classified_bytes, ctx->stream);
+
+  if ((phases & kClassify) && scene->cache_classification) {
+    // everything classify_kernel reads besides the cells themselves
+    std::vector<uint64_t> key;
+    auto bits = [](double v) {
+      uint64_t u;
+      std::memcpy(&u, &v, sizeof(u));
+      return u;
+    };
+    const avr::FrameConsts& fc = plan.consts;
+    key.reserve(12 + plan.boxes.size() * 4);
+    for (double v : {static_cast<double>(fc.range_min), static_cast<double>(fc.inverse_range),
+                     static_cast<double>(fc.clip_start), fc.positive_floor, fc.norm_min,
+                     fc.inv_norm_span}) {
+      key.push_back(bits(v));
+    }
+    key.push_back(static_cast<uint64_t>(fc.apply_clip) | (static_cast<uint64_t>(fc.log_scale) << 8) |
+                  (static_cast<uint64_t>(fc.normalize) << 16));
+    for (const avr::BoxDev& dev : plan.boxes) {
+      key.push_back(reinterpret_cast<uint64_t>(dev.cells));
+      key.push_back((static_cast<uint64_t>(static_cast<uint32_t>(dev.jstride)) << 32) |
+                    static_cast<uint32_t>(dev.kstride));
+      key.push_back((static_cast<uint64_t>(dev.nx) << 42) | (static_cast<uint64_t>(dev.ny) << 21) |
+                    static_cast<uint64_t>(dev.nz));
+      key.push_back(dev.cls_offset);
+    }
+    if (key == scene->classified_key[slot]) {
+      phases &= ~kClassify;  // the slot already holds exactly this classification
+      if (phases == 0) return AVR_OK;
+    } else {
+      scene->classified_key[slot] = std::move(key);
+    }
+  }
 
   std::vector<avr::MarchItemDev>& items = ctx->march_items;  // scratch, reused across frames
   size_t bytes = plan.boxes.size() * sizeof(avr::BoxDev);
@@ -624,6 +662,23 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                   plan->info.n_local_runs, plan->info.n_ranks, plan->local_rects, plan->send_blocks,
                   const_cast<avr_scene*>(scene), slot, send_buffer, samples_out,
                   &const_cast<avr_frame_plan*>(plan)->prologue);
+  });
+}
+
+int avr_scene_set_classification_cache(avr_scene* scene, int enabled) {
+  return guarded([&]() -> int {
+    require(scene != nullptr, "null scene");
+    scene->cache_classification = enabled != 0;
+    for (auto& key : scene->classified_key) key.clear();
+    return AVR_OK;
+  });
+}
+
+int avr_scene_invalidate(avr_scene* scene) {
+  return guarded([&]() -> int {
+    require(scene != nullptr, "null scene");
+    for (auto& key : scene->classified_key) key.clear();
+    return AVR_OK;
   });
 }
 

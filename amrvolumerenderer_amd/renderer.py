@@ -74,7 +74,8 @@ class FrameRenderer:
                  n_ranks: int = 1, process_group=None, color_map=None,
                  stage_through_host: bool = False, force_collectives: bool = False,
                  march_workgroups_per_cu: Optional[int] = None,
-                 stream_priorities: Sequence[int] = (-1, -1, 0)):
+                 stream_priorities: Sequence[int] = (-1, -1, 0),
+                 cache_classification: bool = False):
         self.ctx = ctx
         self.rank = rank
         self.n_ranks = n_ranks
@@ -85,6 +86,10 @@ class FrameRenderer:
         self.scalar_range = tuple(scalar_range)
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
+        # Off by default: every frame re-reads the f64 cells like the reference.  On: a camera
+        # moving over static data only pays for the march (call scene.invalidate() after changing
+        # cells in place).
+        self.scene.set_classification_cache(cache_classification)
         # Three HIP streams, frames are independent: frame i+1 is classified on
         # classify_ctx.stream while frame i is marched on march_ctx.stream (the march's tail leaves CUs
         # idle that the bandwidth-bound classify pass fills) and frame i-1 is exchanged, folded
@@ -103,7 +108,7 @@ class FrameRenderer:
         # short runs whose tail, not their throughput, sets the time; there the cap costs
         # (N = 4: 0.355 -> 0.387 ms, N = 8: 0.223 -> 0.237 ms; N = 2 neutral), so it is off.
         if march_workgroups_per_cu is None:
-            march_workgroups_per_cu = 5 if n_ranks == 1 else 0
+            march_workgroups_per_cu = 5 if (n_ranks == 1 and not cache_classification) else 0
         self.march_ctx.set_march_occupancy(march_workgroups_per_cu)
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host,
                                                force_collectives)

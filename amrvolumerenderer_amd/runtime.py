@@ -424,6 +424,15 @@ class Scene:
         self.ctx.publish()
         return counts
 
+    def set_classification_cache(self, enabled: bool) -> None:
+        """avr_scene_set_classification_cache: keep classified volumes across frames while the
+        boxes, the scalar transform and the scalar range are unchanged (off by default)."""
+        _capi.check(_capi.lib().avr_scene_set_classification_cache(self._handle, int(bool(enabled))))
+
+    def invalidate(self) -> None:
+        """avr_scene_invalidate: the cells were changed in place."""
+        _capi.check(_capi.lib().avr_scene_invalidate(self._handle))
+
     def classify_plan(self, ctx: "Context", plan, slot: int) -> None:
         """avr_classify_plan on `ctx`'s stream: cells -> table indices into classified volume
         `slot`.  No stream ordering is added here; the caller orders it against the march."""

@@ -161,6 +161,15 @@ int avr_scene_create(avr_context *ctx, const avr_box *boxes, int n_boxes,
                      const avr_scalar_transform *transform, avr_scene **out_scene);
 void avr_scene_destroy(avr_scene *scene);
 
+/* Off by default: every frame's classify pass re-reads the f64 cells, as the reference's
+ * per-sample fetch does.  When enabled, a classified volume is kept across frames for as long as
+ * what it was derived from is unchanged -- the boxes (cell pointers, strides, dimensions), the
+ * scalar transform and the scalar range -- so that a camera moving over a static data set only
+ * pays for the march.  The cells are the caller's memory: after changing them in place call
+ * avr_scene_invalidate.  Results are identical either way. */
+int avr_scene_set_classification_cache(avr_scene *scene, int enabled);
+int avr_scene_invalidate(avr_scene *scene);
+
 /* Fused replacement of the per-box loop + owner-side run fold
  * (VolumeRenderer.cpp:1201-1219 + DirectSendBase.cpp:413-426): first a streaming classify pass
  * turns every f64 cell of the scene into its transfer-function table index (the per-sample

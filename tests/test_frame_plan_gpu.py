@@ -157,3 +157,50 @@ def test_two_phase_plan_calls_equal_the_fused_call(ctx):
         scene.march_plan(ctx, plan2, slot, out)
         ctx.synchronize()
         assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+
+
+def test_classification_cache_is_exact_and_invalidates(O, ctx):
+    """avr_scene_set_classification_cache: cached frames equal uncached ones bit for bit, a
+    changed scalar range re-classifies, and cells changed in place need invalidate()."""
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    p = RenderParameters(96, 64, 0.7, 1)
+
+    def frames(renderer, cams):
+        out = []
+        for cam in cams:
+            image, rgb8 = renderer.render(p, cam, want_image=True)
+            renderer.synchronize()
+            out.append((image.cpu().numpy().view(np.uint32).copy(), rgb8.cpu().numpy().copy()))
+        return out
+
+    cams = [scenes.orbit_camera(v) for v in range(5)]
+    plain = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+    cached = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
+                           cache_classification=True)
+    want = frames(plain, cams)
+    got = frames(cached, cams)
+    for (a, a8), (b, b8) in zip(want, got):
+        assert np.array_equal(a, b) and np.array_equal(a8, b8)
+    # another scalar range changes the table indices: the key differs, no stale re-use
+    wide = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, (-0.5, 1.5))
+    cached.scalar_range = (-0.5, 1.5)
+    for (a, a8), (b, b8) in zip(frames(wide, cams[:2]), frames(cached, cams[:2])):
+        assert np.array_equal(a, b) and np.array_equal(a8, b8)
+    cached.scalar_range = spec.scalar_range
+    # cells changed in place: stale until invalidate()
+    before = frames(cached, cams[:2])   # both classified slots now hold the original cells
+    local[0].values.mul_(0.25)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    stale = frames(cached, cams[:2])
+    assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(before, stale))
+    cached.scene.invalidate()
+    fresh = frames(cached, cams[:2])
+    truth = frames(FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range),
+                   cams[:2])
+    assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(truth, fresh))
+    assert not all(np.array_equal(a, b) for (a, _), (b, _) in zip(before, fresh))
