@@ -278,3 +278,18 @@ def test_render_plotfile_end_to_end(O, ctx, tmp_path, mode):
     else:
         assert np.array_equal(got, want8)
     assert want8.any()
+
+
+@pytest.mark.gpu
+def test_example_script_runs(tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "render_plotfile.py")
+    out = tmp_path / "frame.png"
+    subprocess.run([sys.executable, script, "--size", "64", "--output", str(out)], check=True,
+                   cwd=tmp_path)
+    assert out.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    subprocess.run([sys.executable, script, "--size", "48", "--orbit", "3", "--output",
+                    str(tmp_path / "orbit.ppm")], check=True, cwd=tmp_path)
+    assert all((tmp_path / f"orbit_{v:03d}.ppm").exists() for v in range(3))
