@@ -149,10 +149,13 @@ class DirectSendCompositor:
         return recv
 
     def compose(self, plan: FramePlan, send_buffer, want_rgb8: bool = False,
-                on_ops_stream: bool = False):
-        """Returns (piece [piece_len, 5], rgb8 [piece_len, 3] or None).  on_ops_stream: the
-        caller already made the ops' stream current (no extra stream ordering needed)."""
+                on_ops_stream: bool = False, want_piece: bool = True):
+        """Returns (piece [piece_len, 5] or None, rgb8 [piece_len, 3] or None).  on_ops_stream:
+        the caller already made the ops' stream current (no extra stream ordering needed)."""
         recv = self.exchange(plan, send_buffer)
+        if not want_piece:  # only the bytes are wanted (the ops skip the 20 B/pixel float store)
+            return self.ops.fold_plan(plan, recv, want_rgb8, sync_streams=not on_ops_stream,
+                                      want_piece=False)
         if on_ops_stream:
             return self.ops.fold_plan(plan, recv, want_rgb8, sync_streams=False)
         return self.ops.fold_plan(plan, recv, want_rgb8)

@@ -701,7 +701,7 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
                   float* out_piece, uint8_t* out_rgb8) {
   return guarded([&]() -> int {
     bind_device(ctx);
-    require(plan != nullptr && out_piece != nullptr, "null argument");
+    require(plan != nullptr && (out_piece != nullptr || out_rgb8 != nullptr), "null argument");
     require(plan->info.recv_floats == 0 || recv_buffer != nullptr, "null receive buffer");
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
     avr::FoldLaunch launch;

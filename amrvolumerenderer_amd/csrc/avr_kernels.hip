@@ -922,12 +922,14 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
   }
   if (!live) return;
   const int64_t q = p - piece_begin;
-  float* d = out_piece + q * 5;
-  d[0] = acc.r;
-  d[1] = acc.g;
-  d[2] = acc.b;
-  d[3] = acc.a;
-  d[4] = acc.d;
+  if (out_piece != nullptr) {
+    float* d = out_piece + q * 5;
+    d[0] = acc.r;
+    d[1] = acc.g;
+    d[2] = acc.b;
+    d[3] = acc.a;
+    d[4] = acc.d;
+  }
   if (out_rgb8 != nullptr) {
     uint8_t* b = out_rgb8 + q * 3;
     b[0] = static_cast<uint8_t>(component_as_byte(acc.r));

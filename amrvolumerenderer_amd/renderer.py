@@ -216,8 +216,10 @@ class FrameRenderer:
             # piece before the gather (3 bytes per pixel on the wire instead of 20)
             early_rgb8 = (root == 1)
             overlay_piece = early_rgb8 and p.draw_bounds
+            bytes_only = early_rgb8 and not overlay_piece and not want_image
             piece, piece_rgb8 = self.compositor.compose(
-                plan, send, want_rgb8=early_rgb8 and not overlay_piece, on_ops_stream=True)
+                plan, send, want_rgb8=early_rgb8 and not overlay_piece, on_ops_stream=True,
+                want_piece=not bytes_only)
             if overlay_piece:
                 # pixels are independent: each rank overlays its own piece (and converts it)
                 piece_rgb8 = comm.bbox_overlay(

@@ -273,7 +273,8 @@ int avr_march_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_pla
  * the runs in global order from the received buffer (recv_floats floats; with one rank the send
  * buffer itself) into out_piece[(piece_end - piece_begin) * 5]; pixels no run covers become the
  * cleared layer pixel (DirectSendBase.cpp:450-455).  If out_rgb8 is non-NULL the piece is also
- * written as RGB8 (Color::GetComponentAsByte, 3 bytes per pixel, same pixel order). */
+ * written as RGB8 (Color::GetComponentAsByte, 3 bytes per pixel, same pixel order); out_piece
+ * may then be NULL when only the bytes are wanted (20 of the 23 bytes stored per pixel). */
 int avr_fold_plan(avr_context *ctx, const avr_frame_plan *plan, const float *recv_buffer,
                   float *out_piece, uint8_t *out_rgb8);
 
