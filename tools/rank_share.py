@@ -23,6 +23,7 @@ ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--only-rank", type=int, default=-1)
 ap.add_argument("--transparency", type=float, default=0.97)
 ap.add_argument("--march-occupancy", type=int, default=None)
+ap.add_argument("--no-join", action="store_true", help="experiment: skip the caller-stream join")
 ap.add_argument("--priorities", default="-1,-1,0", help="march,comm,classify stream priorities")
 ap.add_argument("--pipeline", type=int, default=0,
                 help="also time this many unsynchronised frames (the renderer's three-stream "
@@ -76,34 +77,35 @@ for rank in (range(args.ranks) if args.only_rank < 0 else [args.only_rank]):
           f"send {last.send_floats * 4 / 1e6:6.2f} MB recv {last.recv_floats * 4 / 1e6:6.2f} MB  "
           f"runs {len(last.runs())}  host {1e3 * host / n:6.3f} ms  samples {samples / 1e6:7.1f} M")
     if args.pipeline:
+        # the renderer's own frame loop with the collectives stubbed out: the exchange hands back
+        # a receive buffer of the planned size, the gather nothing
         F = args.pipeline
-        comm = r.comm_ctx
+        stubs = {}
 
-        def two_streams():
-            free = [None, None]
-            for it in range(F):
-                plan = r.plan(params, cam)
-                slot = it & 1
-                if free[slot] is not None:
-                    mctx.stream.wait_event(free[slot])
-                with torch.cuda.stream(mctx.stream):
-                    send = r.paint(plan, None, slot)
-                    done = torch.cuda.Event()
-                    done.record(mctx.stream)
-                with torch.cuda.stream(comm.stream):
-                    comm.stream.wait_event(done)
-                    comm.fold_plan(plan, recv, True, sync_streams=False)
-                    free[slot] = torch.cuda.Event()
-                    free[slot].record(comm.stream)
+        def planned_receive(plan, send):
+            n = max(plan.recv_floats, 5)
+            if n not in stubs:
+                buf = torch.zeros(n, device=ctx.device).view(-1, 5)
+                buf[:, 4] = float("inf")
+                stubs[n] = buf.reshape(-1)
+            return stubs[n]
 
-        for name, fn in (("3 streams", two_streams),):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fn()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / F
-            print(f"    pipelined, {name:15s}: {1e3 * dt:6.3f} ms / frame")
+        r.compositor.exchange = planned_receive
+        if args.no_join:
+            r.classify_ctx.join = lambda: None
+        r.compositor.gather = lambda plan, piece, dst=0: None
+        for _ in range(20):
+            r.render(p, cam)
+        r.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(F):
+            r.render(p, cam)
+        host = time.perf_counter() - t0
+        r.synchronize()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / F
+        print(f"    pipelined, 3 streams      : {1e3 * dt:6.3f} ms / frame (host {1e3 * host / F:.3f} ms)")
     del r, local, all_boxes, recv
     torch.cuda.empty_cache()
 print(f"slowest paint {worst:.3f} ms")
