@@ -88,7 +88,7 @@ def test_camera_placements(O, ctx, cam):
     compare_box(O, ctx, radial(24, 24, 24), (0, 0, 0), (1, 1, 1), cam, 80, 64)
 
 
-@pytest.mark.parametrize("transparency", [0.0, 0.15, 0.97])
+@pytest.mark.parametrize("transparency", [0.0, 0.15, 0.97, 1.0])
 @pytest.mark.parametrize("ref_scale", [1.0, 2.0, 4.0])
 def test_transparency_and_level_factor(O, ctx, transparency, ref_scale):
     # ref_scale 2, 4 -> normalizationFactor 0.5, 0.25 (finer AMR levels)
