@@ -8,7 +8,16 @@
  * restates.  All "float" arithmetic is IEEE binary32 evaluated in source order with no FMA
  * contraction (build with -ffp-contract=off, no -march=native, no -ffast-math).
  *
- * Pin status: see oracle/README.md ("Pinning").
+ * Pin status (details in oracle/README.md, "Pinning"):
+ *   pinned by the reference's own fixtures (Common/Testing/ImageFullTest.cpp): the float and
+ *     ubyte over-blends, orc_blend_regions;
+ *   pinned by properties measured on the reference: orc_compose_layered,
+ *     orc_layer_order, orc_piece_range;
+ *   PARITY UNPINNED (the reference holds no test or vector): orc_paint_box,
+ *     orc_build_color_table, orc_box_sampling, orc_blend_depthsort, orc_box_depth_hint,
+ *     orc_reference_sample_distance, orc_downsample, orc_quantize_rgb8, and the SURVEY 8(f)
+ *     functions (orc_scalar_stats, orc_scene_transform, orc_histogram, orc_tight_bounds,
+ *     orc_bbox_overlay).
  */
 #ifndef AVR_ORACLE_H
 #define AVR_ORACLE_H

@@ -2,6 +2,10 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
 the product package amrvolumerenderer_amd never does.
+
+Pin status: the over-blends and region logic are pinned by the reference's own fixtures, the
+layered compose by properties measured on the reference; the painter (K1), colour table and
+the SURVEY 8(f) functions are PARITY UNPINNED (avr_oracle.h, oracle/README.md).
 """
 from __future__ import annotations
 
