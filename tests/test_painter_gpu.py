@@ -77,6 +77,18 @@ def test_strided_view_with_ghost_cells(O, ctx):
                 96, 96, cells_view=(storage, sl))
 
 
+@pytest.mark.parametrize("sl", [
+    (slice(0, 12), slice(0, 15), slice(0, 17)),   # odd nx on 16-byte aligned rows: the classify
+    (slice(2, 9), slice(1, 14), slice(4, 21)),    # pass's paired loads end on a single cell
+    (slice(0, 5), slice(0, 3), slice(0, 1)),      # one cell per row
+    (slice(0, 16), slice(0, 16), slice(1, 17))])  # rows 8-byte aligned only: unpaired loads
+def test_classify_row_tails_and_alignment(O, ctx, sl):
+    storage = np.random.default_rng(11).random((16, 16, 24))
+    cells = np.ascontiguousarray(storage[sl])
+    compare_box(O, ctx, cells, (0.2, 0.1, 0.3), (0.9, 0.8, 0.85), scenes.default_camera(),
+                80, 64, cells_view=(storage, sl))
+
+
 @pytest.mark.parametrize("cam", [
     CameraParameters((0.5, 0.5, 0.5), (0.9, 0.6, 0.1), (0, 1, 0), 60.0),       # eye inside the box
     CameraParameters((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0, 1, 0), 30.0),       # axis aligned (dir ~ 0)
