@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 from .types import AmrBox, CameraParameters, ColorMapControlPoint, ScalarTransform, VolumeBounds

@@ -6,7 +6,7 @@
 from __future__ import annotations
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 from . import _capi
