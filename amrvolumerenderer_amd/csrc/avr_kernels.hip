@@ -603,28 +603,41 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
   // 16-byte loads (two cells per lane) need every row to start 16-byte aligned
   const bool paired = ((reinterpret_cast<uintptr_t>(box.cells) & 15u) == 0) &&
                       ((jstride & 1u) == 0) && ((kstride & 1u) == 0);
-  if (paired) {
+  if (paired && nx >= 2) {
     typedef double double2_t __attribute__((ext_vector_type(2)));
     const int xi = (t & 63) * 2;  // first of this lane's two cells inside the 128-cell chunk
     const int i = chunk * kClassifyChunk + xi;
+    // All four rows' 16-byte loads are issued before the first is used: four round trips in
+    // flight per lane, so that a few resident workgroups already keep HBM busy -- what the
+    // classify pass gets when it shares the CUs with the march of the previous frame.  To keep
+    // the loads unconditional, the last cell of an odd row is read as the second half of the
+    // pair before it (an 8-byte aligned 16-byte load) and lanes outside the box read the box's
+    // first two cells.
+    double2_t raw[4];
+    bool valid[4], whole[4];
+    uint32_t at[4];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int row = pass * 4 + (t >> 6);  // 0..15 = kk * 4 + jj (one row per wave)
       const int j = bj * kBrickY + (row & 3);
       const int k = bk * kBrickZ + (row >> 2);
-      uint32_t two = 0;
-      if (i < nx && j < ny && k < nz) {
-        const uint32_t at = static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
-                            static_cast<uint32_t>(k) * kstride;
-        if (i + 1 < nx) {
-          const double2_t raw =
-              *(const double2_t __attribute__((address_space(1)))*)(cells + at);
-          two = static_cast<uint32_t>(table_index<SIMPLE>(raw.x, fc)) |
-                (static_cast<uint32_t>(table_index<SIMPLE>(raw.y, fc)) << 8);
-        } else {
-          two = static_cast<uint32_t>(table_index<SIMPLE>(cells[at], fc));
-        }
-      }
+      valid[pass] = i < nx && j < ny && k < nz;
+      whole[pass] = valid[pass] && (i + 1 < nx);
+      at[pass] = static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
+                 static_cast<uint32_t>(k) * kstride;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const uint32_t from = whole[pass] ? at[pass] : (valid[pass] ? at[pass] - 1u : 0u);
+      raw[pass] = *(const double2_t __attribute__((address_space(1)))*)(cells + from);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 4 + (t >> 6);
+      const uint32_t first = static_cast<uint32_t>(
+          table_index<SIMPLE>(whole[pass] ? raw[pass].x : raw[pass].y, fc));
+      const uint32_t second = static_cast<uint32_t>(table_index<SIMPLE>(raw[pass].y, fc));
+      const uint32_t two = whole[pass] ? (first | (second << 8)) : (valid[pass] ? first : 0u);
       // merge with the neighbouring lane: cells xi .. xi+3 of this row in one dword
       uint32_t packed = two << (16 * (t & 1));
       packed |= static_cast<uint32_t>(
