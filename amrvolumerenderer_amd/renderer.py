@@ -110,6 +110,7 @@ class FrameRenderer:
         if march_workgroups_per_cu is None:
             march_workgroups_per_cu = 5 if (n_ranks == 1 and not cache_classification) else 0
         self.march_ctx.set_march_occupancy(march_workgroups_per_cu)
+        self.march_workgroups_per_cu = march_workgroups_per_cu
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host,
                                                force_collectives)
         n_local = sum(1 for b in self.all_boxes if b.owner == rank)
@@ -182,6 +183,32 @@ class FrameRenderer:
         if timed:
             self.kernel_events.append((c0, classified, m0, marched))
         return self._send[slot]
+
+    def autotune(self, p: RenderParameters, camera: CameraParameters, frames: int = 5,
+                 candidates: Sequence[int] = (0, 5)) -> int:
+        """Picks the march occupancy cap (avr_context_set_march_occupancy) for this workload by
+        timing a few pipelined frames with each candidate.  Leaving CU slots to the classify
+        pass pays when the two kernels take comparable time (config-4: 1.25 -> 1.08 ms) and
+        costs when the march dominates (config-5, marched at 8192^2: 35.6 -> 42.3 ms).  Every rank
+        of a multi-rank renderer must call it (the frames are real, collective frames).
+        Returns the chosen cap."""
+        import time
+        best, best_time = candidates[0], float("inf")
+        for cap in candidates:
+            self.march_ctx.set_march_occupancy(cap)
+            for _ in range(2):
+                self.render(p, camera)
+            self.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                self.render(p, camera)
+            self.synchronize()
+            elapsed = time.perf_counter() - t0
+            if elapsed < best_time:
+                best, best_time = cap, elapsed
+        self.march_ctx.set_march_occupancy(best)
+        self.march_workgroups_per_cu = best
+        return best
 
     def synchronize(self) -> None:
         self.classify_ctx.synchronize()

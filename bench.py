@@ -222,6 +222,10 @@ def main():
     def step(i):
         return renderer.render(rparams, cameras[i % len(cameras)])
 
+    # Untimed setup: unless the cap was given, let the renderer pick the march occupancy cap for
+    # this workload (one rank only; a rank's share of an N-rank frame runs uncapped)
+    if args.march_occupancy is None and world == 1:
+        renderer.autotune(rparams, cameras[0])
     # Untimed: a short burst first brings the GPU to its working clocks and fills the allocator
     # pools when the caller asks for very few warm-up steps (setup, like the sample counting
     # above); then the W warm-up steps of the contract.
@@ -318,6 +322,7 @@ def main():
                         f"box_transparency={args.transparency}, default jet map, "
                         f"{len(cameras)} view(s)",
             "ownership": args.ownership, "runs_total": total_runs,
+            "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
             "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,
