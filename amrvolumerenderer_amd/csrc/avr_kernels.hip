@@ -237,7 +237,7 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   // the box, every sampled position with distance <= d < safe_end is inside as well and the
   // reference's inside test (:821-825, :838) is known to pass.  Steps from safe_end on (and
   // whole rays whose end points fail the test, e.g. grazing rays) take the general loop below.
-  const float safe_end = tmax - (step + step);
+  const float safe_end = tmax - step;
   bool interior = false;
   if (distance < safe_end) {
     const float ax = ray.ox + ray.dx * distance, ay = ray.oy + ray.dy * distance,
