@@ -81,11 +81,28 @@ def build_scene_geometry(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence
                          processed_range)
 
 
-def compute_histogram(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
-                      log_scale: bool = False, bins: int = 256, process_group=None,
-                      n_ranks: int = 1) -> dict:
-    """api::ComputeHistogram / python compute_histogram (VolumeRendererApi.cpp:397-413,
-    python/amrVolumeRenderer/module.cpp:304-356) for boxes already in HBM: scene statistics with
+def compute_histogram(plotfile: str, variable: Optional[str] = None, min_level: int = 0,
+                      max_level: int = -1, log_scale: bool = False, bins: int = 256, ctx=None,
+                      rank: int = 0, n_ranks: int = 1, process_group=None) -> dict:
+    """The reference python module's compute_histogram (module.cpp:304-356, same keyword names
+    and defaults; VolumeRenderer::computeScalarHistogram, VolumeRenderer.cpp:880-897): load the
+    plotfile with normalisation to the data range, then bin every uncovered cell."""
+    from . import plotfile as pf
+    from . import runtime
+    if bins <= 0:
+        raise ValueError("binCount must be positive")
+    if ctx is None:
+        ctx = runtime.Context(0)
+    scene = pf.load_plotfile_geometry(ctx, plotfile, variable or "", min_level, max_level,
+                                      log_scale, True, rank, n_ranks, process_group)
+    return compute_scene_histogram(ctx, scene.all_boxes, scene.local_boxes, log_scale, bins,
+                                   process_group, n_ranks)
+
+
+def compute_scene_histogram(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
+                            log_scale: bool = False, bins: int = 256, process_group=None,
+                            n_ranks: int = 1) -> dict:
+    """api::ComputeHistogram (VolumeRendererApi.cpp:397-413) for boxes already in HBM: scene statistics with
     normalisation to the data range, then the 64-bit bin counts of every cell
     (ComputeSceneHistogram, SceneBuilder.cpp:445-577).  Returns the module's dict keys."""
     import torch

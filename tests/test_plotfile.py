@@ -293,3 +293,33 @@ def test_example_script_runs(tmp_path):
     subprocess.run([sys.executable, script, "--size", "48", "--orbit", "3", "--output",
                     str(tmp_path / "orbit.ppm")], check=True, cwd=tmp_path)
     assert all((tmp_path / f"orbit_{v:03d}.ppm").exists() for v in range(3))
+
+
+@pytest.mark.gpu
+def test_compute_histogram_of_a_plotfile(O, ctx, tmp_path):
+    """The python module's second entry: counts of the uncovered cells of both levels in bins of
+    the normalised scalar."""
+    rng = np.random.default_rng(21)
+    levels = two_level_scene(rng)
+    path = str(tmp_path / "plt_hist")
+    pf.write_plotfile(path, ["density", "noise"], levels, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), [2])
+    result = api.compute_histogram(path, variable="noise", bins=64, ctx=ctx)
+    convex = pf.convexify([lev["boxes"] for lev in levels], [2])
+    values = []
+    for level, lev in enumerate(levels):
+        for parent, (lo, hi) in convex[level]:
+            glo = lev["boxes"][parent][0]
+            values.append(lev["data"][parent][1][lo[2] - glo[2]:hi[2] - glo[2] + 1,
+                                                 lo[1] - glo[1]:hi[1] - glo[1] + 1,
+                                                 lo[0] - glo[0]:hi[0] - glo[0] + 1].reshape(-1))
+    values = np.concatenate(values)
+    assert result["samples"] == values.size == int(result["counts"].sum())
+    lo_v, hi_v = values.min(), values.max()
+    assert result["normalized_range"] == (0.0, 1.0)
+    assert result["original_range"] == (float(np.float32(lo_v)), float(np.float32(hi_v)))
+    oboxes = [O.make_box(np.ascontiguousarray(values.reshape(1, 1, -1)), (0, 0, 0), (1, 1, 1))]
+    want = O.histogram(oboxes, O.make_transform(normalize=True, norm_min=lo_v,
+                                                inv_norm_span=1.0 / (hi_v - lo_v)), 0.0, 1.0, 64)
+    assert np.array_equal(result["counts"], want)
+    with pytest.raises(ValueError):
+        api.compute_histogram(path, bins=0, ctx=ctx)

@@ -114,7 +114,7 @@ def test_build_scene_geometry_and_compute_histogram(O, ctx):
     _, otr, *_ = O.scene_transform(stats[:3], stats[3], False, True)
     _close_transform(geometry.scalar_transform, otr)
     assert geometry.scalar_range == (0.0, 1.0)
-    result = api.compute_histogram(ctx, meta, local, log_scale=False, bins=128)
+    result = api.compute_scene_histogram(ctx, meta, local, log_scale=False, bins=128)
     want = O.histogram(orc_boxes, otr, 0.0, 1.0, 128)
     assert np.array_equal(result["counts"], want)
     assert result["samples"] == sum(c.size for c in cells)
