@@ -9,5 +9,9 @@ from . import _capi  # noqa: F401
 from .types import (AmrBox, CameraParameters, ColorMapControlPoint, ScalarTransform,  # noqa: F401
                     VolumeBounds, make_params)
 
-__all__ = ["AmrBox", "CameraParameters", "ColorMapControlPoint", "ScalarTransform",
+# the reference python package's four entry points (python/amrVolumeRenderer/__init__.py)
+from .api import compute_histogram, finalize_runtime, initialize_runtime, render  # noqa: F401
+
+__all__ = ["render", "initialize_runtime", "finalize_runtime", "compute_histogram",
+           "AmrBox", "CameraParameters", "ColorMapControlPoint", "ScalarTransform",
            "VolumeBounds", "make_params"]

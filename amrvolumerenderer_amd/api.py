@@ -92,7 +92,7 @@ def compute_histogram(plotfile: str, variable: Optional[str] = None, min_level: 
     if bins <= 0:
         raise ValueError("binCount must be positive")
     if ctx is None:
-        ctx = runtime.Context(0)
+        ctx, rank, n_ranks, process_group = _runtime_scope()
     scene = pf.load_plotfile_geometry(ctx, plotfile, variable or "", min_level, max_level,
                                       log_scale, True, rank, n_ranks, process_group)
     return compute_scene_histogram(ctx, scene.all_boxes, scene.local_boxes, log_scale, bins,
@@ -250,6 +250,58 @@ def _libm_float(name: str):
     fn.restype = ctypes.c_float
     fn.argtypes = [ctypes.c_float]
     return lambda x: fn(float(x))
+
+
+_runtime = {"refs": 0, "ctx": None, "owns_group": False}
+
+
+def initialize_runtime() -> None:
+    """amrVolumeRenderer.initialize_runtime (module.cpp:103-107): set the process up once ahead
+    of several render() / compute_histogram() calls -- here the rendering context on the local
+    GPU and, when launched with one process per GPU (WORLD_SIZE > 1), the RCCL process group."""
+    from . import runtime
+    import torch
+    if _runtime["refs"] == 0:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                _runtime["owns_group"] = True
+        _runtime["ctx"] = runtime.Context(local_rank)
+    _runtime["refs"] += 1
+
+
+def finalize_runtime() -> None:
+    """amrVolumeRenderer.finalize_runtime (module.cpp:109-119)."""
+    if _runtime["refs"] == 0:
+        raise RuntimeError("amrVolumeRenderer.finalize_runtime requires a matching "
+                           "initialize_runtime call")
+    _runtime["refs"] -= 1
+    if _runtime["refs"] == 0:
+        if _runtime["ctx"] is not None:
+            _runtime["ctx"].close()
+            _runtime["ctx"] = None
+        if _runtime["owns_group"]:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+            _runtime["owns_group"] = False
+
+
+def _runtime_scope():
+    """(context, rank, world size, process group) of the initialised runtime, or a fresh
+    single-GPU context (the reference's RuntimeScope initialises on demand, module.cpp:86-101)."""
+    from . import runtime
+    if _runtime["ctx"] is None:
+        return runtime.Context(0), 0, 1, None
+    rank, world, group = 0, 1, None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world, group = dist.get_rank(), dist.get_world_size(), dist.group.WORLD
+    return _runtime["ctx"], rank, world, group
 
 
 class _Mt19937:
@@ -417,7 +469,8 @@ def render(plotfile: str, width: int = 512, height: int = 512, box_transparency:
         raise RuntimeError("plotfile path is required")
     if not os.path.exists(plotfile):
         raise RuntimeError(f"plotfile path '{plotfile}' does not exist")
-    return run(plotfile, options, variable or "")
+    ctx, rank, world, group = _runtime_scope()
+    return run(plotfile, options, variable or "", ctx, rank, world, group)
 
 
 def run(plotfile: str, options: RenderOptions, variable_name: str = "", ctx=None, rank: int = 0,

@@ -323,3 +323,26 @@ def test_compute_histogram_of_a_plotfile(O, ctx, tmp_path):
     assert np.array_equal(result["counts"], want)
     with pytest.raises(ValueError):
         api.compute_histogram(path, bins=0, ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_package_entry_points_with_an_initialised_runtime(tmp_path):
+    """import amrvolumerenderer_amd as avr; avr.initialize_runtime(); avr.render(...);
+    avr.compute_histogram(...); avr.finalize_runtime() -- the reference package's surface."""
+    import amrvolumerenderer_amd as avr
+    levels = two_level_scene(np.random.default_rng(2))
+    path = str(tmp_path / "plt_pkg")
+    pf.write_plotfile(path, ["density", "noise"], levels, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), [2])
+    with pytest.raises(RuntimeError):
+        avr.finalize_runtime()  # without a matching initialize_runtime
+    avr.initialize_runtime()
+    avr.initialize_runtime()    # reference counted
+    try:
+        out = str(tmp_path / "a.ppm")
+        assert avr.render(path, width=48, height=40, output=out) == 0
+        assert os.path.getsize(out) == len(b"P6\n48 40\n255\n") + 48 * 40 * 3
+        hist = avr.compute_histogram(path, bins=32)
+        assert hist["samples"] == int(hist["counts"].sum()) > 0
+    finally:
+        avr.finalize_runtime()
+        avr.finalize_runtime()
