@@ -52,6 +52,60 @@ class SceneGeometry:
     processed_scalar_range: Optional[Tuple[float, float]] = None   # after log scaling, if any
 
 
+@dataclass
+class AmrData:
+    """api::AmrData (VolumeRenderer/VolumeRendererApi.hpp:22-26) without AMReX objects: per level
+    the grids' index boxes and cell arrays instead of a MultiFab, the problem's lower corner and
+    cell sizes instead of an amrex::Geometry.
+    level_boxes[l] = [((ilo, jlo, klo), (ihi, jhi, khi)), ...]   inclusive, cell-centred
+    level_data[l][g] = float64 array [nz, ny, nx] or [ncomp, nz, ny, nx] (numpy or torch)"""
+    level_boxes: List[list]
+    level_data: List[list]
+    prob_lo: Tuple[float, float, float]
+    cell_sizes: List[Tuple[float, float, float]]
+    refinement_ratios: List[int]
+
+
+def load_amr_data_geometry(ctx, data: AmrData, requested_min_level: int = 0,
+                           requested_max_level: int = -1, component: int = 0,
+                           log_scale_input: bool = False, normalize_to_data_range: bool = True,
+                           rank: int = 0, n_ranks: int = 1, process_group=None) -> "SceneGeometry":
+    """loadMultiFabGeometry (VolumeRendererApi.cpp:44-131)."""
+    from . import plotfile as pf
+    if not data.level_boxes or len(data.level_boxes) != len(data.level_data) or \
+            len(data.cell_sizes) != len(data.level_boxes):
+        raise ValueError("levelData and levelGeometry must be non-empty and of matching sizes")
+    finest = len(data.level_boxes) - 1
+    min_level, max_level = pf.clamp_levels(requested_min_level, requested_max_level, finest)
+    if min_level > max_level:
+        raise RuntimeError("minLevel must not exceed maxLevel")
+    if max_level > 0 and len(data.refinement_ratios) < max_level:
+        raise ValueError("refinementRatios must provide ratios for each level transition")
+    if component < 0:
+        raise ValueError("component index out of range")
+
+    def fetch(level, grid_ids):
+        out = {}
+        for g in grid_ids:
+            cells = data.level_data[level][g]
+            if cells is None:
+                raise ValueError("levelData contains a null MultiFab pointer")
+            if cells.ndim == 4:
+                if component >= cells.shape[0]:
+                    raise ValueError("component index out of range")
+                cells = cells[component]
+            elif component != 0:
+                raise ValueError("component index out of range")
+            out[g] = cells
+        return out
+
+    return pf.build_scene_from_levels(
+        ctx, [list(b) for b in data.level_boxes], data.cell_sizes, data.prob_lo,
+        data.refinement_ratios, fetch, min_level, max_level, log_scale_input,
+        normalize_to_data_range, rank, n_ranks, process_group,
+        "Failed to locate any volumetric data in the provided MultiFabs.")
+
+
 def build_scene_geometry(ctx, all_boxes: Sequence[AmrBox], local_boxes: Sequence[AmrBox],
                          bounds: VolumeBounds, log_scale_input: bool = False,
                          normalize_to_data_range: bool = True, process_group=None,
@@ -478,16 +532,37 @@ def run(plotfile: str, options: RenderOptions, variable_name: str = "", ctx=None
     """VolumeRenderer::run(RunOptions) after its argument checks (VolumeRenderer.cpp:1469-1576):
     load the plotfile, apply a scalar-range override and convert the colour map's physical
     values to normalised ones, then renderScene."""
-    import numpy as np
     from . import plotfile as pf
     from . import runtime
-    f32 = np.float32
     if ctx is None:
         ctx = runtime.Context(0)
     has_override = options.scalar_range is not None
     scene = pf.load_plotfile_geometry(ctx, plotfile, variable_name, options.min_level,
                                       options.max_level, options.log_scale_input,
                                       not has_override, rank, n_ranks, process_group)
+    return _render_loaded_scene(ctx, scene, options, rank, n_ranks, process_group)
+
+
+def render_amr_data(data: AmrData, options: RenderOptions, ctx=None, rank: int = 0,
+                    n_ranks: int = 1, process_group=None) -> int:
+    """api::Render(const AmrData&, const RenderOptions&) (VolumeRendererApi.cpp:257-395)."""
+    from . import runtime
+    validate_options(options)
+    if ctx is None:
+        ctx = runtime.Context(0)
+    scene = load_amr_data_geometry(ctx, data, options.min_level, options.max_level,
+                                   options.component, options.log_scale_input,
+                                   options.scalar_range is None, rank, n_ranks, process_group)
+    return _render_loaded_scene(ctx, scene, options, rank, n_ranks, process_group)
+
+
+def _render_loaded_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int,
+                         n_ranks: int, process_group) -> int:
+    """The common tail of VolumeRenderer::run and api::Render: scalar-range override, colour-map
+    values from physical to normalised, camera-up normalisation, renderScene."""
+    import numpy as np
+    f32 = np.float32
+    has_override = options.scalar_range is not None
     if scene.processed_scalar_range is None:
         raise RuntimeError("Internal error: processed scalar range unavailable for color mapping.")
     processed_min, processed_max = (f32(v) for v in scene.processed_scalar_range)

@@ -362,56 +362,34 @@ def assign_box_owners(boxes, n_ranks: int) -> None:
         running += c
 
 
-def load_plotfile_geometry(ctx, plotfile_path: str, variable_name: str = "",
-                           requested_min_level: int = 0, requested_max_level: int = -1,
-                           log_scale_input: bool = False, normalize_to_data_range: bool = True,
-                           rank: int = 0, n_ranks: int = 1, process_group=None):
-    """VolumeRenderer::loadPlotFileGeometry (VolumeRenderer.cpp:587-711) + the geometric part of
-    detail::BuildSceneGeometry (SceneBuilder.cpp:112-313): reads the requested component,
-    removes the cells covered by finer levels, builds world-space boxes (probLo + index * cell
-    size, rescaled so that the shortest domain edge is 1), the padded bounds and the scalar
-    transform.  Every rank reads only the grids its own boxes come from."""
+def build_scene_from_levels(ctx, level_boxes, cell_sizes, prob_lo, ref_ratio, fetch_grids,
+                            min_level: int, max_level: int, log_scale_input: bool,
+                            normalize_to_data_range: bool, rank: int, n_ranks: int,
+                            process_group, no_data_error: str):
+    """amrex::convexify + detail::BuildSceneGeometry (SceneBuilder.cpp:112-425) for levels given
+    as box lists: level_boxes[l] = [IntBox], cell_sizes[l] = (dx, dy, dz), fetch_grids(level,
+    [grid indices]) -> {grid index: float64 array [nz, ny, nx] (numpy or a tensor on ctx.device)}.
+    Only the grids this rank's boxes come from are fetched."""
     import torch
     from . import api
     from .types import AmrBox, VolumeBounds
-    if not plotfile_path:
-        raise ValueError("Plotfile path must not be empty.")
-    plotfile = PlotFileData(plotfile_path)
-    if plotfile.space_dim != 3:
-        raise RuntimeError(f"Plotfile '{plotfile_path}' has space dimension {plotfile.space_dim}. "
-                           "The volume renderer currently expects 3D data.")
-    if not plotfile.var_names:
-        raise RuntimeError("Plotfile contains no cell variables to render.")
-    component = variable_name or plotfile.var_names[0]
-    if component not in plotfile.var_names:
-        raise RuntimeError(f"Variable '{component}' not found in plotfile '{plotfile_path}'.")
-    finest = plotfile.finest_level
-    min_level = min(max(requested_min_level, 0), finest)
-    max_level = requested_max_level
-    if max_level < 0 or max_level > finest:
-        max_level = finest
-    if min_level > max_level:
-        raise RuntimeError(f"Minimum AMR level {min_level} exceeds available maximum level "
-                           f"{max_level}.")
-
-    level_boxes = [plotfile.boxes(level) for level in range(max_level + 1)]
-    convex = convexify(level_boxes, plotfile.ref_ratio[:max_level])
+    convex = convexify(level_boxes[:max_level + 1], list(ref_ratio)[:max_level])
 
     # world-space boxes, level-major then grid order (MFIter order, SceneBuilder.cpp:134-188)
     entries = []  # (level, parent grid, sub-box)
     boxes = []
     for level in range(min_level, max_level + 1):
-        dx = plotfile.cell_size[level]
+        dx = cell_sizes[level]
         for parent, (lo, hi) in convex[level]:
             dims = tuple(hi[a] - lo[a] + 1 for a in range(3))
             if min(dims) <= 0:
                 continue
-            min_corner = tuple(plotfile.prob_lo[a] + float(lo[a]) * dx[a] for a in range(3))
-            max_corner = tuple(plotfile.prob_lo[a] + float(hi[a] + 1) * dx[a] for a in range(3))
+            min_corner = tuple(prob_lo[a] + float(lo[a]) * dx[a] for a in range(3))
+            max_corner = tuple(prob_lo[a] + float(hi[a] + 1) * dx[a] for a in range(3))
             entries.append((level, parent, (lo, hi)))
             boxes.append(AmrBox(min_corner, max_corner, level=level, dims=dims))
     if not boxes:
-        raise RuntimeError("Failed to locate any volumetric data within the plotfile.")
+        raise RuntimeError(no_data_error)
 
     # global rescale: the shortest edge of the data's bounding box becomes 1 (:229-254)
     gmin = [min(b.min_corner[a] for b in boxes) for a in range(3)]
@@ -437,23 +415,70 @@ def load_plotfile_geometry(ctx, plotfile_path: str, variable_name: str = "",
 
     assign_box_owners(boxes, n_ranks)
 
-    # cells: each parent grid of a local box is read and uploaded once; boxes are views into it
+    # cells: each parent grid of a local box is fetched and uploaded once; boxes are views into it
     needed = {}
     for (level, parent, _), b in zip(entries, boxes):
         if b.owner == rank:
             needed.setdefault(level, set()).add(parent)
     grids = {}
     for level, parents in needed.items():
-        for parent, cells in plotfile.get(level, component, sorted(parents)).items():
-            grids[(level, parent)] = torch.from_numpy(cells).to(ctx.device)
+        for parent, cells in fetch_grids(level, sorted(parents)).items():
+            tensor = cells if isinstance(cells, torch.Tensor) else torch.from_numpy(
+                np.ascontiguousarray(cells, dtype=np.float64))
+            grids[(level, parent)] = tensor.to(device=ctx.device, dtype=torch.float64)
     local = []
     for (level, parent, (lo, hi)), b in zip(entries, boxes):
         if b.owner != rank:
             continue
-        glo, _ = level_boxes[level][parent]
+        glo, ghi = level_boxes[level][parent]
         grid = grids[(level, parent)]
+        if tuple(grid.shape) != tuple(ghi[a] - glo[a] + 1 for a in (2, 1, 0)):
+            raise ValueError(f"grid {parent} of level {level} does not match its box")
         view = grid[lo[2] - glo[2]:hi[2] - glo[2] + 1, lo[1] - glo[1]:hi[1] - glo[1] + 1,
                     lo[0] - glo[0]:hi[0] - glo[0] + 1]
         local.append(AmrBox(b.min_corner, b.max_corner, view, b.level, owner=rank))
     return api.build_scene_geometry(ctx, boxes, local, bounds, log_scale_input,
                                     normalize_to_data_range, process_group, n_ranks)
+
+
+def clamp_levels(requested_min_level: int, requested_max_level: int, finest: int):
+    """The level clamps of loadPlotFileGeometry / loadMultiFabGeometry
+    (VolumeRenderer.cpp:626-642, VolumeRendererApi.cpp:58-72)."""
+    min_level = min(max(requested_min_level, 0), finest)
+    max_level = requested_max_level
+    if max_level < 0 or max_level > finest:
+        max_level = finest
+    return min_level, max_level
+
+
+def load_plotfile_geometry(ctx, plotfile_path: str, variable_name: str = "",
+                           requested_min_level: int = 0, requested_max_level: int = -1,
+                           log_scale_input: bool = False, normalize_to_data_range: bool = True,
+                           rank: int = 0, n_ranks: int = 1, process_group=None):
+    """VolumeRenderer::loadPlotFileGeometry (VolumeRenderer.cpp:587-711) + the geometric part of
+    detail::BuildSceneGeometry (SceneBuilder.cpp:112-313): reads the requested component,
+    removes the cells covered by finer levels, builds world-space boxes (probLo + index * cell
+    size, rescaled so that the shortest domain edge is 1), the padded bounds and the scalar
+    transform.  Every rank reads only the grids its own boxes come from."""
+    if not plotfile_path:
+        raise ValueError("Plotfile path must not be empty.")
+    plotfile = PlotFileData(plotfile_path)
+    if plotfile.space_dim != 3:
+        raise RuntimeError(f"Plotfile '{plotfile_path}' has space dimension {plotfile.space_dim}. "
+                           "The volume renderer currently expects 3D data.")
+    if not plotfile.var_names:
+        raise RuntimeError("Plotfile contains no cell variables to render.")
+    component = variable_name or plotfile.var_names[0]
+    if component not in plotfile.var_names:
+        raise RuntimeError(f"Variable '{component}' not found in plotfile '{plotfile_path}'.")
+    min_level, max_level = clamp_levels(requested_min_level, requested_max_level,
+                                        plotfile.finest_level)
+    if min_level > max_level:
+        raise RuntimeError(f"Minimum AMR level {min_level} exceeds available maximum level "
+                           f"{max_level}.")
+    level_boxes = [plotfile.boxes(level) for level in range(max_level + 1)]
+    return build_scene_from_levels(
+        ctx, level_boxes, plotfile.cell_size, plotfile.prob_lo, plotfile.ref_ratio,
+        lambda level, grid_ids: plotfile.get(level, component, grid_ids), min_level, max_level,
+        log_scale_input, normalize_to_data_range, rank, n_ranks, process_group,
+        "Failed to locate any volumetric data within the plotfile.")

@@ -346,3 +346,30 @@ def test_package_entry_points_with_an_initialised_runtime(tmp_path):
     finally:
         avr.finalize_runtime()
         avr.finalize_runtime()
+
+
+@pytest.mark.gpu
+def test_render_amr_data_equals_render_of_the_same_plotfile(ctx, tmp_path):
+    """api::Render(AmrData): in-memory levels (a multi-component array per grid) give the same
+    image as the plotfile holding the same data."""
+    rng = np.random.default_rng(4)
+    levels = two_level_scene(rng)
+    path = str(tmp_path / "plt_mem")
+    pf.write_plotfile(path, ["density", "noise"], levels, (0.0, 0.0, 0.0), (2.0, 2.0, 2.0), [2])
+    cam = CameraParameters((2.4, 1.7, 2.2), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), 40.0, 0.05, 30.0)
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    assert api.render(path, width=72, height=48, box_transparency=0.4, variable="noise", output=a,
+                      camera_eye=cam.eye, camera_look_at=cam.look_at, camera_fov_y=40.0,
+                      camera_near=0.05, camera_far=30.0) == 0
+    data = api.AmrData([lev["boxes"] for lev in levels], [lev["data"] for lev in levels],
+                       (0.0, 0.0, 0.0), [(2.0 / 16,) * 3, (2.0 / 32,) * 3], [2])
+    options = api.RenderOptions(width=72, height=48, box_transparency=0.4, component=1,
+                                camera=cam, output_filename=b)
+    assert api.render_amr_data(data, options, ctx=ctx) == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    with pytest.raises(ValueError):
+        api.render_amr_data(data, api.RenderOptions(component=5, camera=cam, output_filename=b),
+                            ctx=ctx)
+    with pytest.raises(ValueError):  # no ratio for the level transition
+        api.render_amr_data(api.AmrData(data.level_boxes, data.level_data, data.prob_lo,
+                                        data.cell_sizes, []), options, ctx=ctx)
