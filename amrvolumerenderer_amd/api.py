@@ -451,7 +451,7 @@ def automatic_camera(bounds: VolumeBounds, camera_seed: int = 91021,
 
 
 def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 0,
-                 n_ranks: int = 1, process_group=None) -> int:
+                 n_ranks: int = 1, process_group=None, stage_through_host: bool = False) -> int:
     """renderScene (VolumeRenderer.cpp:947-1101 -> renderSingleTrial) with an explicit camera or
     the automatic one: paints, composites, gathers and writes the image on rank 0.  Returns 0 on
     success like the reference."""
@@ -463,7 +463,7 @@ def render_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int = 
     extension = os.path.splitext(options.output_filename)[1].lower()
     renderer = FrameRenderer(ctx, scene.all_boxes, scene.local_boxes, scene.scalar_transform,
                              scene.bounds, scene.scalar_range, rank, n_ranks, process_group,
-                             color_map=options.color_map)
+                             color_map=options.color_map, stage_through_host=stage_through_host)
     _, rgb8 = renderer.render(
         RenderParameters(options.width, options.height, options.box_transparency,
                          options.antialiasing, options.visibility_graph,
@@ -528,7 +528,7 @@ def render(plotfile: str, width: int = 512, height: int = 512, box_transparency:
 
 
 def run(plotfile: str, options: RenderOptions, variable_name: str = "", ctx=None, rank: int = 0,
-        n_ranks: int = 1, process_group=None) -> int:
+        n_ranks: int = 1, process_group=None, stage_through_host: bool = False) -> int:
     """VolumeRenderer::run(RunOptions) after its argument checks (VolumeRenderer.cpp:1469-1576):
     load the plotfile, apply a scalar-range override and convert the colour map's physical
     values to normalised ones, then renderScene."""
@@ -540,7 +540,8 @@ def run(plotfile: str, options: RenderOptions, variable_name: str = "", ctx=None
     scene = pf.load_plotfile_geometry(ctx, plotfile, variable_name, options.min_level,
                                       options.max_level, options.log_scale_input,
                                       not has_override, rank, n_ranks, process_group)
-    return _render_loaded_scene(ctx, scene, options, rank, n_ranks, process_group)
+    return _render_loaded_scene(ctx, scene, options, rank, n_ranks, process_group,
+                                stage_through_host)
 
 
 def render_amr_data(data: AmrData, options: RenderOptions, ctx=None, rank: int = 0,
@@ -557,7 +558,7 @@ def render_amr_data(data: AmrData, options: RenderOptions, ctx=None, rank: int =
 
 
 def _render_loaded_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank: int,
-                         n_ranks: int, process_group) -> int:
+                         n_ranks: int, process_group, stage_through_host: bool = False) -> int:
     """The common tail of VolumeRenderer::run and api::Render: scalar-range override, colour-map
     values from physical to normalised, camera-up normalisation, renderScene."""
     import numpy as np
@@ -617,7 +618,7 @@ def _render_loaded_scene(ctx, scene: SceneGeometry, options: RenderOptions, rank
         options = _replace(options, camera=CameraParameters(cam.eye, cam.look_at, up,
                                                             cam.fov_y_degrees, cam.near_plane,
                                                             cam.far_plane))
-    return render_scene(ctx, scene, options, rank, n_ranks, process_group)
+    return render_scene(ctx, scene, options, rank, n_ranks, process_group, stage_through_host)
 
 
 def _replace(options: RenderOptions, **changes) -> RenderOptions:

@@ -138,3 +138,78 @@ def test_rccl_collectives_with_one_rank(tmp_path):
     mp.spawn(_rccl_worker, args=(_free_port(), str(out)), nprocs=1, join=True)
     flags = out.read_text().split()
     assert flags and all(f == "1" for f in flags), flags
+
+
+def _plotfile_worker(rank, world, port, plot_path, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amrvolumerenderer_amd import api, runtime
+        from amrvolumerenderer_amd.types import CameraParameters
+        ctx = runtime.Context(0)
+        cam = CameraParameters((2.4, 1.7, 2.2), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), 40.0, 0.05, 30.0)
+        options = api.RenderOptions(width=80, height=56, box_transparency=0.5, camera=cam,
+                                    output_filename=out_path)
+        assert api.run(plot_path, options, "density", ctx, rank, world, dist.group.WORLD,
+                       stage_through_host=True) == 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_render_a_plotfile(tmp_path):
+    """Multi-rank plotfile ingestion end to end: both ranks read only their own grids, the scene
+    statistics are reduced over the ranks, the frame is composited and rank 0 writes the file --
+    against the oracle's 2-rank compose with the same ownership."""
+    from oracle import oracle as O
+    from amrvolumerenderer_amd import plotfile as pf
+    from amrvolumerenderer_amd.types import AmrBox, CameraParameters, VolumeBounds
+    from amrvolumerenderer_amd import scenes
+    from test_frame_plan import local_indices, oracle_camera, oracle_params, oracle_transform
+    from test_plotfile import two_level_scene
+    levels = two_level_scene(np.random.default_rng(9))
+    plot = str(tmp_path / "plt_two")
+    pf.write_plotfile(plot, ["density", "noise"], levels, (0.0, 0.0, 0.0), (2.0, 2.0, 2.0), [2])
+    out = str(tmp_path / "frame.ppm")
+    mp.spawn(_plotfile_worker, args=(2, _free_port(), plot, out), nprocs=2, join=True)
+
+    W, H, scale = 80, 56, 0.5
+    convex = pf.convexify([lev["boxes"] for lev in levels], [2])
+    meta, oboxes, cells_all = [], [], []
+    for level, lev in enumerate(levels):
+        dx = 2.0 / (16 * 2 ** level)
+        for parent, (lo, hi) in convex[level]:
+            glo = lev["boxes"][parent][0]
+            cells = np.ascontiguousarray(
+                lev["data"][parent][0][lo[2] - glo[2]:hi[2] - glo[2] + 1,
+                                       lo[1] - glo[1]:hi[1] - glo[1] + 1,
+                                       lo[0] - glo[0]:hi[0] - glo[0] + 1])
+            mn = tuple(lo[a] * dx * scale for a in range(3))
+            mx = tuple((hi[a] + 1) * dx * scale for a in range(3))
+            meta.append(AmrBox(mn, mx, level=level, dims=cells.shape[::-1]))
+            oboxes.append(O.make_box(cells, mn, mx))
+            cells_all.append(cells)
+    pf.assign_box_owners(meta, 2)  # the partition policy, not arithmetic
+    owners = [b.owner for b in meta]
+    assert set(owners) == {0, 1}
+    lo_v, hi_v = min(c.min() for c in cells_all), max(c.max() for c in cells_all)
+    bounds = VolumeBounds((-0.05,) * 3, (1.05,) * 3)
+    cam = CameraParameters((2.4, 1.7, 2.2), (0.5, 0.5, 0.5), (0.0, 1.0, 0.0), 40.0, 0.05, 30.0)
+    transform = scenes.ScalarTransform(normalize_to_unit_range=True, normalization_min=lo_v,
+                                       inverse_normalization_span=1.0 / (hi_v - lo_v))
+    ref = O.reference_sample_distance(oboxes, bounds.min_corner, bounds.max_corner)
+    op = oracle_params(O, W, H, (0.0, 1.0), 0.5, ref, bounds)
+    ocam, otr = oracle_camera(O, cam), oracle_transform(O, transform)
+    layers = [O.paint_box(ob, otr, op, ocam)[0] for ob in oboxes]
+    hints = [O.box_depth_hint(ob, ocam) for ob in oboxes]
+    want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, 2), 2)
+    tight = O.tight_bounds(oboxes, bounds.min_corner, bounds.max_corner)
+    want = O.bbox_overlay(want, W, H, tight[0], tight[1], ocam, 1).reshape(-1, 5)
+    data = open(out, "rb").read()
+    header = f"P6\n{W} {H}\n255\n".encode()
+    assert data.startswith(header)
+    got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
+    assert np.array_equal(got, O.quantize_rgb8(want, W, H))
