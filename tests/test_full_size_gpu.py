@@ -1,0 +1,97 @@
+"""Parity at BASELINE.json's headline configuration, full size: config-4 (3-level AMR, 512^3 base,
+176 boxes of 128^3 = 2.95 GB of f64 cells), 2048 x 2048, translucent transfer function -- the
+frame bench.py times -- bit for bit against the oracle, as one rank and as eight (simulated)
+ranks.  The oracle paints the 759 M samples on the host's cores in a few seconds."""
+import numpy as np
+import pytest
+import torch
+
+from amrvolumerenderer_amd import scenes
+from amrvolumerenderer_amd.compositor import FramePlan
+from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+from amrvolumerenderer_amd.types import AmrBox, make_params
+
+import plan_helpers as PH
+from helpers import oracle_camera, oracle_params, oracle_transform
+from test_frame_plan import local_indices
+
+pytestmark = pytest.mark.gpu
+W = H = 2048
+TRANSPARENCY = 0.97
+
+
+@pytest.fixture(scope="module")
+def config4(O, ctx):
+    spec = scenes.config4("smooth")
+    cam = scenes.default_camera()
+    device_cells = [scenes.box_cells_torch(spec, i, ctx.device) for i in range(len(spec.boxes))]
+    torch.cuda.synchronize()
+    host_cells = [c.cpu().numpy() for c in device_cells]   # the same bits on both sides
+    oboxes = [O.make_box(c, m.min_corner, m.max_corner) for c, m in zip(host_cells, spec.boxes)]
+    ref = O.reference_sample_distance(oboxes, spec.bounds.min_corner, spec.bounds.max_corner)
+    op = oracle_params(O, W, H, spec.scalar_range, TRANSPARENCY, ref, spec.bounds)
+    ocam, otr = oracle_camera(O, cam), oracle_transform(O, spec.transform)
+    layers, samples = [], 0
+    for ob in oboxes:
+        layer, n = O.paint_box(ob, otr, op, ocam, threads=16)
+        layers.append(layer)
+        samples += n
+    hints = [O.box_depth_hint(ob, ocam) for ob in oboxes]
+    return spec, cam, device_cells, layers, hints, ref, samples
+
+
+def test_config4_single_rank_frame_is_the_oracles(O, ctx, config4):
+    spec, cam, device_cells, layers, hints, ref, samples = config4
+    n = len(layers)
+    want, _, _ = O.compose_layered(layers, hints, [0] * n, np.arange(n), 1)
+    meta = [scenes.metadata_box(spec, i) for i in range(n)]
+    local = [AmrBox(m.min_corner, m.max_corner, c, m.level) for c, m in zip(device_cells, spec.boxes)]
+    renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+    assert np.float32(renderer.reference_sample_distance) == np.float32(ref)
+    counter = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    image, rgb8 = renderer.render(RenderParameters(W, H, TRANSPARENCY, 1, draw_bounds=False), cam,
+                                  samples=counter, want_image=True)
+    renderer.synchronize()
+    assert int(counter.item()) == samples == 759136367  # the sample count bench.py reports
+    got = image.cpu().numpy().reshape(-1, 5)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(rgb8.cpu().numpy(), O.quantize_rgb8(want, W, H))
+    # the frame bench.py times (bytes only, pipelined) gives the same bytes
+    frames = [renderer.render(RenderParameters(W, H, TRANSPARENCY, 1, draw_bounds=False), cam)
+              for _ in range(3)]
+    renderer.synchronize()
+    for _, again in frames:
+        assert torch.equal(again, rgb8)
+
+
+def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config4):
+    spec, cam, device_cells, layers, hints, ref, _ = config4
+    n_ranks = 8
+    scenes.assign_owners(spec, n_ranks, "morton")
+    owners = [b.owner for b in spec.boxes]
+    want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
+    meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+    params = make_params(W, H, spec.scalar_range, TRANSPARENCY, ref, spec.bounds)
+    plans, sends = [], []
+    for r in range(n_ranks):
+        plan = FramePlan(meta, params, cam, r, n_ranks)
+        local = [AmrBox(spec.boxes[i].min_corner, spec.boxes[i].max_corner, device_cells[i],
+                        spec.boxes[i].level, owner=r) for i in scenes.local_box_indices(spec, r)]
+        scene = ctx.create_scene(local, spec.transform)
+        send = scene.render_plan(plan)
+        ctx.synchronize()
+        plans.append(plan)
+        sends.append(send[:plan.send_floats].cpu().numpy())
+    got8 = np.zeros((W * H, 3), np.uint8)
+    got = np.zeros((W * H, 5), np.float32)
+    for plan, recv in zip(plans, PH.route(plans, sends)):
+        dev = torch.from_numpy(np.ascontiguousarray(recv)).to(ctx.device)
+        if dev.numel() == 0:
+            dev = torch.zeros(1, device=ctx.device)
+        piece, rgb8 = ctx.fold_plan(plan, dev, want_rgb8=True)
+        ctx.synchronize()
+        got[plan.piece_begin:plan.piece_end] = piece.cpu().numpy()
+        got8[plan.piece_begin:plan.piece_end] = rgb8.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got8, O.quantize_rgb8(want, W, H)[::-1].reshape(-1, 3))
+    scenes.assign_owners(spec, 1, "morton")
