@@ -3,13 +3,13 @@
   api::Render(AmrData, RenderOptions)    VolumeRenderer/VolumeRendererApi.hpp:22-54
   python render(plotfile, **kwargs)      python/amrVolumeRenderer/module.cpp:264-303
 
-What is built this round is the hot path below these entries.  Scene construction from AMReX
-data (SceneBuilder, plotfile reading) is not, so `render_scene` takes
-the scene in the form the hot path consumes -- the list of AmrBox with cell data in HBM, the
-scalar transform, the bounds and the normalised scalar range, i.e. the fields of
-VolumeRenderer::SceneGeometry (VolumeRenderer/VolumeRenderer.hpp:74-89) -- and `render` validates
-its arguments exactly as the reference does and then reports that plotfile ingestion is not
-available.
+Both entries run end to end: `render` / `run` read an AMReX plotfile without AMReX
+(plotfile.py: Header, Cell_H, FAB files; our own convexify -- see DESIGN.md 6e for the one known
+divergence from amrex::convexify's box list), build the scene statistics and the scalar transform
+with the HIP scan kernels, and hand the fields of VolumeRenderer::SceneGeometry
+(VolumeRenderer/VolumeRenderer.hpp:74-89) to `render_scene`; `render_amr_data` is api::Render
+over plain per-level box lists and cell arrays (an amrex::MultiFab cannot be taken without AMReX).
+Arguments are validated exactly as the reference does.
 """
 from __future__ import annotations
 
@@ -346,15 +346,19 @@ def finalize_runtime() -> None:
 
 
 def _runtime_scope():
-    """(context, rank, world size, process group) of the initialised runtime, or a fresh
-    single-GPU context (the reference's RuntimeScope initialises on demand, module.cpp:86-101)."""
-    from . import runtime
+    """(context, rank, world size, process group) of the runtime.  Like the reference's
+    RuntimeScope (module.cpp:86-101) a call without a prior initialize_runtime() initialises on
+    demand -- honouring LOCAL_RANK / RANK / WORLD_SIZE, so that under a one-process-per-GPU
+    launcher every process renders its own share on its own GPU -- and that on-demand
+    initialisation stays for the life of the process (MPI cannot be re-initialised either)."""
     if _runtime["ctx"] is None:
-        return runtime.Context(0), 0, 1, None
+        initialize_runtime()
     rank, world, group = 0, 1, None
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         rank, world, group = dist.get_rank(), dist.get_world_size(), dist.group.WORLD
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise RuntimeError("WORLD_SIZE > 1 but no process group could be initialised")
     return _runtime["ctx"], rank, world, group
 
 
