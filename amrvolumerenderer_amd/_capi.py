@@ -105,6 +105,7 @@ SIGNATURES = {
     "avr_context_destroy": (None, [_vp]),
     "avr_context_set_stream": (C.c_int, [_vp, _vp]),
     "avr_context_set_march_occupancy": (C.c_int, [_vp, C.c_int]),
+    "avr_context_set_march_counters": (C.c_int, [_vp, _vp]),
     "avr_context_synchronize": (C.c_int, [_vp]),
     "avr_build_color_table": (C.c_int, [C.c_float, C.c_float, _fp, C.POINTER(ColormapPoint),
                                          C.c_int, _fp]),

@@ -210,6 +210,7 @@ struct avr_context {
   avr_scene scratch_scene;         // classified storage of avr_paint_box
   std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
   int march_workgroups_per_cu = 0;             // 0 = uncapped
+  uint64_t* march_counters = nullptr;          // diagnostics (avr_context_set_march_counters)
 };
 
 
@@ -354,6 +355,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.run_blocks_dev = staging.add(run_blocks.data(), run_blocks.size());
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
+    launch.counters = reinterpret_cast<unsigned long long*>(ctx->march_counters);
     launch.items_dev = staging.add(items.data(), items.size());
     launch.n_items = static_cast<uint32_t>(items.size());
     launch.workgroups_per_cu = ctx->march_workgroups_per_cu;
@@ -423,6 +425,14 @@ int avr_context_set_march_occupancy(avr_context* ctx, int workgroups_per_cu) {
     require(ctx != nullptr, "null context");
     require(workgroups_per_cu >= 0 && workgroups_per_cu <= 8, "workgroups_per_cu must be in [0, 8]");
     ctx->march_workgroups_per_cu = (workgroups_per_cu == 8) ? 0 : workgroups_per_cu;
+    return AVR_OK;
+  });
+}
+
+int avr_context_set_march_counters(avr_context* ctx, uint64_t* counters_dev) {
+  return guarded([&]() -> int {
+    require(ctx != nullptr, "null context");
+    ctx->march_counters = counters_dev;
     return AVR_OK;
   });
 }

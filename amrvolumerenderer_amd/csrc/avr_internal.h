@@ -136,6 +136,7 @@ struct RenderLaunch {
   const RunBlockDev* run_blocks_dev;  // n_runs x n_pieces
   float* out_layers;
   unsigned long long* samples_out;  // may be null
+  unsigned long long* counters;     // diagnostics (4 x uint64), only read when samples_out is set
   uint8_t* classified;              // frame's classified buffer (FramePlan::classified_bytes)
   const uint32_t* tile_begin_dev;   // n_boxes + 1 prefix of classify workgroups
   int n_boxes;

@@ -147,10 +147,11 @@ __device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_
 // exact-divide path restates the reference literally.
 // (qx, qy, qz) = (pos - min) * (1 / spacing), already computed by the caller.  CLAMP = false:
 // the caller knows the truncated quotients are <= n - 1 (see the interior loop of march_box).
-template <int MODE, bool CLAMP>
+template <int MODE, bool CLAMP, bool STATS>
 __device__ __forceinline__ uint32_t offset_from_quotients(const BoxDev& box, uint32_t row_pitch,
                                                           uint32_t plane_pitch, float qx, float qy,
-                                                          float qz, float fx, float fy, float fz) {
+                                                          float qz, float fx, float fy, float fz,
+                                                          unsigned& near_hits) {
   int i = static_cast<int>(qx);
   int j = static_cast<int>(qy);
   int k = static_cast<int>(qz);
@@ -166,6 +167,7 @@ __device__ __forceinline__ uint32_t offset_from_quotients(const BoxDev& box, uin
     const float ey = fabsf(qy - rintf(qy));
     const float ez = fabsf(qz - rintf(qz));
     if (fminf(fminf(ex, ey), ez) <= box.near_tol) {
+      if (STATS) ++near_hits;
       int ei = static_cast<int>(floorf(fx / box.dx));
       int ej = static_cast<int>(floorf(fy / box.dy));
       int ek = static_cast<int>(floorf(fz / box.dz));
@@ -177,10 +179,10 @@ __device__ __forceinline__ uint32_t offset_from_quotients(const BoxDev& box, uin
   return bricklet_offset(i, j, k, row_pitch, plane_pitch);
 }
 
-template <int MODE>
+template <int MODE, bool STATS>
 __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, uint32_t row_pitch,
                                                 uint32_t plane_pitch, float fx, float fy,
-                                                float fz) {
+                                                float fz, unsigned& near_hits) {
   if (MODE == kExactDivide) {  // the reference, literally
     int ei = static_cast<int>(floorf(fx / box.dx));
     int ej = static_cast<int>(floorf(fy / box.dy));
@@ -190,8 +192,9 @@ __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, uint32_t row_
     ek = (ek < 0) ? 0 : ((ek >= box.nz) ? box.nz - 1 : ek);
     return bricklet_offset(ei, ej, ek, row_pitch, plane_pitch);
   }
-  return offset_from_quotients<MODE, true>(box, row_pitch, plane_pitch, fx * box.inv_dx,
-                                           fy * box.inv_dy, fz * box.inv_dz, fx, fy, fz);
+  return offset_from_quotients<MODE, true, STATS>(box, row_pitch, plane_pitch, fx * box.inv_dx,
+                                                  fy * box.inv_dy, fz * box.inv_dz, fx, fy, fz,
+                                                  near_hits);
 }
 
 // Two floats handled by one packed instruction (v_pk_mul_f32 / v_pk_add_f32: each half is an
@@ -204,7 +207,8 @@ template <bool STATS, int MODE>
 __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts& fc,
                                             const uint8_t* __restrict__ classified,
                                             const float4* __restrict__ table, const Ray& ray,
-                                            float tmin, float tmax, unsigned& fetches) {
+                                            float tmin, float tmax, unsigned& fetches,
+                                            unsigned& near_hits) {
   const float min_x = box.minc[0], min_y = box.minc[1], min_z = box.minc[2];
   const float max_x = box.maxc[0], max_y = box.maxc[1], max_z = box.maxc[2];
   const float step = box.sample_dist;
@@ -272,14 +276,22 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
       if (!(d4 < safe_end)) break;
       uint32_t off1, off2, off3, off4;
       if (MODE == kExactDivide) {
-        off1 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d1) - min_x,
-                                 (ray.oy + ray.dy * d1) - min_y, (ray.oz + ray.dz * d1) - min_z);
-        off2 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d2) - min_x,
-                                 (ray.oy + ray.dy * d2) - min_y, (ray.oz + ray.dz * d2) - min_z);
-        off3 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d3) - min_x,
-                                 (ray.oy + ray.dy * d3) - min_y, (ray.oz + ray.dz * d3) - min_z);
-        off4 = cell_offset<MODE>(box, row_pitch, plane_pitch, (ray.ox + ray.dx * d4) - min_x,
-                                 (ray.oy + ray.dy * d4) - min_y, (ray.oz + ray.dz * d4) - min_z);
+        off1 = cell_offset<MODE, STATS>(box, row_pitch, plane_pitch,
+                                        (ray.ox + ray.dx * d1) - min_x,
+                                        (ray.oy + ray.dy * d1) - min_y,
+                                        (ray.oz + ray.dz * d1) - min_z, near_hits);
+        off2 = cell_offset<MODE, STATS>(box, row_pitch, plane_pitch,
+                                        (ray.ox + ray.dx * d2) - min_x,
+                                        (ray.oy + ray.dy * d2) - min_y,
+                                        (ray.oz + ray.dz * d2) - min_z, near_hits);
+        off3 = cell_offset<MODE, STATS>(box, row_pitch, plane_pitch,
+                                        (ray.ox + ray.dx * d3) - min_x,
+                                        (ray.oy + ray.dy * d3) - min_y,
+                                        (ray.oz + ray.dz * d3) - min_z, near_hits);
+        off4 = cell_offset<MODE, STATS>(box, row_pitch, plane_pitch,
+                                        (ray.ox + ray.dx * d4) - min_x,
+                                        (ray.oy + ray.dy * d4) - min_y,
+                                        (ray.oz + ray.dz * d4) - min_z, near_hits);
       } else {
         // the same expressions as the scalar path, two samples per packed instruction
         const float_pair d12 = {d1, d2}, d34 = {d3, d4};
@@ -289,14 +301,18 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
         const float_pair qx12 = fx12 * box.inv_dx, qx34 = fx34 * box.inv_dx;
         const float_pair qy12 = fy12 * box.inv_dy, qy34 = fy34 * box.inv_dy;
         const float_pair qz12 = fz12 * box.inv_dz, qz34 = fz34 * box.inv_dz;
-        off1 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx12.x, qy12.x,
-                                                  qz12.x, fx12.x, fy12.x, fz12.x);
-        off2 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx12.y, qy12.y,
-                                                  qz12.y, fx12.y, fy12.y, fz12.y);
-        off3 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx34.x, qy34.x,
-                                                  qz34.x, fx34.x, fy34.x, fz34.x);
-        off4 = offset_from_quotients<MODE, false>(box, row_pitch, plane_pitch, qx34.y, qy34.y,
-                                                  qz34.y, fx34.y, fy34.y, fz34.y);
+        off1 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx12.x,
+                                                         qy12.x, qz12.x, fx12.x, fy12.x,
+                                                         fz12.x, near_hits);
+        off2 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx12.y,
+                                                         qy12.y, qz12.y, fx12.y, fy12.y,
+                                                         fz12.y, near_hits);
+        off3 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx34.x,
+                                                         qy34.x, qz34.x, fx34.x, fy34.x,
+                                                         fz34.x, near_hits);
+        off4 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx34.y,
+                                                         qy34.y, qz34.y, fx34.y, fy34.y,
+                                                         fz34.y, near_hits);
       }
       const int idx1 = cells[off1];
       const int idx2 = cells[off2];
@@ -370,8 +386,8 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   // with an inside test reproduces both.
   while (distance < tmax && acc_a < 1.0f) {
     if (AVR_INSIDE(pos_x, pos_y, pos_z)) {
-      const uint32_t offset = cell_offset<MODE>(box, row_pitch, plane_pitch, pos_x - min_x,
-                                                pos_y - min_y, pos_z - min_z);
+      const uint32_t offset = cell_offset<MODE, STATS>(box, row_pitch, plane_pitch, pos_x - min_x,
+                                                       pos_y - min_y, pos_z - min_z, near_hits);
       // the cell's transfer-function table index, computed from the f64 cell value by the
       // classify pass of this frame (same arithmetic as VolumePainter.cpp:870-883)
       const int idx = cells[offset];
@@ -424,7 +440,7 @@ render_runs_kernel(
     const int n_runs, const int n_pieces, const RunRectDev* __restrict__ run_rects,
     const RunBlockDev* __restrict__ run_blocks, const int tiles_x, const int tiles_y,
     const MarchItemDev* __restrict__ items, float* __restrict__ out,
-    unsigned long long* samples_out) {
+    unsigned long long* samples_out, unsigned long long* counters) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
@@ -474,6 +490,9 @@ render_runs_kernel(
   const float inv_dz = 1.0f / ray.dz;
 
   unsigned fetches = 0;
+  // diagnostics of the STATS build (avr_context_set_march_counters): samples that took the exact
+  // divide because the reciprocal product sat near an integer, and samples per index mode
+  unsigned near_hits = 0, mode_fetches[3] = {0u, 0u, 0u};
   {
     const int end = run_end[run];
     Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};  // cleared layer pixel: exact blend identity
@@ -505,22 +524,28 @@ render_runs_kernel(
       if (hit) {
         const float4* table = lds_tables + box.lut * kTableSize;
         Layer5 layer;
+        const unsigned before = fetches;
+        int mode = ONLY_MODE;
         if (ONLY_MODE == kPow2Multiply) {
           layer = march_box<STATS, kPow2Multiply>(box, fc, classified, table, ray, tmin, tmax,
-                                                  fetches);
+                                                  fetches, near_hits);
         } else if (ONLY_MODE == kReciprocal) {
           layer = march_box<STATS, kReciprocal>(box, fc, classified, table, ray, tmin, tmax,
-                                                fetches);
+                                                fetches, near_hits);
         } else if (box.index_mode == kPow2Multiply) {  // wave-uniform
+          mode = kPow2Multiply;
           layer = march_box<STATS, kPow2Multiply>(box, fc, classified, table, ray, tmin, tmax,
-                                                  fetches);
+                                                  fetches, near_hits);
         } else if (box.index_mode == kReciprocal) {
+          mode = kReciprocal;
           layer = march_box<STATS, kReciprocal>(box, fc, classified, table, ray, tmin, tmax,
-                                                fetches);
+                                                fetches, near_hits);
         } else {
+          mode = kExactDivide;
           layer = march_box<STATS, kExactDivide>(box, fc, classified, table, ray, tmin, tmax,
-                                                 fetches);
+                                                 fetches, near_hits);
         }
+        if (STATS) mode_fetches[mode] += fetches - before;
         acc = blend_depthsort(acc, layer);
       }
     }
@@ -548,6 +573,17 @@ render_runs_kernel(
       total += __shfl_down(total, offset, 64);
     }
     if (lane == 0 && total != 0) atomicAdd(samples_out, total);
+    if (counters != nullptr) {
+      // counters[0] near-integer fallbacks, [1] kExactDivide, [2] kReciprocal, [3] kPow2Multiply
+      const unsigned values[4] = {near_hits, mode_fetches[kExactDivide], mode_fetches[kReciprocal],
+                                  mode_fetches[kPow2Multiply]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned long long sum = values[c];
+        for (int offset = 32; offset > 0; offset >>= 1) sum += __shfl_down(sum, offset, 64);
+        if (lane == 0 && sum != 0) atomicAdd(counters + c, sum);
+      }
+    }
   }
 }
 
@@ -1063,7 +1099,7 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
                      lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,      \
                      L.n_tables, L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces,              \
                      L.run_rects_dev, L.run_blocks_dev, tiles_x, tiles_y, L.items_dev,           \
-                     L.out_layers, L.samples_out)
+                     L.out_layers, L.samples_out, L.counters)
   if (L.only_mode == kPow2Multiply) {
     if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
   } else if (L.only_mode == kReciprocal) {

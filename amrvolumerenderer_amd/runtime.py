@@ -215,6 +215,17 @@ class Context:
         _capi.check(_capi.lib().avr_context_set_march_occupancy(self._handle,
                                                                 int(workgroups_per_cu)))
 
+    def set_march_counters(self, counters: Optional[torch.Tensor]) -> None:
+        """avr_context_set_march_counters: diagnostics for the parity tests (4 x int64 on the
+        device, or None to switch them off)."""
+        if counters is not None:
+            self._check_tensor(counters, torch.int64, "counters")
+            if counters.numel() < 4:
+                raise ValueError("counters needs 4 entries")
+        self._march_counters = counters  # keep alive while set
+        _capi.check(_capi.lib().avr_context_set_march_counters(
+            self._handle, C.c_void_p(counters.data_ptr()) if counters is not None else None))
+
     # -- helpers ----------------------------------------------------------------------------
     def _check_tensor(self, t: torch.Tensor, dtype, what: str) -> None:
         if not isinstance(t, torch.Tensor) or t.device != self.device:

@@ -4,7 +4,10 @@
 transfer function (box_transparency 0.97: full traversal, the throughput regime).
 
   python bench.py --gpus N --steps K --warmup W
-(for N > 1 launched by torch.distributed.run, one rank per GPU over RCCL).
+For N > 1 the driver launches it under torch.distributed.run (one rank per GPU over RCCL); started
+bare (no WORLD_SIZE in the environment) it launches those N ranks itself, as child processes and
+before anything in this process touches the GPU, relays rank 0's JSON line and exits with the
+children's status.
 
 A "step" is one frame: fused paint + run fold -> DirectSend exchange -> fold -> gather ->
 8-bit conversion, with all cell data already resident in HBM.  Strong scaling: the frame is
@@ -137,8 +140,53 @@ def profiled_traffic(args, world):
     return int(kib * 1024), "profiles/r1_final/pmc_summary.txt"
 
 
+def launcher_command(n_ranks, port, argv):
+    """The command the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port",
+            str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(args, argv, run=None):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as CHILD processes (never
+    an exec, and nothing here has touched the GPU or even imported torch), relay rank 0's JSON
+    line, return the children's exit status.  `run` is injectable for the launcher's unit test."""
+    import subprocess
+    # the native library is built once here (hipcc needs no GPU) instead of by N racing children
+    from amrvolumerenderer_amd import build as avr_build
+    avr_build.build()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this platform
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    command = launcher_command(args.gpus, free_port(), argv)
+    run = run or subprocess.run
+    done = run(command, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [line for line in (done.stdout or "").splitlines() if line.startswith('{"metric"')]
+    for line in (done.stdout or "").splitlines():
+        if not line.startswith('{"metric"'):
+            print(line, file=sys.stderr)
+    if done.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank launch failed with status {done.returncode}",
+              file=sys.stderr)
+        return done.returncode or 1
+    if len(lines) != 1:
+        print(f"bench.py: expected one result line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -146,10 +194,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
 
     if args.rehearse_on_one_gpu:
         local_rank = 0
@@ -226,11 +272,17 @@ def main():
     # this workload (one rank only; a rank's share of an N-rank frame runs uncapped)
     if args.march_occupancy is None and world == 1:
         renderer.autotune(rparams, cameras[0])
-    # Untimed: a short burst first brings the GPU to its working clocks and fills the allocator
-    # pools when the caller asks for very few warm-up steps (setup, like the sample counting
-    # above); then the W warm-up steps of the contract.
-    for i in range(max(0, 20 - args.warmup)):
-        step(i)
+    # Untimed setup, like the sample counting above: about a third of a second of frames brings
+    # the GPU to its working clocks and fills the allocator pools, so that a run timing very few
+    # steps (the driver's --steps 20 is a 20 ms timed region) measures the steady state a
+    # 200-step run does; then the W warm-up steps of the contract.
+    burst_end = time.perf_counter() + 0.35
+    burst = 0
+    while time.perf_counter() < burst_end or burst < 20:
+        step(burst)
+        burst += 1
+        if burst % 16 == 0:
+            renderer.synchronize()   # keep the queue short so the clock check means GPU time
     renderer.synchronize()
     for i in range(args.warmup):
         step(i)
@@ -309,7 +361,9 @@ def main():
     }
 
     out = {
-        "metric": "Mray-samples/s (2048^2 render of 512^3-base 3-level AMR)",
+        "metric": f"Mray-samples/s ({width}x{height} render of {spec.n0}^3-base "
+                  f"{spec.levels}-level AMR" + (f", antialiasing {args.antialiasing}"
+                                                 if args.antialiasing > 1 else "") + ")",
         "value": round(value, 3), "unit": "Mray-samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "frames_per_s": round(1e3 / ms_per_step, 3),

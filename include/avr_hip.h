@@ -115,6 +115,16 @@ int avr_context_synchronize(avr_context *ctx);
  * changes results. */
 int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
 
+/* Diagnostics for the parity tests: while set (device pointer to 4 x uint64; NULL = off), every
+ * march launched with a samples_out counter also ADDS
+ *   counters[0]  samples whose cell index took the exact IEEE divide of
+ *                Common/VolumePainter.cpp:846-852 because the reciprocal product lay within the
+ *                proven error bound of an integer ("Exact index without the divide"),
+ *   counters[1..3]  samples of boxes indexed by the exact divide throughout (degenerate spacing) /
+ *                by the reciprocal product / by the power-of-two product.
+ * Never changes results. */
+int avr_context_set_march_counters(avr_context *ctx, uint64_t *counters_dev);
+
 /* ---- host-side per-frame quantities (no device work) ------------------------------------- */
 
 /* buildColorTable (Common/VolumePainter.cpp:442-516): 256 RGBA entries to host memory. */

@@ -629,9 +629,14 @@ static uint64_t march_pixel(const march_consts *k, int index, float out_color[4]
   return fetches;
 }
 
-uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
-                       const orc_paint_params *params, const orc_camera *camera,
-                       float *out_rgbad, int threads) {
+/* VolumePainter::paint restricted to the pixel window [x0, x1) x [y0, y1) of the width x height
+ * image: the rays are those of the full image (pixel index y * width + x), only the loop bounds
+ * and the output addressing change; out_rgbad holds (y1 - y0) x (x1 - x0) pixels, row-major.
+ * Lets the tests check crops of frames whose full per-box layers would not fit in memory
+ * (config-5: 1856 boxes x 8192^2 x 20 B). */
+uint64_t orc_paint_box_window(const orc_box *box, const orc_transform *transform,
+                              const orc_paint_params *params, const orc_camera *camera, int x0,
+                              int y0, int x1, int y1, float *out_rgbad, int threads) {
   float sample_distance, norm_factor, alpha_scale;
   orc_box_sampling(box, params, &sample_distance, &norm_factor, &alpha_scale);
 
@@ -642,7 +647,13 @@ uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
   const int width = params->width;
   const int height = params->height;
   if (width <= 0 || height <= 0) return 0;
-  const int64_t pixel_count = (int64_t)width * height;
+  if (x0 < 0) x0 = 0;
+  if (y0 < 0) y0 = 0;
+  if (x1 > width) x1 = width;
+  if (y1 > height) y1 = height;
+  if (x1 <= x0 || y1 <= y0) return 0;
+  const int win_w = x1 - x0;
+  const int64_t pixel_count = (int64_t)win_w * (y1 - y0);
 
   march_consts k;
   memset(&k, 0, sizeof(k));
@@ -697,8 +708,8 @@ uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : total) num_threads(threads > 0 ? threads : 1)
 #endif
-  for (int y = 0; y < height; ++y) {
-    for (int x = 0; x < width; ++x) {
+  for (int y = y0; y < y1; ++y) {
+    for (int x = x0; x < x1; ++x) {
       const int index = y * width + x;
       float color[4];
       float depth;
@@ -709,7 +720,7 @@ uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
       const float b = clampf(color[2], 0.0f, 1.0f);
       const float a = clampf(color[3], 0.0f, 1.0f);
       if (!isfinite(depth) || a <= 0.0f) depth = INFINITY;
-      float *o = out_rgbad + (int64_t)index * 5;
+      float *o = out_rgbad + ((int64_t)(y - y0) * win_w + (x - x0)) * 5;
       o[0] = r;
       o[1] = g;
       o[2] = b;
@@ -718,6 +729,13 @@ uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
     }
   }
   return total;
+}
+
+uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
+                       const orc_paint_params *params, const orc_camera *camera,
+                       float *out_rgbad, int threads) {
+  return orc_paint_box_window(box, transform, params, camera, 0, 0, params->width, params->height,
+                              out_rgbad, threads);
 }
 
 /* computeBoxDepthHint, VolumeRenderer.cpp:541-553 */

@@ -94,6 +94,10 @@ void orc_box_sampling(const orc_box *box, const orc_paint_params *params,
 uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
                        const orc_paint_params *params, const orc_camera *camera,
                        float *out_rgbad, int threads);
+/* The same for the pixel window [x0, x1) x [y0, y1) only (rays of the full image). */
+uint64_t orc_paint_box_window(const orc_box *box, const orc_transform *transform,
+                              const orc_paint_params *params, const orc_camera *camera, int x0,
+                              int y0, int x1, int y1, float *out_rgbad, int threads);
 
 /* computeBoxDepthHint (VolumeRenderer/VolumeRenderer.cpp:541-553). */
 float orc_box_depth_hint(const orc_box *box, const orc_camera *camera);

@@ -103,6 +103,10 @@ def lib():
         L.orc_paint_box.argtypes = [C.POINTER(Box), C.POINTER(Transform), C.POINTER(PaintParams),
                                     C.POINTER(Camera), fp, C.c_int]
         L.orc_paint_box.restype = C.c_uint64
+        L.orc_paint_box_window.argtypes = [C.POINTER(Box), C.POINTER(Transform),
+                                           C.POINTER(PaintParams), C.POINTER(Camera), C.c_int,
+                                           C.c_int, C.c_int, C.c_int, fp, C.c_int]
+        L.orc_paint_box_window.restype = C.c_uint64
         L.orc_box_depth_hint.argtypes = [C.POINTER(Box), C.POINTER(Camera)]
         L.orc_box_depth_hint.restype = C.c_float
         L.orc_reference_sample_distance.argtypes = [C.POINTER(Box), C.c_int,
@@ -256,6 +260,17 @@ def paint_box(box: Box, transform: Transform, params: PaintParams, camera: Camer
     out = np.empty((params.height, params.width, 5), dtype=np.float32)
     n = lib().orc_paint_box(C.byref(box), C.byref(transform), C.byref(params), C.byref(camera),
                             out.ctypes.data_as(C.POINTER(C.c_float)), int(threads))
+    return out, int(n)
+
+
+def paint_box_window(box: Box, transform: Transform, params: PaintParams, camera: Camera,
+                     x0: int, y0: int, x1: int, y1: int, threads: int = 1):
+    """VolumePainter::paint for the pixel window [x0, x1) x [y0, y1) of the full image.
+    Returns (image[y1 - y0, x1 - x0, 5] float32, executed cell fetches in the window)."""
+    out = np.empty((y1 - y0, x1 - x0, 5), dtype=np.float32)
+    n = lib().orc_paint_box_window(C.byref(box), C.byref(transform), C.byref(params),
+                                   C.byref(camera), int(x0), int(y0), int(x1), int(y1),
+                                   out.ctypes.data_as(C.POINTER(C.c_float)), int(threads))
     return out, int(n)
 
 

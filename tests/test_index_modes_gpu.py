@@ -1,0 +1,151 @@
+"""Randomised parity stress of the march's cell-index paths (csrc/avr_kernels.hip,
+offset_from_quotients / cell_offset) against the oracle's literal floor((pos - min) / dx)
+(Common/VolumePainter.cpp:846-867):
+
+  kReciprocal   non-power-of-two spacings: (pos - min) * RN(1/dx), with the exact divide taken
+                whenever the product is within near_tol of an integer ("Exact index
+                without the divide") -- 240 random boxes x cameras, including grazing rays,
+                eyes inside the box and axis-parallel views;
+  kExactDivide  degenerate spacing (1/dx overflows): the reference's divide, literally.
+
+Bit-exact layers and equal sample counts; the diagnostic march counters prove that the
+near-integer fallback and the exact-divide mode were actually taken.
+"""
+import numpy as np
+import pytest
+import torch
+
+from amrvolumerenderer_amd.types import (AmrBox, CameraParameters, ScalarTransform, VolumeBounds,
+                                         make_params)
+
+from helpers import assert_bit_equal, device_box, oracle_camera, oracle_params, oracle_transform
+
+pytestmark = pytest.mark.gpu
+NORM = ScalarTransform(normalize_to_unit_range=True)
+
+
+def random_case(rng, kind):
+    dims = tuple(int(v) for v in rng.integers(3, 41, size=3))          # nx, ny, nz
+    lo = rng.uniform(-0.4, 0.4, size=3)
+    ext = rng.uniform(0.15, 1.3, size=3)
+    # make sure no spacing is a power of two (it would select kPow2Multiply)
+    for a in range(3):
+        dx = np.float32(np.float32(lo[a] + ext[a]) - np.float32(lo[a])) / np.float32(dims[a])
+        mant, _ = np.frexp(dx)
+        if mant == 0.5:
+            ext[a] *= 1.0137
+    hi = lo + ext
+    centre = 0.5 * (lo + hi)
+    cells = rng.random((dims[2], dims[1], dims[0]))
+    if kind == "outside":
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        eye = centre + direction * rng.uniform(1.2, 3.0) * float(np.linalg.norm(ext))
+        look = centre + rng.uniform(-0.1, 0.1, size=3) * ext
+        fov = float(rng.uniform(20.0, 70.0))
+    elif kind == "inside":
+        eye = lo + rng.uniform(0.1, 0.9, size=3) * ext
+        look = eye + rng.normal(size=3)
+        fov = float(rng.uniform(40.0, 100.0))
+    elif kind == "grazing":
+        # the eye in the plane of a face, looking along it: rays skim the face at tiny angles
+        axis = int(rng.integers(0, 3))
+        face = (lo, hi)[int(rng.integers(0, 2))][axis]
+        other = [a for a in range(3) if a != axis]
+        eye = centre.copy()
+        eye[axis] = face + rng.choice([0.0, 1e-6, -1e-6, 1e-4]) * ext[axis]
+        eye[other[0]] = lo[other[0]] - rng.uniform(0.2, 1.0) * ext[other[0]]
+        look = centre.copy()
+        look[axis] = eye[axis]
+        fov = float(rng.uniform(10.0, 50.0))
+    else:  # axis-parallel view: direction components of exactly zero on the centre rays
+        axis = int(rng.integers(0, 3))
+        eye = centre.copy()
+        eye[axis] = hi[axis] + rng.uniform(0.5, 2.0) * ext[axis]
+        look = centre.copy()
+        fov = float(rng.uniform(15.0, 60.0))
+    up = (0.0, 1.0, 0.0) if abs((look - eye)[1]) < 0.9 * np.linalg.norm(look - eye) \
+        else (1.0, 0.0, 0.0)
+    cam = CameraParameters(tuple(float(v) for v in eye), tuple(float(v) for v in look), up, fov,
+                           0.05, 50.0)
+    size = (int(rng.integers(17, 64)), int(rng.integers(17, 56)))
+    transparency = float(rng.choice([0.0, 0.5, 0.97]))
+    return cells, tuple(float(v) for v in lo), tuple(float(v) for v in hi), cam, size, transparency
+
+
+def run_case(O, ctx, cells, lo, hi, cam, size, transparency, counters, bounds):
+    ob = O.make_box(cells, lo, hi)
+    ref = 0.5 * min((hi[a] - lo[a]) / cells.shape[2 - a] for a in range(3)) * 1.7
+    op = oracle_params(O, size[0], size[1], (0.0, 1.0), transparency, ref, bounds)
+    want, want_n = O.paint_box(ob, oracle_transform(O, NORM), op, oracle_camera(O, cam))
+    box = device_box(ctx, cells, lo, hi)
+    params = make_params(size[0], size[1], (0.0, 1.0), transparency, ref, bounds)
+    samples = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    ctx.set_march_counters(counters)
+    try:
+        got = ctx.paint_box(box, NORM, params, cam, samples=samples)
+        ctx.synchronize()
+    finally:
+        ctx.set_march_counters(None)
+    assert_bit_equal(got.cpu().numpy(), want, "paint_box")
+    assert int(samples.item()) == want_n
+    return want_n
+
+
+@pytest.mark.parametrize("kind,seed", [("outside", 1), ("inside", 2), ("grazing", 3),
+                                       ("parallel", 4)])
+def test_reciprocal_index_path_random_boxes(O, ctx, kind, seed):
+    rng = np.random.default_rng(1000 + seed)
+    bounds = VolumeBounds((-1.0,) * 3, (2.0,) * 3)
+    counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    total = 0
+    for _ in range(60):
+        total += run_case(O, ctx, *random_case(rng, kind), counters, bounds)
+    near, exact_mode, reciprocal_mode = (int(v) for v in counters.cpu()[:3])
+    assert total > 100_000
+    assert reciprocal_mode == total and exact_mode == 0     # every box took kReciprocal
+    if kind != "grazing":
+        # samples whose product sat within near_tol of an integer and took the exact divide
+        assert 0 < near < 0.02 * total, (near, total)
+
+
+def test_near_integer_fallback_is_decisive(O, ctx):
+    """Rays parallel to an axis through cell faces: every sample's quotient on the other axes is
+    constant, and the entry sample sits right on cell boundaries.  The fallback must fire."""
+    rng = np.random.default_rng(77)
+    bounds = VolumeBounds((-1.0,) * 3, (2.0,) * 3)
+    counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    cells = rng.random((12, 12, 12))
+    lo, hi = (0.0, 0.0, 0.0), (0.9, 0.9, 0.9)       # dx = 0.075: 1/dx is not a float
+    # orthographic-like: far eye, tiny fov, looking down -z; pixel rays hit x, y = k * dx exactly
+    cam = CameraParameters((0.45, 0.45, 40.0), (0.45, 0.45, 0.0), (0.0, 1.0, 0.0), 1.3, 0.05, 90.0)
+    n = run_case(O, ctx, cells, lo, hi, cam, (48, 48), 0.9, counters, bounds)
+    assert n > 10_000 and int(counters[0].item()) > 0
+
+
+def test_exact_divide_mode_degenerate_spacing(O, ctx):
+    """A slab whose x extent is subnormal: dx = 5e-40 is positive and finite but 1/dx overflows,
+    so the host selects kExactDivide (csrc/avr_host.cpp, plan_frame) and the march evaluates
+    (pos - min) / dx with the IEEE divide, as VolumePainter.cpp:846-852 does.  A one-column image
+    looking down -z from x = 0 gives rays with dir.x == 0 and pos.x == 0 exactly, inside the
+    slab's closed bounds."""
+    rng = np.random.default_rng(5)
+    bounds = VolumeBounds((-0.05,) * 3, (1.05,) * 3)
+    counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    cells = rng.random((16, 16, 4))   # nz, ny, nx
+    lo, hi = (-1e-39, 0.0, 0.0), (1e-39, 1.0, 1.0)
+    cam = CameraParameters((0.0, 0.5, 3.0), (0.0, 0.5, 0.5), (0.0, 1.0, 0.0), 30.0, 0.05, 20.0)
+    for transparency in (0.0, 0.9):
+        n = run_case(O, ctx, cells, lo, hi, cam, (1, 64), transparency, counters, bounds)
+        assert n > 100
+    near, exact_mode, reciprocal_mode = (int(v) for v in counters.cpu()[:3])
+    assert exact_mode > 200 and reciprocal_mode == 0
+    # the x index of every sample is floor(1e-39 / 5e-40) = 2: the layer differs from the one
+    # painted with column 2 replaced, and equals itself with the other columns replaced
+    ob_cells = cells.copy()
+    ob_cells[:, :, [0, 1, 3]] = 0.123
+    params = make_params(1, 64, (0.0, 1.0), 0.9, 0.03, bounds)
+    a = ctx.paint_box(device_box(ctx, cells, lo, hi), NORM, params, cam)
+    b = ctx.paint_box(device_box(ctx, ob_cells, lo, hi), NORM, params, cam)
+    ctx.synchronize()
+    assert torch.equal(a, b) and float(a[..., 3].max()) > 0.0
