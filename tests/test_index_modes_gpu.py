@@ -73,9 +73,10 @@ def random_case(rng, kind):
     return cells, tuple(float(v) for v in lo), tuple(float(v) for v in hi), cam, size, transparency
 
 
-def run_case(O, ctx, cells, lo, hi, cam, size, transparency, counters, bounds):
+def run_case(O, ctx, cells, lo, hi, cam, size, transparency, counters, bounds, ref=None):
     ob = O.make_box(cells, lo, hi)
-    ref = 0.5 * min((hi[a] - lo[a]) / cells.shape[2 - a] for a in range(3)) * 1.7
+    if ref is None:
+        ref = 0.5 * min((hi[a] - lo[a]) / cells.shape[2 - a] for a in range(3)) * 1.7
     op = oracle_params(O, size[0], size[1], (0.0, 1.0), transparency, ref, bounds)
     want, want_n = O.paint_box(ob, oracle_transform(O, NORM), op, oracle_camera(O, cam))
     box = device_box(ctx, cells, lo, hi)
@@ -110,17 +111,28 @@ def test_reciprocal_index_path_random_boxes(O, ctx, kind, seed):
 
 
 def test_near_integer_fallback_is_decisive(O, ctx):
-    """Rays parallel to an axis through cell faces: every sample's quotient on the other axes is
-    constant, and the entry sample sits right on cell boundaries.  The fallback must fire."""
+    """A one-column image looking down -z: every ray has dir.x == 0 exactly and pos.x == eye.x.
+    With eye.x = RN(k * dx) the quotient (pos.x - min.x) / dx rounds to k or to the float just
+    below k -- the one place where the reciprocal product may floor differently from the IEEE
+    divide -- so EVERY sample must take the exact-divide fallback and still match the oracle."""
     rng = np.random.default_rng(77)
     bounds = VolumeBounds((-1.0,) * 3, (2.0,) * 3)
-    counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
     cells = rng.random((12, 12, 12))
-    lo, hi = (0.0, 0.0, 0.0), (0.9, 0.9, 0.9)       # dx = 0.075: 1/dx is not a float
-    # orthographic-like: far eye, tiny fov, looking down -z; pixel rays hit x, y = k * dx exactly
-    cam = CameraParameters((0.45, 0.45, 40.0), (0.45, 0.45, 0.0), (0.0, 1.0, 0.0), 1.3, 0.05, 90.0)
-    n = run_case(O, ctx, cells, lo, hi, cam, (48, 48), 0.9, counters, bounds)
-    assert n > 10_000 and int(counters[0].item()) > 0
+    lo, hi = (0.0, 0.0, 0.0), (0.9, 0.9, 0.9)
+    dx = np.float32(np.float32(0.9) - np.float32(0.0)) / np.float32(12)   # 1/dx is not a float
+    hits = 0
+    for k in range(1, 12):
+        for nudge in (0, 1, -1):    # RN(k dx) and its float neighbours
+            eye_x = np.float32(np.float32(k) * dx)
+            eye_x = np.nextafter(eye_x, np.float32(np.inf * nudge)) if nudge else eye_x
+            counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+            cam = CameraParameters((float(eye_x), 0.45, 4.0), (float(eye_x), 0.45, 0.0),
+                                   (0.0, 1.0, 0.0), 10.0, 0.05, 90.0)
+            n = run_case(O, ctx, cells, lo, hi, cam, (1, 48), 0.9, counters, bounds)
+            assert n > 500
+            assert int(counters[0].item()) == n   # every sample sat on the cell boundary
+            hits += n
+    assert hits > 20_000
 
 
 def test_exact_divide_mode_degenerate_spacing(O, ctx):
@@ -135,11 +147,13 @@ def test_exact_divide_mode_degenerate_spacing(O, ctx):
     cells = rng.random((16, 16, 4))   # nz, ny, nx
     lo, hi = (-1e-39, 0.0, 0.0), (1e-39, 1.0, 1.0)
     cam = CameraParameters((0.0, 0.5, 3.0), (0.0, 0.5, 0.5), (0.0, 1.0, 0.0), 30.0, 0.05, 20.0)
+    total = 0
     for transparency in (0.0, 0.9):
-        n = run_case(O, ctx, cells, lo, hi, cam, (1, 64), transparency, counters, bounds)
-        assert n > 100
+        # the step is max(0.5 * 5e-40, 1e-5) = 1e-5: ~1e5 samples along each ray
+        total += run_case(O, ctx, cells, lo, hi, cam, (1, 64), transparency, counters, bounds,
+                          ref=0.03)
     near, exact_mode, reciprocal_mode = (int(v) for v in counters.cpu()[:3])
-    assert exact_mode > 200 and reciprocal_mode == 0
+    assert exact_mode == total > 1_000_000 and reciprocal_mode == 0
     # the x index of every sample is floor(1e-39 / 5e-40) = 2: the layer differs from the one
     # painted with column 2 replaced, and equals itself with the other columns replaced
     ob_cells = cells.copy()
