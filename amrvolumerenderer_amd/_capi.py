@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libavr_hip.so")
+# AVR_HIP_LIBRARY: developer override used by the kernel A/B tools (tools/ab_march.sh) to load
+# another build of the SAME library; there is still no fallback of any kind.
+LIB_PATH = os.environ.get("AVR_HIP_LIBRARY") or os.path.join(_HERE, "libavr_hip.so")
 
 AVR_OK = 0
 AVR_ERR_INVALID_ARGUMENT = -1
@@ -178,6 +180,11 @@ def lib():
             raise AvrError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: torch (device memory, streams, RCCL for the Python layer)
+        # ships its own libamdhip64 and must be loaded first, so that this library binds to the
+        # same runtime instead of bringing the system copy in beside it -- with two runtimes in
+        # one process the one loaded second reports no device.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -309,13 +309,12 @@ def _libm_float(name: str):
 _runtime = {"refs": 0, "ctx": None, "owns_group": False}
 
 
-def initialize_runtime() -> None:
-    """amrVolumeRenderer.initialize_runtime (module.cpp:103-107): set the process up once ahead
-    of several render() / compute_histogram() calls -- here the rendering context on the local
-    GPU and, when launched with one process per GPU (WORLD_SIZE > 1), the RCCL process group."""
+def _ensure_runtime() -> None:
+    """ensure_runtime_initialized (module.cpp:35-66): the rendering context on the local GPU and,
+    when launched with one process per GPU (WORLD_SIZE > 1), the RCCL process group."""
     from . import runtime
     import torch
-    if _runtime["refs"] == 0:
+    if _runtime["ctx"] is None:
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
         torch.cuda.set_device(local_rank)
@@ -326,6 +325,12 @@ def initialize_runtime() -> None:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
                 _runtime["owns_group"] = True
         _runtime["ctx"] = runtime.Context(local_rank)
+
+
+def initialize_runtime() -> None:
+    """amrVolumeRenderer.initialize_runtime (module.cpp:103-107): set the process up once ahead
+    of several render() / compute_histogram() calls (reference counted)."""
+    _ensure_runtime()
     _runtime["refs"] += 1
 
 
@@ -349,10 +354,11 @@ def _runtime_scope():
     """(context, rank, world size, process group) of the runtime.  Like the reference's
     RuntimeScope (module.cpp:86-101) a call without a prior initialize_runtime() initialises on
     demand -- honouring LOCAL_RANK / RANK / WORLD_SIZE, so that under a one-process-per-GPU
-    launcher every process renders its own share on its own GPU -- and that on-demand
-    initialisation stays for the life of the process (MPI cannot be re-initialised either)."""
-    if _runtime["ctx"] is None:
-        initialize_runtime()
+    launcher every process renders its own share on its own GPU.  Unlike the reference's scope
+    (which finalises MPI on exit when no manual reference is held, after which nothing can be
+    initialised again) the on-demand runtime stays until finalize_runtime drops the last manual
+    reference or the process ends."""
+    _ensure_runtime()
     rank, world, group = 0, 1, None
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

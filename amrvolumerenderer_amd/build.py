@@ -22,6 +22,8 @@ def is_stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into amrvolumerenderer_amd/libavr_hip.so."""
+    if os.environ.get("AVR_HIP_LIBRARY"):
+        return os.environ["AVR_HIP_LIBRARY"]   # an explicitly chosen build (A/B tools)
     if force or is_stale():
         cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
         subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)

@@ -298,6 +298,22 @@ bool is_power_of_two(float v) {
   return std::frexp(v, &exponent) == 0.5f;
 }
 
+// kPow2Multiply evaluates the quotient as fma(pos, 1/d, -min/d).  With 1/d = 2^k the exact value
+// pos * 2^k - min * 2^k = (pos - min) * 2^k is rounded once, and RN(x * 2^k) = RN(x) * 2^k as
+// long as neither side is subnormal or overflows; a difference of two floats that IS subnormal
+// is exact, so only the magnitudes have to be bounded: every corner is 0 or in [2^-60, 2^60]
+// and so is 1/d.  Anything else (never a real data set) takes the unfused kReciprocal path.
+bool fold_is_exact(const BoxDev& dev) {
+  auto bounded = [](float v) {
+    const float a = std::fabs(v);
+    return a == 0.0f || (a >= 0x1p-60f && a <= 0x1p60f);
+  };
+  for (int axis = 0; axis < 3; ++axis) {
+    if (!bounded(dev.minc[axis]) || !bounded(dev.maxc[axis])) return false;
+  }
+  return bounded(dev.inv_dx) && bounded(dev.inv_dy) && bounded(dev.inv_dz);
+}
+
 // Conservative screen rectangle of a box: every pixel whose forward ray can intersect the box
 // lies inside.  Pixels outside produce the empty layer pixel (0,0,0,0,+inf) in the reference
 // (slab miss, or an intersection interval entirely behind the eye: VolumePainter.cpp:802-837),
@@ -877,8 +893,8 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
       const uint64_t chunks = static_cast<uint64_t>((dev.nx + kClassifyChunk - 1) / kClassifyChunk);
       const uint64_t tiles = bricks_y * bricks_z * chunks;
       // 24-bit multiplies in the bricklet address arithmetic of the march
-      if (bricks_x * bricks_y * kBrickBytes >= (uint64_t{1} << 24)) {
-        throw std::invalid_argument("box cross-section too large (ceil(nx/8)*ceil(ny/4) >= 2^17)");
+      if (bricks_z * bricks_y * kBrickBytes >= (uint64_t{1} << 24)) {
+        throw std::invalid_argument("box cross-section too large (ceil(ny/4)*ceil(nz/4) >= 2^17)");
       }
       const uint64_t total_tiles = plan->classify_tile_begin[static_cast<std::size_t>(b)] + tiles;
       if (total_tiles >= (uint64_t{1} << 31)) throw std::invalid_argument("scene has too many cells");
@@ -898,8 +914,12 @@ void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& t
                          std::isfinite(dev.inv_dz);
     if (!regular) {
       dev.index_mode = kExactDivide;
-    } else if (is_power_of_two(dev.dx) && is_power_of_two(dev.dy) && is_power_of_two(dev.dz)) {
+    } else if (is_power_of_two(dev.dx) && is_power_of_two(dev.dy) && is_power_of_two(dev.dz) &&
+               fold_is_exact(dev)) {
       dev.index_mode = kPow2Multiply;
+      dev.nmin_inv[0] = -(dev.minc[0] * dev.inv_dx);
+      dev.nmin_inv[1] = -(dev.minc[1] * dev.inv_dy);
+      dev.nmin_inv[2] = -(dev.minc[2] * dev.inv_dz);
     } else {
       dev.index_mode = kReciprocal;
     }

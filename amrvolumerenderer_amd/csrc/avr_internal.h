@@ -17,7 +17,9 @@ constexpr int kMaxLdsTables = 16;  // transfer-function tables staged in LDS per
 // Cell index = floor((pos - min) / dx) with an IEEE divide in the reference
 // (Common/VolumePainter.cpp:846-852).  The same integer is obtained cheaper when provable:
 enum IndexMode : int32_t {
-  kPow2Multiply = 0,  // dx is a power of two: (pos - min) * (1/dx) IS the correctly rounded quotient
+  kPow2Multiply = 0,  // dx is a power of two: (pos - min) * (1/dx) IS the correctly rounded quotient,
+                      // and so is fma(pos, 1/dx, -min/dx): scaling by 2^k commutes with rounding
+                      // (the host admits the mode only for magnitudes where nothing is subnormal)
   kReciprocal = 1,    // q = (pos - min) * RN(1/dx) is within 2^-22 * q of the rounded quotient, so
                       // floor(q) is the reference's index unless q is within near_tol of an
                       // integer; those samples take the exact divide
@@ -43,8 +45,10 @@ struct alignas(16) BoxDev {
   float near_tol;         // kReciprocal: |q - rint(q)| <= near_tol sends the sample to the exact divide
   int32_t pad_;
   uint64_t cls_offset;    // byte offset of this box's classified bricklets in the frame's buffer
+  float nmin_inv[3];      // kPow2Multiply: -(minc * inv_d), exact (a power-of-two scaling)
+  int32_t pad2_;
 };
-static_assert(sizeof(BoxDev) == 128, "BoxDev must stay one 128-byte record");
+static_assert(sizeof(BoxDev) == 144, "BoxDev is read with scalar loads: keep it a multiple of 16 bytes");
 
 // Frame constants (camera basis, scalar mapping); passed to kernels by value (kernarg -> SGPRs).
 struct FrameConsts {
@@ -58,7 +62,8 @@ struct FrameConsts {
 };
 
 // Classified volume: every cell's transfer-function table index (uint8) in 128-byte bricklets
-// of 8 x 4 x 4 cells (x fastest inside a bricklet; bricklets x-fastest inside the box).
+// of 8 x 4 x 4 cells (x fastest inside a bricklet; bricklets z-fastest, then y, then x inside the
+// box: see bricklet_offset in avr_kernels.hip).
 constexpr int kBrickX = 8, kBrickY = 4, kBrickZ = 4, kBrickBytes = 128;
 constexpr int kClassifyChunk = 128;  // cells of one x-row handled by one classify workgroup
 

@@ -120,24 +120,25 @@ __device__ __forceinline__ void slab_axis(float origin, float direction, float i
 }
 
 // Byte offset of cell (i, j, k) inside a box's classified volume: 128-byte bricklets of
-// 8 x 4 x 4 cells, so that the cells a bundle of neighbouring rays touches over several steps
-// share cache lines in all three directions (an x-fastest row would only help along x).
-__device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_t row_pitch,
-                                                    uint32_t plane_pitch) {
-  // ((k>>2)*by + (j>>2))*bx*128 + (i>>3)*128 + (k&3)*32 + (j&3)*8 + (i&7)
-  //   = i + (i>>3)*120  +  j*8 + (j>>2)*(bx*128 - 32)  +  k*32 + (k>>2)*(by*bx*128 - 128)
-  // with row_pitch = bx*128 - 32 and plane_pitch = by*bx*128 - 128, both < 2^24 (host check),
-  // so every product is a 24-bit multiply (full-rate v_mad_u32_u24).
-  // Three shifts, two shift-adds and three 24-bit multiply-adds (the compiler otherwise splits
-  // the multiply-adds into v_mul_u32_u24 + v_add3_u32: ten instructions instead of eight).
+// 8 x 4 x 4 cells (x fastest inside), so that the cells a bundle of neighbouring rays touches over
+// several steps share cache lines in all three directions (an x-fastest row would only help
+// along x: measured 2x slower).  The bricklets themselves are ordered z fastest, then y, then x:
+//   offset = (i&7) + 8*(j&3) + 32*(k&3) + 128*((k>>2) + bz*((j>>2) + by*(i>>3)))
+// and because a bricklet is 4 cells of 32 bytes deep in z, 32*(k&3) + 128*(k>>2) = 32*k: the z
+// term needs no split at all --
+//   offset = i + 8*j + 32*k + y_pitch*(j>>2) + x_pitch*(i>>3)
+// with y_pitch = 128*bz - 32 and x_pitch = 128*bz*by - 8, both < 2^24 (host check), i.e. two
+// shifts, two shift-adds and two 24-bit multiply-adds (the march is bound by the number of
+// vector instructions; an x-fastest brick order needs two more).
+__device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_t y_pitch,
+                                                    uint32_t x_pitch) {
   const uint32_t ui = static_cast<uint32_t>(i), uj = static_cast<uint32_t>(j),
                  uk = static_cast<uint32_t>(k);
   uint32_t offset;
   asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(offset) : "v"(uj), "v"(ui));
   asm("v_lshl_add_u32 %0, %1, 5, %0" : "+v"(offset) : "v"(uk));
-  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(ui >> 3), "v"(120u));
-  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(uj >> 2), "s"(row_pitch));
-  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(uk >> 2), "s"(plane_pitch));
+  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(uj >> 2), "s"(y_pitch));
+  asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(offset) : "v"(ui >> 3), "s"(x_pitch));
   return offset;
 }
 
@@ -147,6 +148,10 @@ __device__ __forceinline__ uint32_t bricklet_offset(int i, int j, int k, uint32_
 // exact-divide path restates the reference literally.
 // (qx, qy, qz) = (pos - min) * (1 / spacing), already computed by the caller.  CLAMP = false:
 // the caller knows the truncated quotients are <= n - 1 (see the interior loop of march_box).
+// Two floats handled by one packed instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: each
+// half is an ordinary IEEE binary32 operation, so results equal the scalar expressions bit for bit).
+typedef float float_pair __attribute__((ext_vector_type(2)));
+
 template <int MODE, bool CLAMP, bool STATS>
 __device__ __forceinline__ uint32_t offset_from_quotients(const BoxDev& box, uint32_t row_pitch,
                                                           uint32_t plane_pitch, float qx, float qy,
@@ -197,10 +202,6 @@ __device__ __forceinline__ uint32_t cell_offset(const BoxDev& box, uint32_t row_
                                                   near_hits);
 }
 
-// Two floats handled by one packed instruction (v_pk_mul_f32 / v_pk_add_f32: each half is an
-// ordinary IEEE binary32 operation, so results equal the scalar expressions bit for bit).
-typedef float float_pair __attribute__((ext_vector_type(2)));
-
 // The march of one ray through one box (VolumePainter.cpp:811-921 + host epilogue :939-955).
 // Returns the layer pixel the reference would store for this box.
 template <bool STATS, int MODE>
@@ -214,10 +215,10 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   const float step = box.sample_dist;
   const uint8_t __attribute__((address_space(1)))* cells =
       (const uint8_t __attribute__((address_space(1)))*)(classified + box.cls_offset);
-  const uint32_t bricks_x = static_cast<uint32_t>(box.nx + kBrickX - 1) >> 3;
+  const uint32_t bricks_z = static_cast<uint32_t>(box.nz + kBrickZ - 1) >> 2;
   const uint32_t bricks_y = static_cast<uint32_t>(box.ny + kBrickY - 1) >> 2;
-  const uint32_t row_pitch = bricks_x * kBrickBytes - 32u;
-  const uint32_t plane_pitch = bricks_y * bricks_x * kBrickBytes - 128u;
+  const uint32_t row_pitch = bricks_z * kBrickBytes - 32u;              // y_pitch of bricklet_offset
+  const uint32_t plane_pitch = bricks_y * bricks_z * kBrickBytes - 8u;  // x_pitch
 
   float distance = tmin + box.mesh_eps;
   if (distance < 0.0f) distance = box.mesh_eps;
@@ -264,11 +265,20 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
   if (interior) {
     // Four steps per trip while all four lie below safe_end: the four cell bytes and the four
     // table entries are requested before the first is consumed (four memory round trips in
-    // flight per wave).  Sample k+1 is accumulated only if the reference's loop condition
-    // (accumA < 1) still holds after sample k -- done with selects, not branches, so the
-    // compiler cannot sink the later loads below the earlier accumulates.  Remaining steps
-    // below safe_end fall through to the general loop.
-    while (acc_a < 1.0f) {
+    // flight per wave).  Remaining steps below safe_end fall through to the general loop.
+    //
+    // Everything per sample is written with the full-rate vector instructions of gfx950
+    // (v_mul / v_add / v_sub / v_fma_f32, 2.25 cycles per wave instruction measured with
+    // tools/ubench/valu_rates; v_pk_*_f32, conversions, shifts-left, multiply-adds and compares
+    // take 4.15): the march is bound by vector issue, so the sum of those costs is its time.
+    const float inv_x = box.inv_dx, inv_y = box.inv_dy, inv_z = box.inv_dz;
+    // loop-invariant operand pairs of the packed fused quotient (kept in registers: a packed
+    // instruction reads at most one scalar-register operand)
+    const float_pair ix2 = {inv_x, inv_x}, iy2 = {inv_y, inv_y}, iz2 = {inv_z, inv_z};
+    float_pair nx2 = {box.nmin_inv[0], box.nmin_inv[0]}, ny2 = {box.nmin_inv[1], box.nmin_inv[1]},
+               nz2 = {box.nmin_inv[2], box.nmin_inv[2]};
+    if (MODE == kPow2Multiply) asm volatile("" : "+v"(nx2), "+v"(ny2), "+v"(nz2));
+    for (;;) {
       const float d1 = distance;
       const float d2 = d1 + step;
       const float d3 = d2 + step;
@@ -292,27 +302,47 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
                                         (ray.ox + ray.dx * d4) - min_x,
                                         (ray.oy + ray.dy * d4) - min_y,
                                         (ray.oz + ray.dz * d4) - min_z, near_hits);
+      } else if (MODE == kPow2Multiply) {
+        // q = (pos - min) * 2^k as ONE fused operation: the exact value pos * 2^k - min * 2^k is
+        // rounded once, which is RN(pos - min) * 2^k (see fold_is_exact in avr_host.cpp).  Two
+        // samples per packed instruction (v_pk_mul / v_pk_add / v_pk_fma_f32: each half is an
+        // ordinary IEEE operation): the march is bound by the NUMBER of vector instructions.
+        const float_pair d12 = {d1, d2}, d34 = {d3, d4};
+        const float_pair qx12 = __builtin_elementwise_fma(ray.ox + ray.dx * d12, ix2, nx2);
+        const float_pair qy12 = __builtin_elementwise_fma(ray.oy + ray.dy * d12, iy2, ny2);
+        const float_pair qz12 = __builtin_elementwise_fma(ray.oz + ray.dz * d12, iz2, nz2);
+        const float_pair qx34 = __builtin_elementwise_fma(ray.ox + ray.dx * d34, ix2, nx2);
+        const float_pair qy34 = __builtin_elementwise_fma(ray.oy + ray.dy * d34, iy2, ny2);
+        const float_pair qz34 = __builtin_elementwise_fma(ray.oz + ray.dz * d34, iz2, nz2);
+        off1 = bricklet_offset(static_cast<int>(qx12.x), static_cast<int>(qy12.x),
+                               static_cast<int>(qz12.x), row_pitch, plane_pitch);
+        off2 = bricklet_offset(static_cast<int>(qx12.y), static_cast<int>(qy12.y),
+                               static_cast<int>(qz12.y), row_pitch, plane_pitch);
+        off3 = bricklet_offset(static_cast<int>(qx34.x), static_cast<int>(qy34.x),
+                               static_cast<int>(qz34.x), row_pitch, plane_pitch);
+        off4 = bricklet_offset(static_cast<int>(qx34.y), static_cast<int>(qy34.y),
+                               static_cast<int>(qz34.y), row_pitch, plane_pitch);
       } else {
-        // the same expressions as the scalar path, two samples per packed instruction
+        // the reference's two roundings, (pos - min) then * RN(1/d), two samples per instruction
         const float_pair d12 = {d1, d2}, d34 = {d3, d4};
         const float_pair fx12 = (ray.ox + ray.dx * d12) - min_x, fx34 = (ray.ox + ray.dx * d34) - min_x;
         const float_pair fy12 = (ray.oy + ray.dy * d12) - min_y, fy34 = (ray.oy + ray.dy * d34) - min_y;
         const float_pair fz12 = (ray.oz + ray.dz * d12) - min_z, fz34 = (ray.oz + ray.dz * d34) - min_z;
-        const float_pair qx12 = fx12 * box.inv_dx, qx34 = fx34 * box.inv_dx;
-        const float_pair qy12 = fy12 * box.inv_dy, qy34 = fy34 * box.inv_dy;
-        const float_pair qz12 = fz12 * box.inv_dz, qz34 = fz34 * box.inv_dz;
+        const float_pair qx12 = fx12 * inv_x, qx34 = fx34 * inv_x;
+        const float_pair qy12 = fy12 * inv_y, qy34 = fy34 * inv_y;
+        const float_pair qz12 = fz12 * inv_z, qz34 = fz34 * inv_z;
         off1 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx12.x,
-                                                         qy12.x, qz12.x, fx12.x, fy12.x,
-                                                         fz12.x, near_hits);
+                                                         qy12.x, qz12.x, fx12.x, fy12.x, fz12.x,
+                                                         near_hits);
         off2 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx12.y,
-                                                         qy12.y, qz12.y, fx12.y, fy12.y,
-                                                         fz12.y, near_hits);
+                                                         qy12.y, qz12.y, fx12.y, fy12.y, fz12.y,
+                                                         near_hits);
         off3 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx34.x,
-                                                         qy34.x, qz34.x, fx34.x, fy34.x,
-                                                         fz34.x, near_hits);
+                                                         qy34.x, qz34.x, fx34.x, fy34.x, fz34.x,
+                                                         near_hits);
         off4 = offset_from_quotients<MODE, false, STATS>(box, row_pitch, plane_pitch, qx34.y,
-                                                         qy34.y, qz34.y, fx34.y, fy34.y,
-                                                         fz34.y, near_hits);
+                                                         qy34.y, qz34.y, fx34.y, fy34.y, fz34.y,
+                                                         near_hits);
       }
       const int idx1 = cells[off1];
       const int idx2 = cells[off2];
@@ -322,57 +352,67 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
       const float4 s2 = table[idx2];
       const float4 s3 = table[idx3];
       const float4 s4 = table[idx4];
-      // Fast path: accumulate all four unconditionally into copies; if no lane of the wave
-      // saturated (accumA >= 1) before its fourth sample -- the normal case -- commit them.
-      unsigned taken = 4u;
-      float next = d4 + step;
-      {
-        const float w1 = s1.w * (1.0f - acc_a);
-        const float a1 = acc_a + w1;
-        const float w2 = s2.w * (1.0f - a1);
-        const float a2 = a1 + w2;
-        const float w3 = s3.w * (1.0f - a2);
-        const float a3 = a2 + w3;
-        const bool stops_early = (a1 >= 1.0f) || (a2 >= 1.0f) || (a3 >= 1.0f);
-        if (__builtin_amdgcn_ballot_w64(stops_early) == 0) {
-          const float w4 = s4.w * (1.0f - a3);
-          const float_pair rg1 = {s1.x, s1.y}, rg2 = {s2.x, s2.y}, rg3 = {s3.x, s3.y},
-                           rg4 = {s4.x, s4.y};
-          float_pair acc_rg = {acc_r, acc_g};
-          acc_rg = (((acc_rg + rg1 * w1) + rg2 * w2) + rg3 * w3) + rg4 * w4;
-          acc_r = acc_rg.x;
-          acc_g = acc_rg.y;
-          acc_b = (((acc_b + s1.z * w1) + s2.z * w2) + s3.z * w3) + s4.z * w4;
-          acc_a = a3 + w4;
-        } else {
-          // some lane's ray terminates inside this group: per-sample selects
-          AVR_ACCUMULATE(s1);
-          taken = 1u;
-          next = d2;
-#define AVR_ACCUMULATE_IF_RUNNING(sample, following)          \
-          {                                                     \
-            const bool running_ = acc_a < 1.0f;                 \
-            const float alpha_ = (sample).w * (1.0f - acc_a);   \
-            const float r_ = acc_r + (sample).x * alpha_;       \
-            const float g_ = acc_g + (sample).y * alpha_;       \
-            const float b_ = acc_b + (sample).z * alpha_;       \
-            const float a_ = acc_a + alpha_;                    \
-            acc_r = running_ ? r_ : acc_r;                      \
-            acc_g = running_ ? g_ : acc_g;                      \
-            acc_b = running_ ? b_ : acc_b;                      \
-            acc_a = running_ ? a_ : acc_a;                      \
-            next = running_ ? (following) : next;               \
-            taken += running_ ? 1u : 0u;                        \
-          }
-          // once accumA reaches 1 it stays >= 1 (alpha >= 0), so later samples are rejected too
-          AVR_ACCUMULATE_IF_RUNNING(s2, d3)
-          AVR_ACCUMULATE_IF_RUNNING(s3, d4)
-          AVR_ACCUMULATE_IF_RUNNING(s4, d4 + step)
-#undef AVR_ACCUMULATE_IF_RUNNING
-        }
+      // accumA never decreases and never exceeds 1 (table alphas lie in [0, 1]:
+      // a + s.w * (1 - a) <= 1 also after rounding), and once it is 1 it stays 1 (the weight is
+      // then s.w * 0), so "some sample of this group found accumA >= 1" (the reference's loop exit,
+      // :837) is exactly a4 >= 1: one comparison and one wave ballot per group.  All four samples
+      // are accumulated unconditionally into copies, committed when no lane saturated.
+      // (r, g) and (b, a) are accumulated as pairs: per sample  t = 1 - a;  w = s.w * t;
+      // (r, g) += (s.x, s.y) * w;  (b, a) += (s.z * w, w)  -- six instructions, each half the
+      // reference's own operation.
+      float_pair rg = {acc_r, acc_g}, ba = {acc_b, acc_a};
+#define AVR_STEP(sample)                                                          \
+      {                                                                           \
+        const float w_ = (sample).w * (1.0f - ba.y);                              \
+        const float_pair color_ = {(sample).x, (sample).y};                       \
+        const float_pair zw_ = {(sample).z * w_, w_};                             \
+        rg = rg + color_ * w_;                                                    \
+        ba = ba + zw_;                                                            \
       }
-      distance = next;
-      if (STATS) fetches += taken;
+      AVR_STEP(s1)
+      AVR_STEP(s2)
+      AVR_STEP(s3)
+      AVR_STEP(s4)
+#undef AVR_STEP
+      if (__builtin_amdgcn_ballot_w64(ba.y >= 1.0f) == 0) {
+        // the normal case: no lane of the wave saturates inside this group
+        acc_r = rg.x;
+        acc_g = rg.y;
+        acc_b = ba.x;
+        acc_a = ba.y;
+        distance = d4 + step;
+        if (STATS) fetches += 4u;
+      } else {
+        // some lane's ray terminates inside this group: per-sample selects (sample k + 1 is
+        // accumulated only if the reference's loop condition accumA < 1 still holds after
+        // sample k; done with selects, not branches, so that the loads above stay unconditional)
+        unsigned taken = 1u;
+        float next = d2;
+        AVR_ACCUMULATE(s1);
+#define AVR_ACCUMULATE_IF_RUNNING(sample, following)          \
+        {                                                     \
+          const bool running_ = acc_a < 1.0f;                 \
+          const float alpha_ = (sample).w * (1.0f - acc_a);   \
+          const float r_ = acc_r + (sample).x * alpha_;       \
+          const float g_ = acc_g + (sample).y * alpha_;       \
+          const float b_ = acc_b + (sample).z * alpha_;       \
+          const float a_ = acc_a + alpha_;                    \
+          acc_r = running_ ? r_ : acc_r;                      \
+          acc_g = running_ ? g_ : acc_g;                      \
+          acc_b = running_ ? b_ : acc_b;                      \
+          acc_a = running_ ? a_ : acc_a;                      \
+          next = running_ ? (following) : next;               \
+          taken += running_ ? 1u : 0u;                        \
+        }
+        // once accumA reaches 1 it stays >= 1 (alpha >= 0), so later samples are rejected too
+        AVR_ACCUMULATE_IF_RUNNING(s2, d3)
+        AVR_ACCUMULATE_IF_RUNNING(s3, d4)
+        AVR_ACCUMULATE_IF_RUNNING(s4, d4 + step)
+#undef AVR_ACCUMULATE_IF_RUNNING
+        distance = next;
+        if (STATS) fetches += taken;
+        if (!(acc_a < 1.0f)) break;  // the reference's loop condition (:837)
+      }
     }
   }
 
@@ -432,7 +472,7 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
 // <= 80 SGPRs: 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16))
 // (MI355X_MICROARCH.md, "Residency"), i.e. 8 per CU only up to 80 SGPRs, 6 at 98+.
 template <bool STATS, int ONLY_MODE>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_num_sgpr(80))) void
+__global__ __launch_bounds__(kBlockThreads, 6) void
 render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
@@ -442,6 +482,9 @@ render_runs_kernel(
     const MarchItemDev* __restrict__ items, float* __restrict__ out,
     unsigned long long* samples_out, unsigned long long* counters) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
+#if defined(AVR_TIMELINE)  // diagnostic build (tools/wg_timeline.py): per-workgroup start / end / CU
+  const unsigned long long avr_exp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
   // Work item = one super-tile (2 x 2 workgroups in Morton order) of one run.  Workgroups are
@@ -478,8 +521,11 @@ render_runs_kernel(
   const int lane = static_cast<int>(threadIdx.x) & 63;
   const int wave_x0 = tile_x * kTile + (wave & 1) * 8;  // wave-uniform 8x8 sub-tile
   const int wave_y0 = tile_y * kTile + (wave >> 1) * 8;
-  const int px = wave_x0 + (lane & 7);
-  const int py = wave_y0 + (lane >> 3);
+  // lane -> pixel: every 16 consecutive lanes (the unit the texture addresser works on) cover a
+  // compact 4 x 4 pixel patch of the wave's 8 x 8 tile, not an 8 x 2 strip: fewer distinct
+  // bricklets (cache lines) per address-processing group
+  const int px = wave_x0 + (lane & 3) + ((lane >> 2) & 4);
+  const int py = wave_y0 + ((lane >> 2) & 3) + ((lane >> 3) & 4);
   const bool live = (px < fc.width) && (py < fc.height);
   const int64_t n_pixels = static_cast<int64_t>(fc.width) * fc.height;
   const int64_t p = static_cast<int64_t>(py) * fc.width + px;
@@ -567,6 +613,18 @@ render_runs_kernel(
     }
   }
 
+#if defined(AVR_TIMELINE)
+  if (counters != nullptr && threadIdx.x == 0) {
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    counters[4 * blockIdx.x + 0] = avr_exp_t0;
+    counters[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    counters[4 * blockIdx.x + 2] = (static_cast<unsigned long long>(xcc) << 32) | hw_id;
+    counters[4 * blockIdx.x + 3] = fetches;
+  }
+#endif
   if (STATS && samples_out != nullptr) {
     unsigned long long total = fetches;
     for (int offset = 32; offset > 0; offset >>= 1) {
@@ -665,7 +723,10 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const uint32_t from = whole[pass] ? at[pass] : (valid[pass] ? at[pass] - 1u : 0u);
-      raw[pass] = *(const double2_t __attribute__((address_space(1)))*)(cells + from);
+      // every f64 cell is read exactly once per frame: a streaming (non-temporal) load keeps it
+      // from evicting the classified bricklets the co-resident march gathers from L2
+      raw[pass] = __builtin_nontemporal_load(
+          (const double2_t __attribute__((address_space(1)))*)(cells + from));
     }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -690,8 +751,9 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
       const int k = bk * kBrickZ + (row >> 2);
       uint32_t idx = 0;
       if (i < nx && j < ny && k < nz) {
-        const double raw = cells[static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
-                                 static_cast<uint32_t>(k) * kstride];
+        const double raw = __builtin_nontemporal_load(
+            cells + (static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
+                     static_cast<uint32_t>(k) * kstride));
         idx = static_cast<uint32_t>(table_index<SIMPLE>(raw, fc));
       }
       uint32_t packed = idx << (8 * (t & 3));
@@ -703,17 +765,19 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     }
   }
   __syncthreads();
-  // up to 16 complete bricklets, contiguous in the box's classified volume
+  // up to 16 complete bricklets, x-neighbours: in the z-fastest brick order of bricklet_offset
+  // they lie bricks_y * bricks_z lines apart, each written as one whole 128-byte line
   const int first_brick_x = chunk * (kClassifyChunk / kBrickX);
   const int bricks_here = (bricks_x - first_brick_x < 16) ? (bricks_x - first_brick_x) : 16;
-  const uint64_t out_base =
-      box.cls_offset + ((static_cast<uint64_t>(bk) * static_cast<uint64_t>(bricks_y) +
-                         static_cast<uint64_t>(bj)) * static_cast<uint64_t>(bricks_x) +
-                        static_cast<uint64_t>(first_brick_x)) * kBrickBytes;
+  const int bricks_z = (nz + kBrickZ - 1) >> 2;
   if (t * 8 < bricks_here * kBrickBytes) {
+    const uint64_t brick = (static_cast<uint64_t>(first_brick_x + (t >> 4)) *
+                                static_cast<uint64_t>(bricks_y) + static_cast<uint64_t>(bj)) *
+                               static_cast<uint64_t>(bricks_z) + static_cast<uint64_t>(bk);
     const uint2 v =
         *reinterpret_cast<const uint2*>(&staged[(t >> 4) * kStagedStride + (t & 15) * 2]);
-    *reinterpret_cast<uint2*>(classified + out_base + static_cast<uint64_t>(t) * 8) = v;
+    *reinterpret_cast<uint2*>(classified + box.cls_offset + brick * kBrickBytes +
+                              static_cast<uint64_t>(t & 15) * 8) = v;
   }
 }
 
