@@ -95,6 +95,15 @@ class RunInfo(C.Structure):
                 ("n_layers", C.c_int32), ("rect", C.c_int32 * 4)]
 
 
+class RenderParams(C.Structure):
+    """avr_render_params."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("box_transparency", C.c_float),
+                ("antialiasing", C.c_int32), ("use_visibility_graph", C.c_int32),
+                ("draw_bounds", C.c_int32), ("write_visibility_graph", C.c_int32)]
+
+
+COMM_ID_BYTES = 128
+
 # name -> (restype, argtypes); every symbol include/avr_hip.h declares.
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -167,6 +176,34 @@ SIGNATURES = {
     "avr_fold_runs_depthsort": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _vp, _i64]),
     "avr_downsample_depthsort": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "avr_quantize_rgb8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "avr_flip_rows": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "avr_context_create_with_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "avr_context_stream": (_vp, [_vp]),
+    "avr_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "avr_comm_create": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "avr_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "avr_comm_destroy": (None, [_vp]),
+    "avr_comm_rank": (C.c_int, [_vp]),
+    "avr_comm_size": (C.c_int, [_vp]),
+    "avr_exchange": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_gather": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "avr_renderer_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(Box), _ip,
+                                       C.c_int, C.POINTER(ScalarTransform), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), _fp, C.POINTER(ColormapPoint),
+                                       C.c_int, C.POINTER(_vp)]),
+    "avr_renderer_destroy": (None, [_vp]),
+    "avr_renderer_set_options": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "avr_renderer_set_scalar_range": (C.c_int, [_vp, _fp]),
+    "avr_renderer_invalidate": (C.c_int, [_vp]),
+    "avr_renderer_reference_sample_distance": (C.c_int, [_vp, _fp]),
+    "avr_renderer_render": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip, _vp,
+                                       _vp, _vp, _vp]),
+    "avr_renderer_synchronize": (C.c_int, [_vp]),
+    "avr_renderer_stream": (_vp, [_vp, C.c_int]),
+    "avr_renderer_plan_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),
+    "avr_renderer_set_timing": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_timings": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -209,6 +209,7 @@ struct avr_context {
   avr::StagingRing staging;
   avr_scene scratch_scene;         // classified storage of avr_paint_box
   std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
+  int priority = 0;                            // 1: own stream in the highest priority class
   int march_workgroups_per_cu = 0;             // 0 = uncapped
   uint64_t* march_counters = nullptr;          // diagnostics (avr_context_set_march_counters)
 };
@@ -244,8 +245,15 @@ void bind_device(avr_context* ctx) {
   require(ctx != nullptr, "null context");
   avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
   if (ctx->stream == nullptr) {  // no external stream was supplied: create the context's own
-    avr::hip_check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
-                   "hipStreamCreate");
+    if (ctx->priority != 0) {
+      int least = 0, greatest = 0;  // numerically lower = more urgent
+      avr::hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+      avr::hip_check(hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, greatest),
+                     "hipStreamCreateWithPriority");
+    } else {
+      avr::hip_check(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking),
+                     "hipStreamCreate");
+    }
     ctx->stream = ctx->own_stream;
   }
 }
@@ -375,6 +383,13 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
 
 }  // namespace
 
+namespace avr {
+void* context_stream(avr_context* ctx) {
+  bind_device(ctx);
+  return ctx->stream;
+}
+}  // namespace avr
+
 extern "C" {
 
 const char* avr_last_error(void) { return avr::g_last_error.c_str(); }
@@ -398,6 +413,21 @@ int avr_context_create(int device_id, avr_context** out_ctx) {
     *out_ctx = ctx;
     return AVR_OK;
   });
+}
+
+int avr_context_create_with_priority(int device_id, int high_priority, avr_context** out_ctx) {
+  const int status = avr_context_create(device_id, out_ctx);
+  if (status == AVR_OK) (*out_ctx)->priority = high_priority ? 1 : 0;
+  return status;
+}
+
+void* avr_context_stream(avr_context* ctx) {
+  try {
+    return avr::context_stream(ctx);
+  } catch (const std::exception& e) {
+    avr::set_error(e.what());
+    return nullptr;
+  }
 }
 
 void avr_context_destroy(avr_context* ctx) {
@@ -967,6 +997,16 @@ int avr_downsample_depthsort(avr_context* ctx, const float* src, int target_w, i
     if (target_w == 0 || target_h == 0) return AVR_OK;
     require(src != nullptr && dst != nullptr, "null image");
     return avr::launch_downsample(src, target_w, target_h, block, dst, ctx->stream);
+  });
+}
+
+int avr_flip_rows(avr_context* ctx, const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(row_bytes >= 0 && h >= 0, "invalid image description");
+    if (row_bytes == 0 || h == 0) return AVR_OK;
+    require(src != nullptr && dst != nullptr && src != dst, "invalid image pointers");
+    return avr::launch_flip_rows(src, row_bytes, h, dst, ctx->stream);
   });
 }
 

@@ -1,0 +1,361 @@
+// Rank communicator of the sort-last compositor: the image-fragment exchange and the gather of
+// DirectSend as collectives on the GPUs' own interconnect (include/avr_hip.h, "rank
+// communicator").
+//
+// Reference: DirectSend/Base/DirectSendBase.cpp:76-177 (PostReceives / PostSends: per run,
+// N(N-1) MPI_Isend / MPI_Irecv pairs of host buffers) and Common/ImageColorOnly.hpp:220-270
+// (Gather: two MPI_Gather of ints + MPI_Gatherv of bytes).  Here: ONE grouped ncclSend / ncclRecv
+// round per frame over RCCL (xGMI, device buffers, on the compositing stream), block sizes known
+// to every rank from the replicated frame plan, so no metadata messages exist.
+//
+// RCCL is bound at run time (dlopen): a single-rank user never loads it, and inside a Python
+// process the copy torch already loaded is the one used (one runtime per process).
+//
+// The "local" flavour connects N rank objects living in ONE process on ONE GPU (one host thread
+// per rank): host-synchronous copies between the ranks' buffers.  It exists to rehearse the
+// N-rank frame where only one GPU is available (RCCL cannot place two ranks on one device); it is
+// not a performance path.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "avr_internal.h"
+#include "avr_plan.h"
+
+namespace avr {
+
+namespace {
+
+void hip_ok(hipError_t err, const char* what) {
+  if (err != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(err));
+}
+
+// ---- RCCL entry points, resolved once ----------------------------------------------------------
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+const Rccl& rccl() {
+  static Rccl api;
+  static std::once_flag once;
+  static std::string failure;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.handle != nullptr) break;
+    }
+    if (api.handle == nullptr) {
+      failure = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
+      return;
+    }
+    auto bind = [](void* handle, const char* symbol) {
+      void* fn = dlsym(handle, symbol);
+      if (fn == nullptr) failure = std::string("RCCL lacks ") + symbol;
+      return fn;
+    };
+    api.get_unique_id = reinterpret_cast<decltype(api.get_unique_id)>(bind(api.handle, "ncclGetUniqueId"));
+    api.comm_init_rank = reinterpret_cast<decltype(api.comm_init_rank)>(bind(api.handle, "ncclCommInitRank"));
+    api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(bind(api.handle, "ncclCommDestroy"));
+    api.group_start = reinterpret_cast<decltype(api.group_start)>(bind(api.handle, "ncclGroupStart"));
+    api.group_end = reinterpret_cast<decltype(api.group_end)>(bind(api.handle, "ncclGroupEnd"));
+    api.send = reinterpret_cast<decltype(api.send)>(bind(api.handle, "ncclSend"));
+    api.recv = reinterpret_cast<decltype(api.recv)>(bind(api.handle, "ncclRecv"));
+    api.error_string = reinterpret_cast<decltype(api.error_string)>(bind(api.handle, "ncclGetErrorString"));
+  });
+  if (!failure.empty()) throw std::runtime_error(failure);
+  return api;
+}
+
+void nccl_ok(ncclResult_t result, const char* what) {
+  if (result != ncclSuccess) {
+    throw std::runtime_error(std::string(what) + ": " + rccl().error_string(result));
+  }
+}
+
+// ---- in-process rehearsal communicator -------------------------------------------------------
+struct LocalWorld {
+  int n_ranks = 0;
+  std::mutex mutex;
+  std::condition_variable arrived;
+  int waiting = 0;
+  uint64_t generation = 0;
+  // what each rank publishes for the collective in flight
+  std::vector<const char*> base;              // send buffer / piece
+  std::vector<std::vector<int64_t>> offsets;  // byte offset of the block for each peer
+  std::vector<std::vector<int64_t>> sizes;    // byte size of the block for each peer
+
+  void barrier() {
+    std::unique_lock<std::mutex> lock(mutex);
+    const uint64_t mine = generation;
+    if (++waiting == n_ranks) {
+      waiting = 0;
+      ++generation;
+      arrived.notify_all();
+    } else {
+      arrived.wait(lock, [&] { return generation != mine; });
+    }
+  }
+};
+
+}  // namespace
+}  // namespace avr
+
+struct avr_comm {
+  int rank = 0;
+  int n_ranks = 1;
+  int device = 0;
+  ncclComm_t nccl = nullptr;                      // RCCL flavour
+  std::shared_ptr<avr::LocalWorld> local;         // in-process flavour
+};
+
+namespace {
+
+template <typename F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::invalid_argument& e) {
+    avr::set_error(e.what());
+    return AVR_ERR_INVALID_ARGUMENT;
+  } catch (const std::exception& e) {
+    avr::set_error(e.what());
+    return AVR_ERR_RUNTIME;
+  } catch (...) {
+    avr::set_error("unknown failure");
+    return AVR_ERR_RUNTIME;
+  }
+}
+
+void require(bool condition, const char* message) {
+  if (!condition) throw std::invalid_argument(message);
+}
+
+void check_plan(const avr_comm* comm, const avr_frame_plan* plan) {
+  require(comm != nullptr && plan != nullptr, "null argument");
+  require(plan->info.n_ranks == comm->n_ranks && plan->info.rank == comm->rank,
+          "the frame plan was made for another rank / rank count than the communicator");
+}
+
+// Waits on the host until everything queued on `stream` so far has finished.
+void drain(hipStream_t stream) { avr::hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+
+}  // namespace
+
+extern "C" {
+
+int avr_comm_unique_id(char id_out[AVR_COMM_ID_BYTES]) {
+  return guarded([&]() -> int {
+    require(id_out != nullptr, "null argument");
+    static_assert(AVR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    avr::nccl_ok(avr::rccl().get_unique_id(&id), "ncclGetUniqueId");
+    std::memcpy(id_out, id.internal, AVR_COMM_ID_BYTES);
+    return AVR_OK;
+  });
+}
+
+int avr_comm_create(int device_id, const char id[AVR_COMM_ID_BYTES], int rank, int n_ranks,
+                    avr_comm** out_comm) {
+  return guarded([&]() -> int {
+    require(out_comm != nullptr && id != nullptr, "null argument");
+    *out_comm = nullptr;
+    require(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "invalid rank");
+    avr::hip_ok(hipSetDevice(device_id), "hipSetDevice");
+    ncclUniqueId unique;
+    std::memcpy(unique.internal, id, AVR_COMM_ID_BYTES);
+    auto comm = std::make_unique<avr_comm>();
+    comm->rank = rank;
+    comm->n_ranks = n_ranks;
+    comm->device = device_id;
+    avr::nccl_ok(avr::rccl().comm_init_rank(&comm->nccl, n_ranks, unique, rank), "ncclCommInitRank");
+    *out_comm = comm.release();
+    return AVR_OK;
+  });
+}
+
+int avr_comm_create_local(int n_ranks, avr_comm** out_comms) {
+  return guarded([&]() -> int {
+    require(out_comms != nullptr && n_ranks >= 1, "invalid argument");
+    auto world = std::make_shared<avr::LocalWorld>();
+    world->n_ranks = n_ranks;
+    world->base.assign(static_cast<size_t>(n_ranks), nullptr);
+    world->offsets.resize(static_cast<size_t>(n_ranks));
+    world->sizes.resize(static_cast<size_t>(n_ranks));
+    for (int r = 0; r < n_ranks; ++r) {
+      auto* comm = new avr_comm();
+      comm->rank = r;
+      comm->n_ranks = n_ranks;
+      comm->local = world;
+      out_comms[r] = comm;
+    }
+    return AVR_OK;
+  });
+}
+
+void avr_comm_destroy(avr_comm* comm) {
+  if (comm == nullptr) return;
+  if (comm->nccl != nullptr) {
+    try {
+      (void)avr::rccl().comm_destroy(comm->nccl);
+    } catch (...) {
+    }
+  }
+  delete comm;
+}
+
+int avr_comm_rank(const avr_comm* comm) { return comm ? comm->rank : -1; }
+int avr_comm_size(const avr_comm* comm) { return comm ? comm->n_ranks : -1; }
+
+int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
+                 float* recv) {
+  return guarded([&]() -> int {
+    check_plan(comm, plan);
+    hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
+    const int n = comm->n_ranks, me = comm->rank;
+    require(plan->info.send_floats == 0 || send != nullptr, "null send buffer");
+    require(plan->info.recv_floats == 0 || recv != nullptr, "null receive buffer");
+    std::vector<int64_t> send_at(static_cast<size_t>(n) + 1, 0), recv_at(static_cast<size_t>(n) + 1, 0);
+    for (int s = 0; s < n; ++s) {
+      send_at[static_cast<size_t>(s) + 1] = send_at[static_cast<size_t>(s)] + plan->send_splits[static_cast<size_t>(s)];
+      recv_at[static_cast<size_t>(s) + 1] = recv_at[static_cast<size_t>(s)] + plan->recv_splits[static_cast<size_t>(s)];
+    }
+    if (plan->send_splits[static_cast<size_t>(me)] != plan->recv_splits[static_cast<size_t>(me)]) {
+      throw std::runtime_error("frame plan: a rank's block for itself differs between send and receive layout");
+    }
+    if (comm->local) {
+      // in-process rehearsal: publish, meet, pull, meet
+      avr::LocalWorld& world = *comm->local;
+      drain(stream);  // my send buffer is complete
+      world.base[static_cast<size_t>(me)] = reinterpret_cast<const char*>(send);
+      world.offsets[static_cast<size_t>(me)].assign(static_cast<size_t>(n), 0);
+      world.sizes[static_cast<size_t>(me)].assign(static_cast<size_t>(n), 0);
+      for (int s = 0; s < n; ++s) {
+        world.offsets[static_cast<size_t>(me)][static_cast<size_t>(s)] = send_at[static_cast<size_t>(s)] * 4;
+        world.sizes[static_cast<size_t>(me)][static_cast<size_t>(s)] = plan->send_splits[static_cast<size_t>(s)] * 4;
+      }
+      world.barrier();
+      for (int s = 0; s < n; ++s) {
+        const int64_t bytes = world.sizes[static_cast<size_t>(s)][static_cast<size_t>(me)];
+        if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
+          throw std::runtime_error("exchange: the ranks' frame plans disagree on a block size");
+        }
+        if (bytes == 0) continue;
+        avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(s)],
+                                   world.base[static_cast<size_t>(s)] +
+                                       world.offsets[static_cast<size_t>(s)][static_cast<size_t>(me)],
+                                   static_cast<size_t>(bytes), hipMemcpyDeviceToDevice, stream),
+                    "hipMemcpyAsync(exchange)");
+      }
+      drain(stream);
+      world.barrier();  // every rank has pulled: the send buffers may be rewritten
+      return AVR_OK;
+    }
+    // RCCL: one grouped round; a rank's block for itself is a device copy
+    const avr::Rccl& api = avr::rccl();
+    const int64_t own = plan->send_splits[static_cast<size_t>(me)];
+    if (own > 0) {
+      avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(me)], send + send_at[static_cast<size_t>(me)],
+                                 static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
+                  "hipMemcpyAsync(exchange)");
+    }
+    if (n == 1) return AVR_OK;
+    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    for (int s = 0; s < n; ++s) {
+      if (s == me) continue;
+      const int64_t out = plan->send_splits[static_cast<size_t>(s)];
+      const int64_t in = plan->recv_splits[static_cast<size_t>(s)];
+      if (out > 0) {
+        avr::nccl_ok(api.send(send + send_at[static_cast<size_t>(s)], static_cast<size_t>(out), ncclFloat, s,
+                              comm->nccl, stream), "ncclSend");
+      }
+      if (in > 0) {
+        avr::nccl_ok(api.recv(recv + recv_at[static_cast<size_t>(s)], static_cast<size_t>(in), ncclFloat, s,
+                              comm->nccl, stream), "ncclRecv");
+      }
+    }
+    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    return AVR_OK;
+  });
+}
+
+int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const void* piece,
+               int bytes_per_pixel, void* full, int root) {
+  return guarded([&]() -> int {
+    check_plan(comm, plan);
+    hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
+    const int n = comm->n_ranks, me = comm->rank;
+    require(bytes_per_pixel > 0 && root >= 0 && root < n, "invalid argument");
+    const int64_t n_pixels = plan->info.n_pixels;
+    const int64_t piece_size = n_pixels / n;  // getPieceRange (DirectSendBase.cpp:59-74)
+    auto piece_range = [&](int rank, int64_t* begin, int64_t* end) {
+      const int k = plan->piece_of_rank[static_cast<size_t>(rank)];
+      *begin = piece_size * k;
+      *end = (k < n - 1) ? *begin + piece_size : n_pixels;
+    };
+    int64_t my_begin = 0, my_end = 0;
+    piece_range(me, &my_begin, &my_end);
+    require(my_end == my_begin || piece != nullptr, "null piece");
+    require(me != root || full != nullptr || n_pixels == 0, "null destination on the root");
+    char* dst = static_cast<char*>(full);
+    if (comm->local) {
+      avr::LocalWorld& world = *comm->local;
+      drain(stream);
+      world.base[static_cast<size_t>(me)] = static_cast<const char*>(piece);
+      world.barrier();
+      if (me == root) {
+        for (int s = 0; s < n; ++s) {
+          int64_t b = 0, e = 0;
+          piece_range(s, &b, &e);
+          if (e == b) continue;
+          avr::hip_ok(hipMemcpyAsync(dst + b * bytes_per_pixel, world.base[static_cast<size_t>(s)],
+                                     static_cast<size_t>(e - b) * bytes_per_pixel,
+                                     hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+        }
+        drain(stream);
+      }
+      world.barrier();
+      return AVR_OK;
+    }
+    const avr::Rccl& api = avr::rccl();
+    if (me == root && my_end > my_begin) {
+      avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
+                                 static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
+                                 hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+    }
+    if (n == 1) return AVR_OK;
+    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    if (me == root) {
+      for (int s = 0; s < n; ++s) {
+        if (s == root) continue;
+        int64_t b = 0, e = 0;
+        piece_range(s, &b, &e);
+        if (e == b) continue;
+        avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, static_cast<size_t>(e - b) * bytes_per_pixel,
+                              ncclChar, s, comm->nccl, stream), "ncclRecv");
+      }
+    } else if (my_end > my_begin) {
+      avr::nccl_ok(api.send(piece, static_cast<size_t>(my_end - my_begin) * bytes_per_pixel, ncclChar,
+                            root, comm->nccl, stream), "ncclSend");
+    }
+    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    return AVR_OK;
+  });
+}
+
+}  // extern "C"

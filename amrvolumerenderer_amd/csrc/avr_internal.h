@@ -178,6 +178,7 @@ int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, i
                      void* stream);
 int launch_downsample(const float* src, int tw, int th, int block, float* dst, void* stream);
 int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream);
+int launch_flip_rows(const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst, void* stream);
 
 constexpr uint32_t kScanWorkgroups = 2048;  // grid of the grid-stride cell scans
 // scene statistics (avr_scene_stats.hip).  partial_dev: kScanWorkgroups x 32 bytes of scratch;
@@ -242,6 +243,8 @@ bool visibility_order(avr_visibility_graph* graph, const avr_camera& camera, flo
                       const char* dot_prefix, int32_t* rank_order, int* n_splits);
 
 void set_error(const std::string& message);
+// The context's HIP stream (hipStream_t; created on first use) with its device made current.
+void* context_stream(avr_context* ctx);
 
 }  // namespace avr
 

@@ -1099,6 +1099,20 @@ __global__ void quantize_kernel(const float* __restrict__ src, int w, int h, int
   }
 }
 
+// Rows of a byte image in reverse order (image origin bottom-left -> file rows top-down,
+// Common/SavePPM.cpp:25, Common/SavePNG.cpp:64-71).
+template <typename T>
+__global__ void flip_rows_kernel(const T* __restrict__ src, int64_t row_items, int h,
+                                 T* __restrict__ dst) {
+  const int64_t n = row_items * h;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
+       q += stride) {
+    const int64_t row = q / row_items;
+    dst[q] = src[(h - 1 - row) * row_items + (q - row * row_items)];
+  }
+}
+
 int grid_for(int64_t n, int block) {
   int64_t blocks = (n + block - 1) / block;
   const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -1264,6 +1278,22 @@ int launch_downsample(const float* src, int tw, int th, int block, float* dst, v
   hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_v), src, tw, th, block, dst);
   return check_launch("downsample_kernel");
+}
+
+int launch_flip_rows(const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst, void* stream_v) {
+  if (row_bytes <= 0 || h <= 0) return AVR_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const bool wide = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  if (wide) {
+    const int64_t items = row_bytes / 16;
+    hipLaunchKernelGGL(flip_rows_kernel<uint4>, dim3(grid_for(items * h, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4*>(src), items, h, reinterpret_cast<uint4*>(dst));
+  } else {
+    hipLaunchKernelGGL(flip_rows_kernel<uint8_t>, dim3(grid_for(row_bytes * h, 256)), dim3(256), 0,
+                       stream, src, row_bytes, h, dst);
+  }
+  return check_launch("flip_rows_kernel");
 }
 
 int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream_v) {

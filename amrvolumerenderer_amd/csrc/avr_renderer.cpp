@@ -1,0 +1,573 @@
+// Frame driver of one rank: what VolumeRenderer::renderSingleTrial does between "per-box
+// rendering" and the saved image (VolumeRenderer/VolumeRenderer.cpp:1103-1339), re-cut for one
+// rank per GPU and pipelined over three HIP streams (include/avr_hip.h, "frame driver").
+//
+//   reference stage                                   here
+//   ------------------------------------------------  -------------------------------------------
+//   referenceSampleDistance + MPI_Allreduce (:1138)   host, from the replicated box metadata
+//   BuildVisibilityOrderedGroup (:1235-1241)          avr_visibility_order (cached adjacency)
+//   allgather of layer counts / hints, sort, runs     avr_frame_plan (replicated metadata)
+//     (DirectSendBase.cpp:329-410)
+//   per-box paint loop + owner-side run fold          classify pass (stream C) + ONE march launch
+//     (:1201-1219, DirectSendBase.cpp:413-426)          (stream M) into the sparse send layout
+//   one direct-send round per run (:400-446)          avr_exchange: one RCCL round (stream X)
+//   receiver blend chain                              avr_fold_plan (stream X)
+//   Gather(0) (:1293)                                 avr_gather (stream X)
+//   downsampleImage / bounds overlay / 8 bit          avr_downsample / avr_bbox_overlay /
+//     (:479-528, :139-335, SavePPM.cpp)                 avr_quantize on the root (stream X)
+//
+// Frames are independent, so frame i+1 is classified while frame i is marched and frame i-1 is
+// exchanged, folded and gathered: two classified volumes and two send buffers rotate, events
+// guard their re-use, and the host never waits for the device inside a frame.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "avr_internal.h"
+#include "avr_plan.h"
+
+namespace {
+
+void hip_ok(hipError_t err, const char* what) {
+  if (err != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(err));
+}
+
+void abi_ok(int status) {
+  if (status == AVR_OK) return;
+  const std::string message = avr_last_error();
+  if (status == AVR_ERR_INVALID_ARGUMENT) throw std::invalid_argument(message);
+  throw std::runtime_error(message);
+}
+
+void require(bool condition, const char* message) {
+  if (!condition) throw std::invalid_argument(message);
+}
+
+// Grow-only device buffer.  Growing frees the old block, so every stream that may still touch it
+// is drained first (rare: sizes settle after the first frames; 25 % headroom).
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t capacity = 0;
+  ~DeviceBuffer() {
+    if (ptr != nullptr) (void)hipFree(ptr);
+  }
+  template <typename Drain>
+  void* reserve(size_t bytes, Drain&& drain) {
+    if (bytes > capacity) {
+      drain();
+      if (ptr != nullptr) (void)hipFree(ptr);
+      ptr = nullptr;
+      capacity = 0;
+      const size_t want = bytes + bytes / 4 + 256;
+      hip_ok(hipMalloc(&ptr, want), "hipMalloc(frame buffer)");
+      capacity = want;
+    }
+    return ptr;
+  }
+};
+
+struct PlanKey {
+  avr_render_params render{};
+  avr_camera camera{};
+  std::vector<int32_t> group;  // explicit group order, if any
+  bool operator==(const PlanKey& o) const {
+    return std::memcmp(&render, &o.render, sizeof(render)) == 0 &&
+           std::memcmp(&camera, &o.camera, sizeof(camera)) == 0 && group == o.group;
+  }
+};
+
+struct FrameEvents {
+  hipEvent_t classify_begin = nullptr, classify_end = nullptr, march_begin = nullptr,
+             march_end = nullptr;
+};
+
+}  // namespace
+
+struct avr_renderer {
+  int device = 0, rank = 0, n_ranks = 1;
+  avr_comm* comm = nullptr;
+  avr_context* march = nullptr;     // stream M (high priority)
+  avr_context* compose = nullptr;   // stream X (high priority)
+  avr_context* classify = nullptr;  // stream C (default priority)
+  avr_scene* scene = nullptr;
+  avr_visibility_graph* visibility = nullptr;
+  std::vector<avr_box> all_boxes;
+  std::vector<int32_t> owner;
+  avr_scalar_transform transform{};
+  double bounds_min[3]{}, bounds_max[3]{};
+  double tight_min[3]{}, tight_max[3]{};
+  float scalar_range[2]{0.0f, 1.0f};
+  std::vector<avr_colormap_point> colormap;
+  float reference_sample_distance = 0.0f;
+  int march_cap = -1;  // -1: default (5 for one rank without classification cache, else 0)
+  bool cache_classification = false;
+
+  avr_frame_plan* plan = nullptr;
+  PlanKey key;
+  bool have_plan = false;
+
+  DeviceBuffer send[2], recv, piece, piece_rgb8, full_rgb8, full_image, small_image;
+  hipEvent_t classified_event[2] = {nullptr, nullptr};  // classify pass of the slot finished
+  hipEvent_t marched_event[2] = {nullptr, nullptr};     // march finished reading classified[slot]
+  hipEvent_t composed_event[2] = {nullptr, nullptr};    // stream X finished reading send[slot]
+  hipEvent_t input_event = nullptr;
+  bool marched_pending[2] = {false, false}, composed_pending[2] = {false, false};
+  unsigned frame = 0;
+
+  bool timing = false;
+  hipEvent_t epoch = nullptr;
+  std::vector<FrameEvents> timed;
+
+  ~avr_renderer() {
+    (void)hipSetDevice(device);
+    for (avr_context* ctx : {classify, march, compose}) {
+      if (ctx != nullptr) (void)avr_context_synchronize(ctx);
+    }
+    clear_timing();
+    for (hipEvent_t* list : {classified_event, marched_event, composed_event}) {
+      for (int s = 0; s < 2; ++s) {
+        if (list[s] != nullptr) (void)hipEventDestroy(list[s]);
+      }
+    }
+    if (input_event != nullptr) (void)hipEventDestroy(input_event);
+    if (epoch != nullptr) (void)hipEventDestroy(epoch);
+    if (plan != nullptr) avr_frame_plan_destroy(plan);
+    if (visibility != nullptr) avr_visibility_graph_destroy(visibility);
+    if (scene != nullptr) avr_scene_destroy(scene);
+    for (avr_context* ctx : {classify, march, compose}) avr_context_destroy(ctx);
+  }
+
+  void clear_timing() {
+    for (FrameEvents& e : timed) {
+      for (hipEvent_t ev : {e.classify_begin, e.classify_end, e.march_begin, e.march_end}) {
+        if (ev != nullptr) (void)hipEventDestroy(ev);
+      }
+    }
+    timed.clear();
+  }
+
+  hipStream_t stream_of(avr_context* ctx) { return static_cast<hipStream_t>(avr::context_stream(ctx)); }
+
+  void drain_all() {
+    for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
+  }
+};
+
+namespace {
+
+template <typename F>
+int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::invalid_argument& e) {
+    avr::set_error(e.what());
+    return AVR_ERR_INVALID_ARGUMENT;
+  } catch (const std::bad_alloc&) {
+    avr::set_error("out of host memory");
+    return AVR_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    avr::set_error(e.what());
+    return AVR_ERR_RUNTIME;
+  } catch (...) {
+    avr::set_error("unknown failure");
+    return AVR_ERR_RUNTIME;
+  }
+}
+
+// validateRenderParameters (VolumeRenderer.cpp:562-579); returns sqrt(antialiasing)
+int validate(const avr_render_params& p) {
+  require(p.width > 0 && p.height > 0, "image dimensions must be positive");
+  require(p.box_transparency >= 0.0f && p.box_transparency <= 1.0f,
+          "box_transparency must be in [0, 1]");
+  require(p.antialiasing >= 1, "antialiasing must be >= 1");
+  const int root = static_cast<int>(std::lround(std::sqrt(static_cast<double>(p.antialiasing))));
+  require(root * root == p.antialiasing, "antialiasing must be a perfect square");
+  return root;
+}
+
+hipEvent_t make_event(bool timing) {
+  hipEvent_t event = nullptr;
+  hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : hipEventDisableTiming),
+         "hipEventCreate");
+  return event;
+}
+
+}  // namespace
+
+extern "C" {
+
+int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
+                        const avr_box* all_boxes, const int32_t* owner, int n_boxes,
+                        const avr_scalar_transform* transform, const double bounds_min[3],
+                        const double bounds_max[3], const float scalar_range[2],
+                        const avr_colormap_point* colormap, int colormap_count,
+                        avr_renderer** out_renderer) {
+  return guarded([&]() -> int {
+    require(out_renderer != nullptr && transform != nullptr && bounds_min != nullptr &&
+                bounds_max != nullptr && scalar_range != nullptr, "null argument");
+    *out_renderer = nullptr;
+    require(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "invalid rank");
+    require(n_boxes >= 0 && (n_boxes == 0 || (all_boxes != nullptr && owner != nullptr)),
+            "invalid box list");
+    require(colormap_count >= 0 && (colormap_count == 0 || colormap != nullptr), "invalid color map");
+    require(n_ranks == 1 || comm != nullptr, "a communicator is required for more than one rank");
+    require(comm == nullptr || (avr_comm_size(comm) == n_ranks && avr_comm_rank(comm) == rank),
+            "the communicator belongs to another rank / rank count");
+    auto r = std::make_unique<avr_renderer>();
+    r->device = device_id;
+    r->rank = rank;
+    r->n_ranks = n_ranks;
+    r->comm = comm;
+    r->all_boxes.assign(all_boxes, all_boxes + n_boxes);
+    r->owner.assign(owner, owner + n_boxes);
+    r->transform = *transform;
+    std::copy(bounds_min, bounds_min + 3, r->bounds_min);
+    std::copy(bounds_max, bounds_max + 3, r->bounds_max);
+    r->scalar_range[0] = scalar_range[0];
+    r->scalar_range[1] = scalar_range[1];
+    r->colormap.assign(colormap, colormap + colormap_count);
+    // The march and the compositing stream are high priority, the classify stream is not: not for
+    // the priority itself but because HIP multiplexes streams onto a few hardware queues in
+    // creation order and the two priority classes never share one (when classify and march landed
+    // on one queue the kernels ran strictly one after the other).
+    abi_ok(avr_context_create_with_priority(device_id, 1, &r->march));
+    abi_ok(avr_context_create_with_priority(device_id, 1, &r->compose));
+    abi_ok(avr_context_create_with_priority(device_id, 0, &r->classify));
+    std::vector<avr_box> local;
+    for (int b = 0; b < n_boxes; ++b) {
+      require(owner[b] >= 0 && owner[b] < n_ranks, "box owner out of range");
+      if (owner[b] == rank) {
+        require(all_boxes[b].cells != nullptr, "a box of this rank has no cell data");
+        local.push_back(all_boxes[b]);
+      }
+    }
+    abi_ok(avr_scene_create(r->march, local.data(), static_cast<int>(local.size()), transform,
+                            &r->scene));
+    // coarsest min spacing over all ranks == MPI_Allreduce(MAX) of VolumeRenderer.cpp:1166
+    abi_ok(avr_reference_sample_distance(all_boxes, n_boxes, bounds_min, bounds_max,
+                                         &r->reference_sample_distance));
+    // computeTightBounds (:791-848): min / max over all ranks' boxes == over all_boxes
+    abi_ok(avr_tight_bounds(all_boxes, n_boxes, bounds_min, bounds_max, r->tight_min, r->tight_max));
+    if (n_ranks > 1) {
+      abi_ok(avr_visibility_graph_create(all_boxes, owner, n_boxes, n_ranks, &r->visibility));
+    }
+    hip_ok(hipSetDevice(device_id), "hipSetDevice");
+    for (int s = 0; s < 2; ++s) {
+      r->classified_event[s] = make_event(false);
+      r->marched_event[s] = make_event(false);
+      r->composed_event[s] = make_event(false);
+    }
+    r->input_event = make_event(false);
+    *out_renderer = r.release();
+    return AVR_OK;
+  });
+}
+
+void avr_renderer_destroy(avr_renderer* renderer) { delete renderer; }
+
+int avr_renderer_set_options(avr_renderer* r, int march_workgroups_per_cu, int cache_classification) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    require(march_workgroups_per_cu >= -1 && march_workgroups_per_cu <= 8,
+            "march_workgroups_per_cu must be in [-1, 8]");
+    r->march_cap = march_workgroups_per_cu;
+    r->cache_classification = cache_classification != 0;
+    abi_ok(avr_scene_set_classification_cache(r->scene, r->cache_classification ? 1 : 0));
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_set_scalar_range(avr_renderer* r, const float scalar_range[2]) {
+  return guarded([&]() -> int {
+    require(r != nullptr && scalar_range != nullptr, "null argument");
+    r->scalar_range[0] = scalar_range[0];
+    r->scalar_range[1] = scalar_range[1];
+    r->have_plan = false;  // the plan carries the paint parameters
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_invalidate(avr_renderer* r) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    return avr_scene_invalidate(r->scene);
+  });
+}
+
+int avr_renderer_reference_sample_distance(const avr_renderer* r, float* out) {
+  return guarded([&]() -> int {
+    require(r != nullptr && out != nullptr, "null argument");
+    *out = r->reference_sample_distance;
+    return AVR_OK;
+  });
+}
+
+void* avr_renderer_stream(avr_renderer* r, int which) {
+  if (r == nullptr) return nullptr;
+  avr_context* ctx = (which == 0) ? r->classify : (which == 1) ? r->march : r->compose;
+  try {
+    return avr::context_stream(ctx);
+  } catch (...) {
+    return nullptr;
+  }
+}
+
+int avr_renderer_synchronize(avr_renderer* r) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    r->drain_all();
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_plan_info(const avr_renderer* r, avr_frame_plan_info* out) {
+  return guarded([&]() -> int {
+    require(r != nullptr && out != nullptr, "null argument");
+    require(r->have_plan, "no frame has been rendered yet");
+    return avr_frame_plan_get_info(r->plan, out);
+  });
+}
+
+int avr_renderer_set_timing(avr_renderer* r, int enabled) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    hip_ok(hipSetDevice(r->device), "hipSetDevice");
+    r->drain_all();
+    r->clear_timing();
+    r->timing = enabled != 0;
+    if (r->timing) {
+      if (r->epoch == nullptr) r->epoch = make_event(true);
+      hip_ok(hipEventRecord(r->epoch, r->stream_of(r->march)), "hipEventRecord");
+    }
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_timings(avr_renderer* r, double* classify_ms, double* march_ms, double* busy_ms,
+                         int* frames) {
+  return guarded([&]() -> int {
+    require(r != nullptr && classify_ms != nullptr && march_ms != nullptr && busy_ms != nullptr &&
+                frames != nullptr, "null argument");
+    hip_ok(hipSetDevice(r->device), "hipSetDevice");
+    r->drain_all();
+    *frames = static_cast<int>(r->timed.size());
+    *classify_ms = *march_ms = *busy_ms = 0.0;
+    if (r->timed.empty()) return AVR_OK;
+    // Each kernel's own duration, and the length of the union of all their execution intervals:
+    // the classify pass of frame i+1 runs beside the march of frame i, so the durations overlap.
+    std::vector<std::pair<float, float>> spans;
+    double classify = 0.0, march = 0.0;
+    for (const FrameEvents& e : r->timed) {
+      float c = 0.0f, m = 0.0f, c0 = 0.0f, c1 = 0.0f, m0 = 0.0f, m1 = 0.0f;
+      hip_ok(hipEventElapsedTime(&c, e.classify_begin, e.classify_end), "hipEventElapsedTime");
+      hip_ok(hipEventElapsedTime(&m, e.march_begin, e.march_end), "hipEventElapsedTime");
+      hip_ok(hipEventElapsedTime(&c0, r->epoch, e.classify_begin), "hipEventElapsedTime");
+      hip_ok(hipEventElapsedTime(&c1, r->epoch, e.classify_end), "hipEventElapsedTime");
+      hip_ok(hipEventElapsedTime(&m0, r->epoch, e.march_begin), "hipEventElapsedTime");
+      hip_ok(hipEventElapsedTime(&m1, r->epoch, e.march_end), "hipEventElapsedTime");
+      classify += c;
+      march += m;
+      spans.emplace_back(c0, c1);
+      spans.emplace_back(m0, m1);
+    }
+    std::sort(spans.begin(), spans.end());
+    double busy = 0.0;
+    float cursor = -1e30f;
+    for (const auto& span : spans) {
+      if (span.second > cursor) {
+        busy += span.second - std::max(span.first, cursor);
+        cursor = span.second;
+      }
+    }
+    const double n = static_cast<double>(r->timed.size());
+    *classify_ms = classify / n;
+    *march_ms = march / n;
+    *busy_ms = busy / n;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const avr_camera* camera,
+                        const int32_t* group_order, void* input_stream, uint64_t* samples_out,
+                        uint8_t* rgb8_out, float* image_out) {
+  return guarded([&]() -> int {
+    require(r != nullptr && render != nullptr && camera != nullptr, "null argument");
+    const int root = validate(*render);
+    hip_ok(hipSetDevice(r->device), "hipSetDevice");
+    const bool is_root = r->rank == 0;
+    require(!is_root || rgb8_out != nullptr, "the root rank needs an rgb8 output buffer");
+    const int width = render->width, height = render->height;
+    const int render_w = width * root, render_h = height * root;
+
+    // ---- host plan (re-used while camera and parameters repeat) --------------------------------
+    PlanKey key;
+    key.render = *render;
+    key.camera = *camera;
+    if (group_order != nullptr) key.group.assign(group_order, group_order + r->n_ranks);
+    if (!r->have_plan || !(key == r->key) || render->write_visibility_graph) {
+      std::vector<int32_t> order;
+      const int32_t* group = group_order;
+      if (group == nullptr && r->visibility != nullptr) {
+        order.resize(static_cast<size_t>(r->n_ranks));
+        // aspect as VolumeRenderer.cpp:1114 computes it (float division of the image size)
+        const float aspect = static_cast<float>(width) / static_cast<float>(std::max(height, 1));
+        int succeeded = 1;
+        abi_ok(avr_visibility_order(r->visibility, camera, aspect, render->use_visibility_graph,
+                                    (render->write_visibility_graph && is_root) ? "visibility_graph_"
+                                                                                 : nullptr,
+                                    order.data(), &succeeded, nullptr));
+        group = order.data();
+      }
+      avr_paint_params params{};
+      params.width = render_w;
+      params.height = render_h;
+      params.scalar_range[0] = r->scalar_range[0];
+      params.scalar_range[1] = r->scalar_range[1];
+      params.box_transparency = render->box_transparency;
+      params.reference_sample_distance = r->reference_sample_distance;
+      std::copy(r->bounds_min, r->bounds_min + 3, params.bounds_min);
+      std::copy(r->bounds_max, r->bounds_max + 3, params.bounds_max);
+      params.colormap = r->colormap.empty() ? nullptr : r->colormap.data();
+      params.colormap_count = static_cast<int32_t>(r->colormap.size());
+      avr_frame_plan* fresh = nullptr;
+      abi_ok(avr_frame_plan_create(r->all_boxes.data(), r->owner.data(),
+                                   static_cast<int>(r->all_boxes.size()), r->n_ranks, r->rank, group,
+                                   &params, camera, &fresh));
+      if (r->plan != nullptr) avr_frame_plan_destroy(r->plan);
+      r->plan = fresh;
+      r->key = key;
+      r->have_plan = true;
+    }
+    const avr_frame_plan* plan = r->plan;
+    const avr_frame_plan_info& info = plan->info;
+    const int64_t piece_pixels = info.piece_end - info.piece_begin;
+
+    int cap = r->march_cap;
+    if (cap < 0) cap = (r->n_ranks == 1 && !r->cache_classification) ? 5 : 0;
+    abi_ok(avr_context_set_march_occupancy(r->march, cap));
+
+    hipStream_t stream_c = r->stream_of(r->classify);
+    hipStream_t stream_m = r->stream_of(r->march);
+    hipStream_t stream_x = r->stream_of(r->compose);
+    const int slot = static_cast<int>(r->frame & 1u);
+    ++r->frame;
+    auto drain = [&] { r->drain_all(); };
+
+    FrameEvents timed;
+    if (r->timing) {
+      timed.classify_begin = make_event(true);
+      timed.classify_end = make_event(true);
+      timed.march_begin = make_event(true);
+      timed.march_end = make_event(true);
+    }
+
+    // ---- stream C: classify pass of this frame into classified volume `slot` -------------------
+    if (input_stream != nullptr) {  // the caller's cell data is produced on that stream
+      hip_ok(hipEventRecord(r->input_event, static_cast<hipStream_t>(input_stream)), "hipEventRecord");
+      hip_ok(hipStreamWaitEvent(stream_c, r->input_event, 0), "hipStreamWaitEvent");
+    }
+    if (r->marched_pending[slot]) {  // the frame before last still marches this volume
+      hip_ok(hipStreamWaitEvent(stream_c, r->marched_event[slot], 0), "hipStreamWaitEvent");
+    }
+    if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
+    abi_ok(avr_classify_plan(r->classify, r->scene, plan, slot));
+    hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[slot];
+    hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
+
+    // ---- stream M: march into send buffer `slot` ------------------------------------------------
+    float* send = static_cast<float*>(
+        r->send[slot].reserve(static_cast<size_t>(std::max<int64_t>(info.send_floats, 1)) * 4, drain));
+    hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
+    if (r->composed_pending[slot]) {  // the frame before last is still exchanged / folded from it
+      hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
+    }
+    if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
+    abi_ok(avr_march_plan(r->march, r->scene, plan, slot, send, samples_out));
+    if (r->timing) hip_ok(hipEventRecord(timed.march_end, stream_m), "hipEventRecord");
+    hip_ok(hipEventRecord(r->marched_event[slot], stream_m), "hipEventRecord");
+    r->marched_pending[slot] = true;
+    if (r->timing) r->timed.push_back(timed);
+
+    // ---- stream X: exchange, fold, gather, frame tail ------------------------------------------
+    hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[slot], 0), "hipStreamWaitEvent");
+    const float* received = send;
+    if (r->n_ranks > 1) {
+      float* recv = static_cast<float*>(
+          r->recv.reserve(static_cast<size_t>(std::max<int64_t>(info.recv_floats, 1)) * 4, drain));
+      abi_ok(avr_exchange(r->compose, plan, r->comm, send, recv));
+      received = recv;
+    }
+    // 8-bit conversion is per pixel, so without antialiasing it is done on each rank's piece
+    // before the gather (3 bytes per pixel on the wire instead of 20); the wireframe of the tight
+    // bounds is per pixel too, so each rank overlays its own piece
+    const bool early_rgb8 = root == 1;
+    const bool overlay_piece = early_rgb8 && render->draw_bounds;
+    const bool want_image = image_out != nullptr;
+    const bool bytes_only = early_rgb8 && !overlay_piece && !want_image;
+    float* piece = nullptr;
+    uint8_t* piece_rgb8 = nullptr;
+    if (!bytes_only) {
+      piece = static_cast<float*>(
+          r->piece.reserve(static_cast<size_t>(std::max<int64_t>(piece_pixels, 1)) * 20, drain));
+    }
+    if (early_rgb8) {
+      piece_rgb8 = static_cast<uint8_t*>(
+          r->piece_rgb8.reserve(static_cast<size_t>(std::max<int64_t>(piece_pixels, 1)) * 3, drain));
+    }
+    abi_ok(avr_fold_plan(r->compose, plan, received, piece, overlay_piece ? nullptr : piece_rgb8));
+    if (overlay_piece && piece_pixels > 0) {
+      abi_ok(avr_bbox_overlay(r->compose, r->tight_min, r->tight_max, camera, 1, width, height,
+                              info.piece_begin, info.piece_end, piece, piece_rgb8));
+    }
+    hip_ok(hipEventRecord(r->composed_event[slot], stream_x), "hipEventRecord");
+    r->composed_pending[slot] = true;
+
+    const int64_t n_pixels = info.n_pixels;
+    if (early_rgb8) {
+      // pieces are pixel ranges of the bottom-up image; the output file's rows run top-down
+      uint8_t* full = piece_rgb8;
+      if (r->n_ranks > 1) {
+        full = is_root ? static_cast<uint8_t*>(r->full_rgb8.reserve(static_cast<size_t>(n_pixels) * 3, drain))
+                       : nullptr;
+        abi_ok(avr_gather(r->compose, plan, r->comm, piece_rgb8, 3, full, 0));
+      }
+      if (is_root) abi_ok(avr_flip_rows(r->compose, full, width * 3, height, rgb8_out));
+      if (want_image) {
+        if (r->n_ranks > 1) {
+          abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, is_root ? image_out : nullptr, 0));
+        } else {
+          hip_ok(hipMemcpyAsync(image_out, piece, static_cast<size_t>(n_pixels) * 20,
+                                hipMemcpyDeviceToDevice, stream_x), "hipMemcpyAsync(image)");
+        }
+      }
+    } else {
+      float* full = piece;
+      if (r->n_ranks > 1) {
+        full = is_root ? static_cast<float*>(r->full_image.reserve(static_cast<size_t>(n_pixels) * 20, drain))
+                       : nullptr;
+        abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, full, 0));
+      }
+      if (is_root) {
+        float* small = want_image ? image_out
+                                  : static_cast<float*>(r->small_image.reserve(
+                                        static_cast<size_t>(width) * height * 20, drain));
+        abi_ok(avr_downsample_depthsort(r->compose, full, width, height, root, small));
+        if (render->draw_bounds) {
+          abi_ok(avr_bbox_overlay(r->compose, r->tight_min, r->tight_max, camera, 1, width, height, 0,
+                                  static_cast<int64_t>(width) * height, small, nullptr));
+        }
+        abi_ok(avr_quantize_rgb8(r->compose, small, width, height, 5, rgb8_out));
+      }
+    }
+    return AVR_OK;
+  });
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ wireframe of the tight bounds (:139, :1311)      HIP kernel; without antialiasin
 """
 from __future__ import annotations
 
+import dataclasses
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -75,7 +76,14 @@ class FrameRenderer:
                  stage_through_host: bool = False, force_collectives: bool = False,
                  march_workgroups_per_cu: Optional[int] = None,
                  stream_priorities: Sequence[int] = (-1, -1, 0),
-                 cache_classification: bool = False):
+                 cache_classification: bool = False, native: Optional[bool] = None,
+                 comm: Optional["runtime.Comm"] = None):
+        """native (default: whenever possible): frames are driven by the C++ frame driver behind
+        the C ABI (avr_renderer: three streams, RCCL exchange and gather) and this class only
+        forwards camera, parameters and output tensors.  The Python pipeline below is the same
+        frame expressed with torch streams and torch.distributed collectives; it remains for
+        rehearsals of N ranks on one GPU over gloo (stage_through_host), for the one-rank
+        collective check (force_collectives) and for the tools that time single stages."""
         self.ctx = ctx
         self.rank = rank
         self.n_ranks = n_ranks
@@ -83,13 +91,15 @@ class FrameRenderer:
         self.local_boxes = list(local_boxes)
         self.transform = transform
         self.bounds = bounds
-        self.scalar_range = tuple(scalar_range)
+        self.native = None
+        self._scalar_range = tuple(scalar_range)
         self.color_map = color_map
         self.scene = ctx.create_scene(self.local_boxes, transform)
         # Off by default: every frame re-reads the f64 cells like the reference.  On: a camera
         # moving over static data only pays for the march (call scene.invalidate() after changing
         # cells in place).
         self.scene.set_classification_cache(cache_classification)
+        self._cache_classification = cache_classification
         # Three HIP streams, frames are independent: frame i+1 is classified on
         # classify_ctx.stream while frame i is marched on march_ctx.stream (the march's tail leaves CUs
         # idle that the bandwidth-bound classify pass fills) and frame i-1 is exchanged, folded
@@ -134,12 +144,48 @@ class FrameRenderer:
         # timing events of every frame (bench.py's live kernel durations)
         self.kernel_events: Optional[list] = None
         self._frame = 0
-        self.last_plan: Optional[FramePlan] = None
+        self.last_plan = None
+        # ---- the native frame driver -------------------------------------------------------------
+        if native is None:
+            native = not stage_through_host and not force_collectives
+            if native and n_ranks > 1 and comm is None:
+                import torch.distributed as dist
+                native = (process_group is not None or dist.is_initialized()) and \
+                    dist.get_backend(process_group) == "nccl"
+        if native:
+            if n_ranks > 1 and comm is None:
+                comm = runtime.Comm.from_process_group(ctx.device_index, process_group)
+            merged = []   # replicated metadata, this rank's boxes with their cells
+            mine = iter(self.local_boxes)
+            for b in self.all_boxes:
+                merged.append(dataclasses.replace(next(mine), owner=b.owner)
+                              if b.owner == rank else b)
+            self.native = runtime.NativeRenderer(ctx.device_index, merged, transform, bounds,
+                                                 self.scalar_range, rank, n_ranks, comm, color_map)
+            self.native.set_options(-1 if march_workgroups_per_cu is None
+                                    else march_workgroups_per_cu, cache_classification)
         # The last frame's host plan (visibility order, layer order, runs, exchange layout, per-box
         # prologue) is kept: a frame with the same camera and parameters re-uses it.  Host work
         # only (~60 us of the ~160 us a frame costs the host at N = 8) -- every frame still
         # classifies, marches, exchanges and folds.
         self._plan_cache = None
+
+    @property
+    def scalar_range(self):
+        """geometry.scalarRange: the normalised scalar interval the colour map spans."""
+        return self._scalar_range
+
+    @scalar_range.setter
+    def scalar_range(self, value) -> None:
+        self._scalar_range = tuple(value)
+        if self.native is not None:
+            self.native.set_scalar_range(self._scalar_range)
+
+    def invalidate(self) -> None:
+        """Cell data was changed in place: cached classifications are stale."""
+        self.scene.invalidate()
+        if self.native is not None:
+            self.native.invalidate()
 
     # -- planning (host) -------------------------------------------------------------------------
     def make_params(self, p: RenderParameters):
@@ -196,6 +242,8 @@ class FrameRenderer:
         best, best_time = candidates[0], float("inf")
         for cap in candidates:
             self.march_ctx.set_march_occupancy(cap)
+            if self.native is not None:
+                self.native.set_options(cap, self._cache_classification)
             for _ in range(2):
                 self.render(p, camera)
             self.synchronize()
@@ -207,10 +255,14 @@ class FrameRenderer:
             if elapsed < best_time:
                 best, best_time = cap, elapsed
         self.march_ctx.set_march_occupancy(best)
+        if self.native is not None:
+            self.native.set_options(best, self._cache_classification)
         self.march_workgroups_per_cu = best
         return best
 
     def synchronize(self) -> None:
+        if self.native is not None:
+            self.native.synchronize()
         self.classify_ctx.synchronize()
         self.march_ctx.synchronize()
         self.comm_ctx.synchronize()
@@ -223,6 +275,13 @@ class FrameRenderer:
         image [H, W, 5] if want_image (or antialiasing > 1), else None.  Other ranks get
         (None, None).  The results are produced on comm_ctx.stream: call synchronize() (or order
         your stream after it) before reading them."""
+        if self.native is not None:
+            validate_render_parameters(p)
+            out = self.native.render(p.width, p.height, p.box_transparency, p.antialiasing, camera,
+                                     p.use_visibility_graph, p.draw_bounds,
+                                     p.write_visibility_graph, group_order, samples, want_image)
+            self.last_plan = self.native.plan_info()
+            return out
         key = (p.width, p.height, p.box_transparency, p.antialiasing, p.use_visibility_graph,
                tuple(camera.eye), tuple(camera.look_at), tuple(camera.up), camera.fov_y_degrees,
                camera.near_plane, camera.far_plane, tuple(self.scalar_range), id(self.color_map),

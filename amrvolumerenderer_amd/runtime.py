@@ -543,3 +543,163 @@ class Scene:
         if sync_streams:
             ctx.publish()
         return out
+
+
+class Comm:
+    """avr_comm: this rank's communicator over RCCL / xGMI (one process per GPU).  The 128-byte
+    unique id is created on rank 0 and handed to the other ranks through `broadcast_bytes`, a
+    callable (bytes or None) -> bytes of the caller's own control plane: torch.distributed's
+    store / object broadcast in this package, MPI_Bcast in the reference's host."""
+
+    def __init__(self, device_index: int, rank: int, n_ranks: int, broadcast_bytes):
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        ident = None
+        if self.rank == 0:
+            buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+            _capi.check(_capi.lib().avr_comm_unique_id(buf))
+            ident = buf.raw
+        ident = broadcast_bytes(ident)
+        if len(ident) != _capi.COMM_ID_BYTES:
+            raise ValueError("the communicator id did not survive the broadcast")
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_comm_create(int(device_index), ident, self.rank, self.n_ranks,
+                                                C.byref(handle)))
+        self._handle = handle
+
+    @classmethod
+    def from_process_group(cls, device_index: int, group=None) -> "Comm":
+        """Bootstraps over an initialised torch.distributed group (any backend)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def broadcast(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group else 0,
+                                       group=group)
+            return box[0]
+
+        return cls(device_index, rank, world, broadcast)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _capi.lib().avr_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeRenderer:
+    """avr_renderer: the C++ frame driver of one rank (three HIP streams, double-buffered
+    classified volumes and send layouts, RCCL exchange and gather).  Python only hands over the
+    scene once and, per frame, the camera, the parameters and the output tensors."""
+
+    def __init__(self, device_index: int, all_boxes: Sequence[AmrBox], transform: ScalarTransform,
+                 bounds, scalar_range=(0.0, 1.0), rank: int = 0, n_ranks: int = 1,
+                 comm: Optional[Comm] = None, color_map=None):
+        from .types import make_params
+        self.device_index = int(device_index)
+        self.device = torch.device("cuda", self.device_index)
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        self._comm = comm
+        self._boxes = list(all_boxes)   # keeps the cell tensors alive
+        n = len(self._boxes)
+        arr = (_capi.Box * max(n, 1))(*[b.to_c() for b in self._boxes])
+        owners = (C.c_int32 * max(n, 1))(*[int(b.owner) for b in self._boxes])
+        ctr = transform.to_c()
+        bmin = (C.c_double * 3)(*map(float, bounds.min_corner))
+        bmax = (C.c_double * 3)(*map(float, bounds.max_corner))
+        rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))
+        # make_params owns the conversion of a colour map to C points
+        params = make_params(1, 1, scalar_range, 0.0, 0.0, bounds, color_map)
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_renderer_create(
+            self.device_index, self.rank, self.n_ranks, comm._handle if comm is not None else None,
+            arr, owners, n, C.byref(ctr), bmin, bmax, rng, params.colormap, params.colormap_count,
+            C.byref(handle)))
+        self._handle = handle
+        self._keep = (arr, owners, params)
+        out = C.c_float()
+        _capi.check(_capi.lib().avr_renderer_reference_sample_distance(self._handle, C.byref(out)))
+        self.reference_sample_distance = out.value
+        # torch views of the driver's streams: outputs are allocated and consumed on stream X
+        self.streams = [torch.cuda.ExternalStream(int(_capi.lib().avr_renderer_stream(self._handle, w)),
+                                                  device=self.device) for w in range(3)]
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _capi.lib().avr_renderer_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_options(self, march_workgroups_per_cu: int = -1, cache_classification: bool = False):
+        _capi.check(_capi.lib().avr_renderer_set_options(self._handle, int(march_workgroups_per_cu),
+                                                         int(bool(cache_classification))))
+
+    def synchronize(self) -> None:
+        _capi.check(_capi.lib().avr_renderer_synchronize(self._handle))
+
+    def set_scalar_range(self, scalar_range) -> None:
+        rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))
+        _capi.check(_capi.lib().avr_renderer_set_scalar_range(self._handle, rng))
+
+    def invalidate(self) -> None:
+        _capi.check(_capi.lib().avr_renderer_invalidate(self._handle))
+
+    def plan_info(self) -> "_capi.FramePlanInfo":
+        info = _capi.FramePlanInfo()
+        _capi.check(_capi.lib().avr_renderer_plan_info(self._handle, C.byref(info)))
+        return info
+
+    def set_timing(self, enabled: bool) -> None:
+        _capi.check(_capi.lib().avr_renderer_set_timing(self._handle, int(bool(enabled))))
+
+    def timings(self):
+        """(classify_ms, march_ms, busy_ms, frames) averaged per frame since set_timing(True)."""
+        c, m, b, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _capi.check(_capi.lib().avr_renderer_timings(self._handle, C.byref(c), C.byref(m),
+                                                     C.byref(b), C.byref(n)))
+        return c.value, m.value, b.value, n.value
+
+    def render(self, width: int, height: int, box_transparency: float, antialiasing: int,
+               camera: CameraParameters, use_visibility_graph: bool = True,
+               draw_bounds: bool = True, write_visibility_graph: bool = False,
+               group_order: Optional[Sequence[int]] = None,
+               samples: Optional[torch.Tensor] = None, want_image: bool = False):
+        """One frame (asynchronous).  Rank 0 returns (image [H, W, 5] or None, rgb8 [H, W, 3] with
+        rows top-down); other ranks (None, None).  The tensors are complete on stream X
+        (self.streams[2]): synchronize(), or order your stream after it."""
+        rp = _capi.RenderParams(int(width), int(height), float(box_transparency), int(antialiasing),
+                                int(bool(use_visibility_graph)), int(bool(draw_bounds)),
+                                int(bool(write_visibility_graph)))
+        ccam = camera.to_c()
+        group = None
+        if group_order is not None:
+            group = (C.c_int32 * self.n_ranks)(*[int(g) for g in group_order])
+        rgb8 = image = None
+        caller = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.streams[2]):
+            if self.rank == 0:
+                rgb8 = torch.empty((height, width, 3), dtype=torch.uint8, device=self.device)
+                if want_image:
+                    image = torch.empty((height, width, 5), dtype=torch.float32, device=self.device)
+        if samples is not None and (samples.dtype != torch.int64 or samples.device != self.device):
+            raise ValueError("samples must be an int64 tensor on the renderer's device")
+        # cell data / the samples counter may have been written on the caller's stream
+        wait = None if caller.query() else C.c_void_p(caller.cuda_stream)
+        if samples is not None and wait is not None:
+            self.streams[1].wait_stream(caller)
+        _capi.check(_capi.lib().avr_renderer_render(
+            self._handle, C.byref(rp), C.byref(ccam), group, wait,
+            C.c_void_p(samples.data_ptr()) if samples is not None else None,
+            C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
+            C.c_void_p(image.data_ptr()) if image is not None else None))
+        return image, rgb8

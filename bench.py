@@ -288,17 +288,21 @@ def main():
         step(i)
     renderer.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
 
     # ---- timed region: EXACTLY `steps` frames ----------------------------------------------
     # the two paint kernels' own durations are taken with HIP events on the streams they are
     # launched on (classify on classify_ctx.stream, march on march_ctx.stream)
     params, _ = renderer.make_params(rparams)
-    renderer.kernel_events = []
-    epoch = torch.cuda.Event(enable_timing=True)
-    epoch.record(renderer.march_ctx.stream)
+    native = renderer.native is not None
+    if native:
+        renderer.native.set_timing(True)     # drains the streams, records the epoch
+    else:
+        renderer.kernel_events = []
+        epoch = torch.cuda.Event(enable_timing=True)
+        epoch.record(renderer.march_ctx.stream)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -307,31 +311,36 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_events, renderer.kernel_events = renderer.kernel_events, None
 
     t = torch.tensor([elapsed], dtype=torch.float64,
                      device="cpu" if args.rehearse_on_one_gpu else ctx.device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     elapsed = float(t.item())
-    n_events = max(len(kernel_events), 1)
-    classify_ms = sum(c0.elapsed_time(c1) for c0, c1, _, _ in kernel_events) / n_events
-    march_ms = sum(m0.elapsed_time(m1) for _, _, m0, m1 in kernel_events) / n_events
     # The classify pass of frame i+1 runs beside the march of frame i, so each kernel's own
     # duration (what rocprofv3 --stats reports) includes the time it shared the GPU with the
     # other and their sum exceeds the frame time.  The paint stage's GPU time per frame is the
     # length of the union of the kernels' execution intervals over the timed region / frames.
-    spans = []
-    for c0, c1, m0, m1 in kernel_events:
-        spans.append((epoch.elapsed_time(c0), epoch.elapsed_time(c1)))
-        spans.append((epoch.elapsed_time(m0), epoch.elapsed_time(m1)))
-    spans.sort()
-    busy, cursor = 0.0, float("-inf")
-    for begin, end in spans:
-        if end > cursor:
-            busy += end - max(begin, cursor)
-            cursor = end
-    kernel_ms = busy / n_events
+    if native:
+        classify_ms, march_ms, kernel_ms, n_events = renderer.native.timings()
+        renderer.native.set_timing(False)
+        assert n_events == args.steps
+    else:
+        kernel_events, renderer.kernel_events = renderer.kernel_events, None
+        n_events = max(len(kernel_events), 1)
+        classify_ms = sum(c0.elapsed_time(c1) for c0, c1, _, _ in kernel_events) / n_events
+        march_ms = sum(m0.elapsed_time(m1) for _, _, m0, m1 in kernel_events) / n_events
+        spans = []
+        for c0, c1, m0, m1 in kernel_events:
+            spans.append((epoch.elapsed_time(c0), epoch.elapsed_time(c1)))
+            spans.append((epoch.elapsed_time(m0), epoch.elapsed_time(m1)))
+        spans.sort()
+        busy, cursor = 0.0, float("-inf")
+        for begin, end in spans:
+            if end > cursor:
+                busy += end - max(begin, cursor)
+                cursor = end
+        kernel_ms = busy / n_events
 
     samples_total = sum(frame_samples[i % len(cameras)] for i in range(args.steps))
     ms_per_step = elapsed * 1e3 / args.steps
@@ -376,6 +385,9 @@ def main():
                         f"box_transparency={args.transparency}, default jet map, "
                         f"{len(cameras)} view(s)",
             "ownership": args.ownership, "runs_total": total_runs,
+            "frame_driver": ("C++ (avr_renderer: 3 HIP streams" +
+                             (", RCCL exchange + gather" if world > 1 else "") + ")") if native
+                            else "Python rehearsal pipeline (torch streams, gloo through host copies)",
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),

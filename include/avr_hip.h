@@ -101,6 +101,13 @@ int avr_abi_version(void);
 int avr_context_create(int device_id, avr_context **out_ctx);
 void avr_context_destroy(avr_context *ctx);
 
+/* The same with the context's own stream created in the device's most urgent priority class
+ * (high_priority != 0) or in the default class. */
+int avr_context_create_with_priority(int device_id, int high_priority, avr_context **out_ctx);
+
+/* The stream the context launches on (hipStream_t as void*), for ordering other work against it. */
+void *avr_context_stream(avr_context *ctx);
+
 /* Use an externally owned HIP stream (hipStream_t passed as void*; NULL = the context's own).
  * All launches of the context go to this stream; nothing in this ABI synchronises the stream
  * except avr_context_synchronize and the *_host readbacks. */
@@ -329,6 +336,110 @@ int avr_downsample_depthsort(avr_context *ctx, const float *src, int target_w, i
  * image of `stride` floats per pixel, rows written top-down (y = h-1 .. 0). dst = w*h*3 bytes. */
 int avr_quantize_rgb8(avr_context *ctx, const float *src, int w, int h, int stride,
                       uint8_t *dst);
+
+/* Rows of an h-row byte image in reverse order: the composited image has its origin bottom-left,
+ * the output file's rows run top-down (Common/SavePPM.cpp:25, Common/SavePNG.cpp:64-71). */
+int avr_flip_rows(avr_context *ctx, const uint8_t *src, int64_t row_bytes, int h, uint8_t *dst);
+
+/* ---- rank communicator: the DirectSend exchange and the gather over RCCL / xGMI ----------- */
+
+/* One communicator per rank (= per GPU, one process per rank).  Replaces the MPI communicator +
+ * group handed to Compositor::compose (Common/Compositor.hpp:35-37): the image-fragment exchange
+ * of DirectSendBase::PostSends / PostReceives (DirectSend/Base/DirectSendBase.cpp:76-177) and
+ * ImageFull::Gather (Common/ImageColorOnly.hpp:220-270) become one grouped ncclSend / ncclRecv
+ * round each, on device buffers, launched on the calling context's stream.
+ *
+ * avr_comm_unique_id is called on ONE rank; the caller distributes the id to the others by its
+ * own means (the reference's host already has MPI: MPI_Bcast of 128 bytes; torch.distributed's
+ * store in the Python layer); then every rank calls avr_comm_create (collective). */
+typedef struct avr_comm avr_comm;
+#define AVR_COMM_ID_BYTES 128
+int avr_comm_unique_id(char id_out[AVR_COMM_ID_BYTES]);
+int avr_comm_create(int device_id, const char id[AVR_COMM_ID_BYTES], int rank, int n_ranks,
+                    avr_comm **out_comm);
+/* In-process rehearsal of an N-rank frame on ONE GPU: n_ranks connected communicators for n_ranks
+ * host threads of this process (host-synchronous device copies).  Not a performance path -- RCCL
+ * cannot place two ranks on one device, and this keeps the N-rank frame testable there. */
+int avr_comm_create_local(int n_ranks, avr_comm **out_comms /* [n_ranks] */);
+void avr_comm_destroy(avr_comm *comm);
+int avr_comm_rank(const avr_comm *comm);
+int avr_comm_size(const avr_comm *comm);
+
+/* The sparse all-to-all of one frame (layout: "frame plan" above): block for peer s of `send` goes
+ * to rank s, `recv` receives the blocks of all ranks for this rank's piece.  Collective; on the
+ * context's stream. */
+int avr_exchange(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm, const float *send,
+                 float *recv);
+/* ImageFull::Gather: every rank's piece (bytes_per_pixel bytes per pixel: 20 for the depth-sort
+ * image, 3 for its RGB8 bytes) lands at its pixel range in `full` on rank `root` (full is ignored
+ * elsewhere).  Collective; on the context's stream. */
+int avr_gather(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm, const void *piece,
+               int bytes_per_pixel, void *full, int root);
+
+/* ---- frame driver -------------------------------------------------------------------------- */
+
+/* VolumeRenderer::RenderParameters (VolumeRenderer/VolumeRenderer.hpp:33-44), the fields the hot
+ * path reads.  draw_bounds: the reference always blends the wireframe of the tight bounds over the
+ * final image (VolumeRenderer.cpp:1311-1314); 0 leaves it out. */
+typedef struct {
+  int32_t width, height;
+  float box_transparency;
+  int32_t antialiasing;
+  int32_t use_visibility_graph;
+  int32_t draw_bounds;
+  int32_t write_visibility_graph;
+} avr_render_params;
+
+/* One rank's share of VolumeRenderer::renderSingleTrial (VolumeRenderer.cpp:1103-1339) from the
+ * per-box loop to the 8-bit image, pipelined over three HIP streams of its own: frame i+1 is
+ * classified while frame i is marched and frame i-1 is exchanged, folded and gathered.
+ *   all_boxes / owner   metadata of EVERY box of the scene (replicated on all ranks), level-major;
+ *                       the boxes of `rank` must carry their cell pointers (HBM);
+ *   comm                NULL for one rank.
+ * Replaces the function-local static VolumePainter / DirectSendBase pair of
+ * VolumeRenderer.cpp:909-927 together with the loop that drives them. */
+typedef struct avr_renderer avr_renderer;
+int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm *comm,
+                        const avr_box *all_boxes, const int32_t *owner, int n_boxes,
+                        const avr_scalar_transform *transform, const double bounds_min[3],
+                        const double bounds_max[3], const float scalar_range[2],
+                        const avr_colormap_point *colormap, int colormap_count,
+                        avr_renderer **out_renderer);
+void avr_renderer_destroy(avr_renderer *renderer);
+/* march_workgroups_per_cu: -1 default (5 for one rank re-classifying every frame, else uncapped),
+ * 0..8 as avr_context_set_march_occupancy.  cache_classification: avr_scene_set_classification_cache. */
+int avr_renderer_set_options(avr_renderer *renderer, int march_workgroups_per_cu,
+                             int cache_classification);
+/* geometry.scalarRange of the scene (VolumeRenderer.hpp:74-89) for the frames that follow. */
+int avr_renderer_set_scalar_range(avr_renderer *renderer, const float scalar_range[2]);
+/* avr_scene_invalidate for the renderer's scene: call after changing cell data in place while
+ * cache_classification is on. */
+int avr_renderer_invalidate(avr_renderer *renderer);
+int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
+/* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
+ * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream
+ * whose queued work produces the cell data; the classify pass is ordered after it.
+ * samples_out (device, may be NULL) as avr_paint_box.  On rank 0: rgb8_out (device,
+ * width*height*3 bytes, rows top-down = the output file's pixel bytes, required) and image_out
+ * (device, optional: the gathered -- with antialiasing downsampled and overlaid -- depth-sort
+ * image, width*height*5 floats, origin bottom-left).  Other ranks pass NULL.  The outputs are
+ * complete when the compositing stream (avr_renderer_stream(r, 2)) reaches this point:
+ * avr_renderer_synchronize, or order your stream after it. */
+int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
+                        const avr_camera *camera, const int32_t *group_order, void *input_stream,
+                        uint64_t *samples_out, uint8_t *rgb8_out, float *image_out);
+int avr_renderer_synchronize(avr_renderer *renderer);
+/* which: 0 classify, 1 march, 2 exchange / fold / gather / tail (hipStream_t as void*). */
+void *avr_renderer_stream(avr_renderer *renderer, int which);
+/* The plan of the last frame rendered (runs, piece, exchange volume). */
+int avr_renderer_plan_info(const avr_renderer *renderer, avr_frame_plan_info *out);
+/* Kernel timing for the benchmark: while enabled every frame records HIP events around its
+ * classify pass and its march on the streams they are launched on.  avr_renderer_timings drains
+ * the streams and returns the averages per frame since timing was enabled: each kernel's own
+ * duration and the length of the union of their execution intervals (they overlap by design). */
+int avr_renderer_set_timing(avr_renderer *renderer, int enabled);
+int avr_renderer_timings(avr_renderer *renderer, double *classify_ms, double *march_ms,
+                         double *busy_ms, int *frames);
 
 /* ---- visibility ordering ------------------------------------------------ */
 

@@ -198,7 +198,7 @@ def test_classification_cache_is_exact_and_invalidates(O, ctx):
     torch.cuda.synchronize()
     stale = frames(cached, cams[:2])
     assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(before, stale))
-    cached.scene.invalidate()
+    cached.invalidate()
     fresh = frames(cached, cams[:2])
     truth = frames(FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range),
                    cams[:2])
