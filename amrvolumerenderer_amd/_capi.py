@@ -138,6 +138,9 @@ SIGNATURES = {
     "avr_frame_plan_create": (C.c_int, [C.POINTER(Box), _ip, C.c_int, C.c_int, C.c_int, _ip,
                                          C.POINTER(PaintParams), C.POINTER(Camera),
                                          C.POINTER(_vp)]),
+    "avr_layered_plan_create": (C.c_int, [_fp, _ip, C.c_int, C.c_int, C.c_int, _ip, C.c_int,
+                                           C.c_int, C.POINTER(_vp)]),
+    "avr_pack_layers": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.c_int, _vp]),
     "avr_frame_plan_destroy": (None, [_vp]),
     "avr_frame_plan_get_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),
     "avr_frame_plan_splits": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -197,7 +200,7 @@ SIGNATURES = {
     "avr_renderer_invalidate": (C.c_int, [_vp]),
     "avr_renderer_reference_sample_distance": (C.c_int, [_vp, _fp]),
     "avr_renderer_render": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip, _vp,
-                                       _vp, _vp, _vp]),
+                                       _vp, C.c_int, _vp, _vp]),
     "avr_renderer_synchronize": (C.c_int, [_vp]),
     "avr_renderer_stream": (_vp, [_vp, C.c_int]),
     "avr_renderer_plan_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),

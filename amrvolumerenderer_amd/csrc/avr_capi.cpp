@@ -621,6 +621,71 @@ int avr_frame_plan_create(const avr_box* all_boxes, const int32_t* owner, int n_
   });
 }
 
+int avr_layered_plan_create(const float* hints, const int32_t* owner, int n_layers, int n_ranks,
+                            int rank, const int32_t* group_order, int width, int height,
+                            avr_frame_plan** out_plan) {
+  return guarded([&]() -> int {
+    require(out_plan != nullptr, "null argument");
+    *out_plan = nullptr;
+    auto* plan = new avr_frame_plan();
+    try {
+      plan->params.width = width;
+      plan->params.height = height;
+      avr::build_layer_plan(n_layers, hints, owner, nullptr, n_ranks, rank, group_order, width,
+                            height, plan);
+    } catch (...) {
+      delete plan;
+      throw;
+    }
+    *out_plan = plan;
+    return AVR_OK;
+  });
+}
+
+int avr_pack_layers(avr_context* ctx, const avr_frame_plan* plan, const float* const* local_layers,
+                    int n_local_layers, float* send_buffer) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(plan != nullptr, "null plan");
+    require(n_local_layers == plan->info.n_local_boxes, "layer count does not match the plan");
+    require(n_local_layers == 0 || local_layers != nullptr, "null layer list");
+    require(plan->info.send_floats == 0 || send_buffer != nullptr, "null send buffer");
+    const int n_ranks = plan->info.n_ranks;
+    const int64_t width = plan->params.width;
+    int start = 0;
+    std::vector<const float*> slices;
+    for (int r = 0; r < plan->info.n_local_runs; ++r) {
+      const int end = plan->local_run_end[static_cast<size_t>(r)];
+      const avr::RunRectDev& rect = plan->local_rects[static_cast<size_t>(r)];
+      require(rect.x0 == 0 && rect.x1 == width - 1, "avr_pack_layers needs a full-width layered plan");
+      for (int piece = 0; piece < n_ranks; ++piece) {
+        const size_t at = static_cast<size_t>(r) * n_ranks + static_cast<size_t>(piece);
+        const int rows = plan->send_block_rows[at];
+        if (rows == 0) continue;
+        const int64_t first_pixel = static_cast<int64_t>(plan->send_blocks[at].first_row) * width;
+        slices.clear();
+        for (int l = start; l < end; ++l) {
+          const int32_t local = plan->local_order[static_cast<size_t>(l)];
+          require(local >= 0 && local < n_local_layers && local_layers[local] != nullptr,
+                  "invalid local layer");
+          slices.push_back(local_layers[local] + first_pixel * 5);
+        }
+        // owner-side fold of the run's layers, in order (DirectSendBase.cpp:413-426), over the
+        // block's whole rows
+        ctx->staging.begin(slices.size() * sizeof(float*), 1);
+        const float* const* slices_dev = ctx->staging.add(slices.data(), slices.size());
+        ctx->staging.commit(ctx->stream);
+        const int status = avr::launch_fold_runs(slices_dev, static_cast<int>(slices.size()),
+                                                 send_buffer + plan->send_blocks[at].offset,
+                                                 static_cast<int64_t>(rows) * width, ctx->stream);
+        if (status != AVR_OK) return status;
+      }
+      start = end;
+    }
+    return AVR_OK;
+  });
+}
+
 void avr_frame_plan_destroy(avr_frame_plan* plan) { delete plan; }
 
 int avr_frame_plan_get_info(const avr_frame_plan* plan, avr_frame_plan_info* out) {

@@ -269,12 +269,22 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
     // RCCL: one grouped round; a rank's block for itself is a device copy
     const avr::Rccl& api = avr::rccl();
     const int64_t own = plan->send_splits[static_cast<size_t>(me)];
+    if (n == 1) {
+      // a one-rank communicator only exists to exercise this path where a single GPU is all
+      // there is: the block for itself goes through ncclSend / ncclRecv like any other
+      if (own > 0) {
+        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        avr::nccl_ok(api.send(send, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclSend");
+        avr::nccl_ok(api.recv(recv, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclRecv");
+        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+      }
+      return AVR_OK;
+    }
     if (own > 0) {
       avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(me)], send + send_at[static_cast<size_t>(me)],
                                  static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
                   "hipMemcpyAsync(exchange)");
     }
-    if (n == 1) return AVR_OK;
     avr::nccl_ok(api.group_start(), "ncclGroupStart");
     for (int s = 0; s < n; ++s) {
       if (s == me) continue;
@@ -333,12 +343,22 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       return AVR_OK;
     }
     const avr::Rccl& api = avr::rccl();
+    if (n == 1) {  // as in avr_exchange: the one-rank case goes through RCCL on purpose
+      if (my_end > my_begin) {
+        const size_t bytes = static_cast<size_t>(my_end - my_begin) * bytes_per_pixel;
+        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        avr::nccl_ok(api.send(piece, bytes, ncclChar, 0, comm->nccl, stream), "ncclSend");
+        avr::nccl_ok(api.recv(dst + my_begin * bytes_per_pixel, bytes, ncclChar, 0, comm->nccl, stream),
+                     "ncclRecv");
+        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+      }
+      return AVR_OK;
+    }
     if (me == root && my_end > my_begin) {
       avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
                                  static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                  hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
     }
-    if (n == 1) return AVR_OK;
     avr::nccl_ok(api.group_start(), "ncclGroupStart");
     if (me == root) {
       for (int s = 0; s < n; ++s) {

@@ -6,6 +6,7 @@
 #include "avr_plan.h"
 
 #include <algorithm>
+#include <array>
 #include <stdexcept>
 
 namespace avr {
@@ -76,24 +77,21 @@ void dense_run_tables(int width, int height, int n_runs, int n_pieces,
   }
 }
 
-void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
-                      int rank, const int32_t* group_order, const avr_paint_params& params,
-                      const avr_camera& camera, avr_frame_plan* plan) {
+// The plan of a set of layers described only by (depth hint, owner, screen rectangle): global
+// order, runs, exchange layout.  layer l's local index is its position among its owner's layers.
+void build_layer_plan(int n_layers, const float* hints, const int32_t* owner,
+                      const int32_t (*rects)[4], int n_ranks, int rank, const int32_t* group_order,
+                      int width, int height, avr_frame_plan* plan) {
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("invalid rank");
-  if (n_boxes < 0 || (n_boxes > 0 && (all_boxes == nullptr || owner == nullptr))) {
-    throw std::invalid_argument("invalid box list");
+  if (n_layers < 0 || (n_layers > 0 && (hints == nullptr || owner == nullptr))) {
+    throw std::invalid_argument("invalid layer list");
   }
-  if (params.width <= 0 || params.height <= 0) {
+  if (width <= 0 || height <= 0) {
     throw std::invalid_argument("image width and height must be positive");
   }
-  const int width = params.width, height = params.height;
   const int64_t n_pixels = static_cast<int64_t>(width) * height;
   if (n_pixels > (int64_t{1} << 31) - 1) throw std::invalid_argument("image too large");
-
-  plan->params = params;
-  plan->colormap.assign(params.colormap, params.colormap + std::max(params.colormap_count, 0));
-  plan->params.colormap = plan->colormap.empty() ? nullptr : plan->colormap.data();
-  plan->camera = camera;
+  const int n_boxes = n_layers;
 
   // group order / pieces
   plan->group_order.resize(static_cast<size_t>(n_ranks));
@@ -108,18 +106,16 @@ void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxe
   }
 
   // what the reference all-gathers: per layer (depth hint, owner, local index)
-  std::vector<float> hints(static_cast<size_t>(n_boxes));
   std::vector<int32_t> local_index(static_cast<size_t>(n_boxes));
   std::vector<int32_t> boxes_of_rank(static_cast<size_t>(n_ranks), 0);
   for (int b = 0; b < n_boxes; ++b) {
     if (owner[b] < 0 || owner[b] >= n_ranks) throw std::invalid_argument("box owner out of range");
-    hints[static_cast<size_t>(b)] = box_depth_hint(all_boxes[b], camera);
     local_index[static_cast<size_t>(b)] = boxes_of_rank[static_cast<size_t>(owner[b])]++;
   }
   plan->layer_box.assign(static_cast<size_t>(n_boxes), 0);
   std::vector<int32_t> run_end(static_cast<size_t>(std::max(n_boxes, 1)));
   const int n_runs = (n_boxes > 0)
-                         ? layer_order(hints.data(), owner, local_index.data(), n_boxes,
+                         ? layer_order(hints, owner, local_index.data(), n_boxes,
                                        plan->layer_box.data(), run_end.data())
                          : 0;
 
@@ -130,6 +126,7 @@ void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxe
   plan->local_run_end.clear();
   plan->local_rects.clear();
   std::vector<int32_t> runs_of_rank(static_cast<size_t>(n_ranks), 0);
+  const int32_t full_rect[4] = {0, 0, width - 1, height - 1};
   int start = 0;
   for (int g = 0; g < n_runs; ++g) {
     const int end = run_end[static_cast<size_t>(g)];
@@ -141,9 +138,7 @@ void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxe
     RunRectDev rect = empty_rect();
     for (int l = start; l < end; ++l) {
       const int32_t box = plan->layer_box[static_cast<size_t>(l)];
-      int32_t box_rect[4];
-      box_screen_rect(all_boxes[box], camera, width, height, box_rect);
-      grow(&rect, box_rect);
+      grow(&rect, rects != nullptr ? rects[box] : full_rect);
       if (run.owner == rank) plan->local_order.push_back(local_index[static_cast<size_t>(box)]);
     }
     run.rect[0] = rect.x0;
@@ -215,6 +210,33 @@ void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxe
   info.piece_end = my_rows.end;
   info.send_floats = send_floats;
   info.recv_floats = cursor;
+}
+
+void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
+                      int rank, const int32_t* group_order, const avr_paint_params& params,
+                      const avr_camera& camera, avr_frame_plan* plan) {
+  if (n_boxes < 0 || (n_boxes > 0 && (all_boxes == nullptr || owner == nullptr))) {
+    throw std::invalid_argument("invalid box list");
+  }
+  if (params.width <= 0 || params.height <= 0) {
+    throw std::invalid_argument("image width and height must be positive");
+  }
+  plan->params = params;
+  plan->colormap.assign(params.colormap, params.colormap + std::max(params.colormap_count, 0));
+  plan->params.colormap = plan->colormap.empty() ? nullptr : plan->colormap.data();
+  plan->camera = camera;
+  // depth hints depend only on box corners and the camera (VolumeRenderer.cpp:541-553), and so do
+  // the conservative screen rectangles: every rank derives them from the replicated metadata
+  std::vector<float> hints(static_cast<size_t>(std::max(n_boxes, 1)));
+  std::vector<std::array<int32_t, 4>> rects(static_cast<size_t>(std::max(n_boxes, 1)));
+  for (int b = 0; b < n_boxes; ++b) {
+    hints[static_cast<size_t>(b)] = box_depth_hint(all_boxes[b], camera);
+    box_screen_rect(all_boxes[b], camera, params.width, params.height,
+                    rects[static_cast<size_t>(b)].data());
+  }
+  build_layer_plan(n_boxes, hints.data(), owner,
+                   reinterpret_cast<const int32_t(*)[4]>(rects.data()), n_ranks, rank, group_order,
+                   params.width, params.height, plan);
 }
 
 }  // namespace avr

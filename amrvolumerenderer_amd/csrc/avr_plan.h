@@ -39,6 +39,12 @@ namespace avr {
 void dense_run_tables(int width, int height, int n_runs, int n_pieces,
                       std::vector<RunRectDev>* rects, std::vector<RunBlockDev>* blocks);
 
+// A plan for layers known only by (depth hint, owner[, screen rectangle]) -- the generic
+// Compositor::compose case; rects == nullptr: every layer covers the whole image.
+void build_layer_plan(int n_layers, const float* hints, const int32_t* owner,
+                      const int32_t (*rects)[4], int n_ranks, int rank, const int32_t* group_order,
+                      int width, int height, avr_frame_plan* plan);
+
 void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
                       int rank, const int32_t* group_order, const avr_paint_params& params,
                       const avr_camera& camera, avr_frame_plan* plan);

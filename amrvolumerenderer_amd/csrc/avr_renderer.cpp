@@ -396,13 +396,15 @@ int avr_renderer_timings(avr_renderer* r, double* classify_ms, double* march_ms,
 
 int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const avr_camera* camera,
                         const int32_t* group_order, void* input_stream, uint64_t* samples_out,
-                        uint8_t* rgb8_out, float* image_out) {
+                        int want_image, uint8_t* rgb8_out, float* image_out) {
   return guarded([&]() -> int {
     require(r != nullptr && render != nullptr && camera != nullptr, "null argument");
     const int root = validate(*render);
     hip_ok(hipSetDevice(r->device), "hipSetDevice");
     const bool is_root = r->rank == 0;
     require(!is_root || rgb8_out != nullptr, "the root rank needs an rgb8 output buffer");
+    require(!is_root || !want_image || image_out != nullptr,
+            "want_image needs an image output buffer on the root rank");
     const int width = render->width, height = render->height;
     const int render_w = width * root, render_h = height * root;
 
@@ -509,8 +511,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // bounds is per pixel too, so each rank overlays its own piece
     const bool early_rgb8 = root == 1;
     const bool overlay_piece = early_rgb8 && render->draw_bounds;
-    const bool want_image = image_out != nullptr;
-    const bool bytes_only = early_rgb8 && !overlay_piece && !want_image;
+    const bool gather_image = want_image != 0;  // the same on every rank: it adds a collective
+    const bool bytes_only = early_rgb8 && !overlay_piece && !gather_image;
     float* piece = nullptr;
     uint8_t* piece_rgb8 = nullptr;
     if (!bytes_only) {
@@ -539,7 +541,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         abi_ok(avr_gather(r->compose, plan, r->comm, piece_rgb8, 3, full, 0));
       }
       if (is_root) abi_ok(avr_flip_rows(r->compose, full, width * 3, height, rgb8_out));
-      if (want_image) {
+      if (gather_image) {
         if (r->n_ranks > 1) {
           abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, is_root ? image_out : nullptr, 0));
         } else {
@@ -555,7 +557,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, full, 0));
       }
       if (is_root) {
-        float* small = want_image ? image_out
+        float* small = gather_image ? image_out
                                   : static_cast<float*>(r->small_image.reserve(
                                         static_cast<size_t>(width) * height * 20, drain));
         abi_ok(avr_downsample_depthsort(r->compose, full, width, height, root, small));

@@ -699,7 +699,7 @@ class NativeRenderer:
             self.streams[1].wait_stream(caller)
         _capi.check(_capi.lib().avr_renderer_render(
             self._handle, C.byref(rp), C.byref(ccam), group, wait,
-            C.c_void_p(samples.data_ptr()) if samples is not None else None,
+            C.c_void_p(samples.data_ptr()) if samples is not None else None, int(bool(want_image)),
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
             C.c_void_p(image.data_ptr()) if image is not None else None))
         return image, rgb8

@@ -256,6 +256,20 @@ int avr_frame_plan_create(const avr_box *all_boxes, const int32_t *owner, int n_
                           int n_ranks, int rank, const int32_t *group_order,
                           const avr_paint_params *params, const avr_camera *camera,
                           avr_frame_plan **out_plan);
+/* The same plan for layers that are only known as images with a depth hint -- the generic
+ * Compositor::compose(Image*, MPI_Group, MPI_Comm) of a LayeredImageInterface
+ * (DirectSend/Base/DirectSendBase.cpp:316-458): hints[l] / owner[l] for ALL layers of all ranks in
+ * rank-major order (what the reference's MPI_Allgatherv of the depth hints delivers, :354-361; a
+ * layer's local index is its position among its owner's layers).  Every run covers the whole
+ * image.  Use with avr_pack_layers, avr_exchange, avr_fold_plan. */
+int avr_layered_plan_create(const float *hints, const int32_t *owner, int n_layers, int n_ranks,
+                            int rank, const int32_t *group_order, int width, int height,
+                            avr_frame_plan **out_plan);
+/* Owner-side run fold of already painted layers (DirectSendBase.cpp:413-426) into the send buffer
+ * of a layered plan: local_layers[i] = device pointer to this rank's layer i (width*height*5
+ * floats), host array. */
+int avr_pack_layers(avr_context *ctx, const avr_frame_plan *plan, const float *const *local_layers,
+                    int n_local_layers, float *send_buffer);
 void avr_frame_plan_destroy(avr_frame_plan *plan);
 int avr_frame_plan_get_info(const avr_frame_plan *plan, avr_frame_plan_info *out);
 /* all_to_all split sizes in floats, indexed by peer rank (n_ranks entries each). */
@@ -419,15 +433,16 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream
  * whose queued work produces the cell data; the classify pass is ordered after it.
- * samples_out (device, may be NULL) as avr_paint_box.  On rank 0: rgb8_out (device,
- * width*height*3 bytes, rows top-down = the output file's pixel bytes, required) and image_out
- * (device, optional: the gathered -- with antialiasing downsampled and overlaid -- depth-sort
- * image, width*height*5 floats, origin bottom-left).  Other ranks pass NULL.  The outputs are
+ * samples_out (device, may be NULL) as avr_paint_box.  want_image (the SAME on every rank: it
+ * adds a gather of the float pieces): also deliver the gathered -- with antialiasing downsampled
+ * and overlaid -- depth-sort image.  On rank 0: rgb8_out (device, width*height*3 bytes, rows
+ * top-down = the output file's pixel bytes, required) and, with want_image, image_out (device,
+ * width*height*5 floats, origin bottom-left).  Other ranks pass NULL for both.  The outputs are
  * complete when the compositing stream (avr_renderer_stream(r, 2)) reaches this point:
  * avr_renderer_synchronize, or order your stream after it. */
 int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
                         const avr_camera *camera, const int32_t *group_order, void *input_stream,
-                        uint64_t *samples_out, uint8_t *rgb8_out, float *image_out);
+                        uint64_t *samples_out, int want_image, uint8_t *rgb8_out, float *image_out);
 int avr_renderer_synchronize(avr_renderer *renderer);
 /* which: 0 classify, 1 march, 2 exchange / fold / gather / tail (hipStream_t as void*). */
 void *avr_renderer_stream(avr_renderer *renderer, int which);

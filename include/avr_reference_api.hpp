@@ -25,6 +25,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -362,6 +363,174 @@ class RankFrame {
   avr_frame_plan_info info_{};
   std::vector<int64_t> send_splits_, recv_splits_;
   DeviceBuffer<float> send_, recv_;
+};
+
+// ---- rank communicator ---------------------------------------------------------------------------
+// RAII over avr_comm.  `Control` is the caller's control plane for the three tiny host collectives
+// the compositor needs besides the GPU exchange; inside the reference tree it is MPI
+// (INTEGRATION.md shows the ten-line struct), in this repository's tests a thread barrier:
+//   int  rank() const;  int size() const;
+//   void broadcast(void* data, int bytes, int root);                       // MPI_Bcast
+//   void allgather_int(int value, int* out);                               // MPI_Allgather
+//   void allgatherv_float(const float* in, int n, float* out, const int* counts,
+//                         const int* displs);                              // MPI_Allgatherv
+//   std::vector<int> group_ranks(GroupT group);   // ranks of the ordered group, MPI_Group_translate_ranks
+class Communicator {
+ public:
+  Communicator() = default;
+  explicit Communicator(avr_comm* adopted) : comm_(adopted) {}
+  // One RCCL communicator per rank (= per GPU); collective over `control`.
+  template <class Control>
+  Communicator(Control& control, int device) {
+    char id[AVR_COMM_ID_BYTES];
+    std::memset(id, 0, sizeof(id));
+    if (control.rank() == 0) check(avr_comm_unique_id(id));
+    control.broadcast(id, AVR_COMM_ID_BYTES, 0);
+    check(avr_comm_create(device, id, control.rank(), control.size(), &comm_));
+  }
+  // n connected in-process communicators (one GPU, one host thread per rank): rehearsal only.
+  static std::vector<std::unique_ptr<Communicator>> local(int n_ranks) {
+    std::vector<avr_comm*> raw(static_cast<std::size_t>(n_ranks), nullptr);
+    check(avr_comm_create_local(n_ranks, raw.data()));
+    std::vector<std::unique_ptr<Communicator>> out;
+    for (avr_comm* c : raw) out.push_back(std::make_unique<Communicator>(c));
+    return out;
+  }
+  ~Communicator() { avr_comm_destroy(comm_); }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  avr_comm* get() const { return comm_; }
+  int rank() const { return avr_comm_rank(comm_); }
+  int size() const { return avr_comm_size(comm_); }
+
+ private:
+  avr_comm* comm_ = nullptr;
+};
+
+// ---- Compositor plugin (Common/Compositor.hpp:19-40) -------------------------------------------
+// HipDirectSend::compose has the reference's call shape
+//     std::unique_ptr<Image> compose(Image* localImage, MPI_Group group, MPI_Comm communicator)
+// and DirectSendBase's behaviour (DirectSend/Base/DirectSendBase.cpp:285-458): a localImage that
+// offers the LayeredImageInterface (getLayerCount / getLayer / getLayerDepthHint /
+// createEmptyLayer, Common/LayeredImageInterface.hpp:9-28) is composited by global depth order
+// with same-owner runs folded on the owner; the result is this rank's piece
+// [k * floor(P/N), (k+1) * floor(P/N)) (k = position in the ordered group) of the fully composited
+// image, as a new image of the layers' type.  The layers are host images as in the reference
+// (ImageRGBAFloatColorDepthSort: getColorBuffer(), 5 floats per pixel); they are staged to HBM,
+// exchanged over RCCL and folded there.  This is the drop-in for code that already has painted
+// layers; a renderer that lets this library paint as well uses FrameDriver below and never
+// materialises per-box layers.
+template <class Control>
+class HipDirectSend {
+ public:
+  // one RCCL communicator per rank, built over the control plane (collective)
+  HipDirectSend(Control& control, int device)
+      : control_(control), context_(device), owned_(std::make_unique<Communicator>(control, device)),
+        comm_(owned_.get()) {}
+  // ... or an existing communicator (e.g. the in-process rehearsal one)
+  HipDirectSend(Control& control, int device, Communicator* comm)
+      : control_(control), context_(device), comm_(comm) {}
+
+  // ConcreteT: the layers' image type (the reference's ImageRGBAFloatColorDepthSort; getLayer
+  // and createEmptyLayer hand out its base class `Image` there).  LayeredT: an image that is
+  // also a LayeredImageInterface (the reference's LayeredVolumeImage).
+  template <class ConcreteT, class LayeredT, class GroupT, class CommT>
+  auto compose(LayeredT* localImage, GroupT group, CommT /*communicator*/)
+      -> decltype(localImage->createEmptyLayer(0, 0)) {
+    if (localImage == nullptr) throw std::invalid_argument("compose: null image");
+    const int n_ranks = control_.size(), rank = control_.rank();
+    const int local_count = localImage->getLayerCount();
+    // MPI_Allgather of the layer counts, MPI_Allgatherv of the depth hints (:329-361)
+    std::vector<int> counts(static_cast<std::size_t>(n_ranks)), displs(static_cast<std::size_t>(n_ranks));
+    control_.allgather_int(local_count, counts.data());
+    int total = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+      displs[static_cast<std::size_t>(r)] = total;
+      total += counts[static_cast<std::size_t>(r)];
+    }
+    std::vector<float> mine(static_cast<std::size_t>(local_count > 0 ? local_count : 1));
+    for (int i = 0; i < local_count; ++i) mine[static_cast<std::size_t>(i)] = localImage->getLayerDepthHint(i);
+    std::vector<float> hints(static_cast<std::size_t>(total > 0 ? total : 1));
+    control_.allgatherv_float(mine.data(), local_count, hints.data(), counts.data(), displs.data());
+    std::vector<int32_t> owner(static_cast<std::size_t>(total > 0 ? total : 1));
+    for (int r = 0; r < n_ranks; ++r) {
+      for (int i = 0; i < counts[static_cast<std::size_t>(r)]; ++i) {
+        owner[static_cast<std::size_t>(displs[static_cast<std::size_t>(r)] + i)] = r;
+      }
+    }
+    const std::vector<int> ordered = control_.group_ranks(group);
+    std::vector<int32_t> group_order(ordered.begin(), ordered.end());
+    const int width = localImage->getWidth(), height = localImage->getHeight();
+    avr_frame_plan* plan = nullptr;
+    check(avr_layered_plan_create(hints.data(), owner.data(), total, n_ranks, rank, group_order.data(),
+                                  width, height, &plan));
+    std::unique_ptr<avr_frame_plan, void (*)(avr_frame_plan*)> plan_guard(plan, avr_frame_plan_destroy);
+    avr_frame_plan_info info{};
+    check(avr_frame_plan_get_info(plan, &info));
+    // stage the local layers, fold the local runs into the send layout
+    const std::size_t floats = static_cast<std::size_t>(width) * height * 5;
+    std::vector<std::unique_ptr<DeviceBuffer<float>>> staged;
+    std::vector<const float*> pointers;
+    for (int i = 0; i < local_count; ++i) {
+      auto buffer = std::make_unique<DeviceBuffer<float>>(floats);
+      buffer->upload(static_cast<ConcreteT*>(localImage->getLayer(i))->getColorBuffer(), floats);
+      pointers.push_back(buffer->data());
+      staged.push_back(std::move(buffer));
+    }
+    DeviceBuffer<float> send(static_cast<std::size_t>(info.send_floats) + 1),
+        recv(static_cast<std::size_t>(info.recv_floats) + 1);
+    check(avr_pack_layers(context_.get(), plan, pointers.data(), local_count, send.data()));
+    check(avr_exchange(context_.get(), plan, comm_->get(), send.data(), recv.data()));
+    const std::size_t piece_pixels = static_cast<std::size_t>(info.piece_end - info.piece_begin);
+    DeviceBuffer<float> piece(piece_pixels * 5 + 1);
+    check(avr_fold_plan(context_.get(), plan, recv.data(), piece.data(), nullptr));
+    context_.synchronize();
+    // the result image: this rank's pixel range, created like the reference's empty layer
+    auto result = localImage->createEmptyLayer(static_cast<int>(info.piece_begin),
+                                               static_cast<int>(info.piece_end));
+    piece.download(static_cast<ConcreteT*>(result.get())->getColorBuffer(), piece_pixels * 5);
+    return result;
+  }
+
+ private:
+  Control& control_;
+  Context context_;
+  std::unique_ptr<Communicator> owned_;
+  Communicator* comm_ = nullptr;
+};
+
+// ---- frame driver: one rank's share of renderSingleTrial, pipelined (avr_renderer) --------------
+// all_boxes / owner: the replicated metadata of every box (this rank's boxes with device cell
+// pointers).  render() returns immediately; outputs are complete after synchronize().
+class FrameDriver {
+ public:
+  FrameDriver(int device, int rank, int n_ranks, Communicator* comm, const std::vector<avr_box>& all_boxes,
+              const std::vector<int32_t>& owner, const avr_scalar_transform& transform,
+              const double bounds_min[3], const double bounds_max[3], float range_min = 0.0f,
+              float range_max = 1.0f, const std::vector<avr_colormap_point>& colormap = {}) {
+    const float range[2] = {range_min, range_max};
+    check(avr_renderer_create(device, rank, n_ranks, comm != nullptr ? comm->get() : nullptr,
+                              all_boxes.data(), owner.data(), static_cast<int>(all_boxes.size()),
+                              &transform, bounds_min, bounds_max, range,
+                              colormap.empty() ? nullptr : colormap.data(),
+                              static_cast<int>(colormap.size()), &renderer_));
+  }
+  ~FrameDriver() { avr_renderer_destroy(renderer_); }
+  FrameDriver(const FrameDriver&) = delete;
+  FrameDriver& operator=(const FrameDriver&) = delete;
+  avr_renderer* get() const { return renderer_; }
+  // rgb8_out / image_out: device buffers on rank 0 (W*H*3 bytes rows top-down; W*H*5 floats), else null
+  // want_image must be the same on every rank (it adds a gather of the float pieces)
+  void render(const avr_render_params& params, const avr_camera& camera, unsigned char* rgb8_out,
+              bool want_image = false, float* image_out = nullptr,
+              const int32_t* group_order = nullptr, uint64_t* samples_out = nullptr) {
+    check(avr_renderer_render(renderer_, &params, &camera, group_order, nullptr, samples_out,
+                              want_image ? 1 : 0, rgb8_out, image_out));
+  }
+  void synchronize() { check(avr_renderer_synchronize(renderer_)); }
+
+ private:
+  avr_renderer* renderer_ = nullptr;
 };
 
 }  // namespace avr

@@ -20,6 +20,11 @@
 static const float kSoftClipTolerance = 1e-5f;                /* VolumePainter.cpp:36 */
 static const float kPi = 3.14159265358979323846f;             /* VolumePainter.cpp:37 */
 
+/* 0 = the restatement of the reference (always, except in tools/appb_hash_search.py, which
+ * enumerates what an AMReX header shim could have done differently from AMReX 26.04) */
+static int orc_shim_variant = 0;
+void orc_set_shim_variant(int variant) { orc_shim_variant = variant; }
+
 /* ---- std:: helpers with libstdc++ semantics (NaN handling matters) ---------------------- */
 static inline float clampf(float v, float lo, float hi) { /* std::clamp */
   return (v < lo) ? lo : ((hi < v) ? hi : v);
@@ -506,7 +511,14 @@ static uint64_t march_pixel(const march_consts *k, int index, float out_color[4]
 
   const float len_sq = dir_x * dir_x + dir_y * dir_y + dir_z * dir_z;
   /* host amrex::Math::rsqrt(x) = 1/sqrt(x)   */
-  const float dir_len = (len_sq > 0.0f) ? (1.0f / (1.0f / sqrtf(len_sq))) : 0.0f;
+  float dir_len = (len_sq > 0.0f) ? (1.0f / (1.0f / sqrtf(len_sq))) : 0.0f;
+  if (orc_shim_variant == 1 && len_sq > 0.0f) {
+    /* tools/appb_hash_search.py only: a header shim whose rsqrt works in amrex::Real (double) */
+    dir_len = (float)(1.0 / (1.0 / sqrt((double)len_sq)));
+  } else if (orc_shim_variant == 2 && len_sq > 0.0f) {
+    /* ... or one that returns the float result of a double computation */
+    dir_len = 1.0f / (float)(1.0 / sqrt((double)len_sq));
+  }
   if (dir_len > 0.0f) {
     const float inv = 1.0f / dir_len;
     dir_x *= inv;

@@ -91,6 +91,10 @@ void orc_box_sampling(const orc_box *box, const orc_paint_params *params,
  * (r,g,b,a,depth; the ImageRGBAFloatColorDepthSort buffer).  Returns the number of executed
  * cell fetches (iterations reaching VolumePainter.cpp:870).  threads>1 splits rows over
  * OpenMP threads (results are per-pixel independent, so bits do not change). */
+/* Search tool only (tools/appb_hash_search.py): variants of what a header shim might have
+ * computed differently from AMReX; 0 (the default) is the restatement of the reference. */
+void orc_set_shim_variant(int variant);
+
 uint64_t orc_paint_box(const orc_box *box, const orc_transform *transform,
                        const orc_paint_params *params, const orc_camera *camera,
                        float *out_rgbad, int threads);

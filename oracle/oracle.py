@@ -153,6 +153,8 @@ def lib():
         L.orc_bbox_overlay.argtypes = [dp, dp, C.POINTER(Camera), C.c_int, C.c_void_p, C.c_int,
                                        C.c_int]
         L.orc_bbox_overlay.restype = None
+        L.orc_set_shim_variant.argtypes = [C.c_int]
+        L.orc_set_shim_variant.restype = None
         L.orc_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_fnv1a64.restype = C.c_uint64
         _lib = L

@@ -5,15 +5,22 @@
 // the oracle.
 //   adapter_test paint   cells.bin nx ny nz ghost W H out.bin
 //   adapter_test compose layers.bin n_layers n_pixels hints.bin out.bin
-//   adapter_test frame   scene.bin n_ranks W H transparency out_image.bin out_rgb8.bin
+//   adapter_test frame   scene.bin n_ranks W H transparency antialiasing frames out_image.bin out_rgb8.bin
 //     scene.bin: int32 n_boxes, then per box 6 doubles (corners), 3 int32 dims, int32 owner,
-//     nx*ny*nz doubles.  All ranks of the frame are played in this one process: every rank has
-//     its own avr::RankFrame, and the all-to-all is the device-to-device copies below.
+//     nx*ny*nz doubles.  All ranks of the frame are played in this one process, one host thread
+//     per rank as MPI would run one process per rank: every rank owns an avr::FrameDriver (the
+//     pipelined C++ frame driver, avr_renderer) and the ranks are connected by the in-process
+//     rehearsal communicator; `frames` frames are rendered back to back without synchronising.
+//   adapter_test compose_ranks layers.bin n_layers n_ranks W H hints.bin owners.bin group.bin out.bin
+//     Compositor::compose of a LayeredVolumeImage per rank (avr::HipDirectSend), threads as ranks.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/avr_reference_api.hpp"
@@ -67,6 +74,7 @@ using ColorMap = std::vector<ColorMapControlPoint>;
 
 struct DepthSortImage {  // ImageRGBAFloatColorDepthSort: 5 floats per pixel on the host
   int width, height;
+  int regionBegin = 0;
   std::vector<float> buffer;
   DepthSortImage(int w, int h) : width(w), height(h), buffer(static_cast<size_t>(w) * h * 5) {}
   int getWidth() const { return width; }
@@ -75,12 +83,80 @@ struct DepthSortImage {  // ImageRGBAFloatColorDepthSort: 5 floats per pixel on 
   float* getColorBuffer() { return buffer.data(); }
   const float* getColorBuffer() const { return buffer.data(); }
 };
-struct Layered {  // LayeredVolumeImage / LayeredImageInterface
+struct Layered {  // LayeredVolumeImage: an Image that is also a LayeredImageInterface
+  int width = 0, height = 0;
   std::vector<std::unique_ptr<DepthSortImage>> layers;
   std::vector<float> hints;
+  int getWidth() const { return width; }
+  int getHeight() const { return height; }
   int getLayerCount() const { return static_cast<int>(layers.size()); }
   DepthSortImage* getLayer(int i) { return layers[static_cast<size_t>(i)].get(); }
   float getLayerDepthHint(int i) const { return hints[static_cast<size_t>(i)]; }
+  // createEmptyLayer(regionBegin, regionEnd): an image holding that pixel range
+  std::unique_ptr<DepthSortImage> createEmptyLayer(int begin, int end) const {
+    auto image = std::make_unique<DepthSortImage>(end - begin, 1);
+    image->regionBegin = begin;
+    return image;
+  }
+};
+
+// The control plane of the ranks-as-threads rehearsal: what MPI_Comm_rank / MPI_Bcast /
+// MPI_Allgather(v) / MPI_Group_translate_ranks are to the reference's host code.
+struct ThreadWorld {
+  int n = 1;
+  std::mutex mutex;
+  std::condition_variable cv;
+  int waiting = 0;
+  unsigned long generation = 0;
+  std::vector<char> bytes;
+  std::vector<int> ints;
+  std::vector<float> floats;
+  void barrier() {
+    std::unique_lock<std::mutex> lock(mutex);
+    const unsigned long mine = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return generation != mine; });
+    }
+  }
+};
+struct ThreadControl {
+  ThreadWorld* world;
+  int my_rank;
+  int rank() const { return my_rank; }
+  int size() const { return world->n; }
+  void broadcast(void* data, int n_bytes, int root) {
+    if (my_rank == root) world->bytes.assign(static_cast<char*>(data), static_cast<char*>(data) + n_bytes);
+    world->barrier();
+    std::memcpy(data, world->bytes.data(), static_cast<size_t>(n_bytes));
+    world->barrier();
+  }
+  void allgather_int(int value, int* out) {
+    {
+      std::lock_guard<std::mutex> lock(world->mutex);
+      world->ints.resize(static_cast<size_t>(world->n));
+      world->ints[static_cast<size_t>(my_rank)] = value;
+    }
+    world->barrier();
+    std::copy(world->ints.begin(), world->ints.end(), out);
+    world->barrier();
+  }
+  void allgatherv_float(const float* in, int count, float* out, const int* counts, const int* displs) {
+    int total = 0;
+    for (int r = 0; r < world->n; ++r) total += counts[r];
+    {
+      std::lock_guard<std::mutex> lock(world->mutex);
+      world->floats.resize(static_cast<size_t>(total > 0 ? total : 1));
+      std::copy(in, in + count, world->floats.begin() + displs[my_rank]);
+    }
+    world->barrier();
+    std::copy(world->floats.begin(), world->floats.begin() + total, out);
+    world->barrier();
+  }
+  std::vector<int> group_ranks(const std::vector<int>& group) { return group; }
 };
 
 }  // namespace standin
@@ -144,6 +220,8 @@ int main(int argc, char** argv) {
       const std::vector<float> all =
           read_file<float>(argv[2], static_cast<size_t>(n_layers) * n_pixels * 5);
       standin::Layered layered;
+      layered.width = n_pixels;
+      layered.height = 1;
       layered.hints = read_file<float>(argv[5], static_cast<size_t>(n_layers));
       for (int l = 0; l < n_layers; ++l) {
         auto img = std::make_unique<standin::DepthSortImage>(n_pixels, 1);
@@ -155,10 +233,12 @@ int main(int argc, char** argv) {
       write_file(argv[6], out.data(), out.size());
       return 0;
     }
-    if (mode == "frame" && argc == 9) {
+    if (mode == "frame" && argc == 11) {
       const int n_ranks = std::atoi(argv[3]);
       const int W = std::atoi(argv[4]), H = std::atoi(argv[5]);
       const float transparency = static_cast<float>(std::atof(argv[6]));
+      const int antialiasing = std::atoi(argv[7]);
+      const int frames = std::atoi(argv[8]);
       FILE* f = std::fopen(argv[2], "rb");
       if (!f) throw std::runtime_error("cannot read scene");
       int32_t n_boxes = 0;
@@ -195,20 +275,7 @@ int main(int argc, char** argv) {
       std::memset(&transform, 0, sizeof(transform));
       transform.normalize_to_unit_range = 1;
       transform.inverse_normalization_span = 1.0;
-      avr_paint_params params;
-      std::memset(&params, 0, sizeof(params));
-      params.width = W;
-      params.height = H;
-      params.scalar_range[0] = 0.0f;
-      params.scalar_range[1] = 1.0f;
-      params.box_transparency = transparency;
-      double bmin[3] = {-0.05, -0.05, -0.05}, bmax[3] = {1.05, 1.05, 1.05};
-      for (int c = 0; c < 3; ++c) {
-        params.bounds_min[c] = bmin[c];
-        params.bounds_max[c] = bmax[c];
-      }
-      avr::check(avr_reference_sample_distance(boxes.data(), n_boxes, bmin, bmax,
-                                               &params.reference_sample_distance));
+      const double bmin[3] = {-0.05, -0.05, -0.05}, bmax[3] = {1.05, 1.05, 1.05};
       avr_camera camera;
       std::memset(&camera, 0, sizeof(camera));
       const double eye[3] = {2.2, 1.6, 2.9}, look[3] = {0.5, 0.5, 0.5}, up[3] = {0.0, 1.0, 0.0};
@@ -220,67 +287,108 @@ int main(int argc, char** argv) {
       camera.fov_y_degrees = 45.0f;
       camera.near_plane = 0.1f;
       camera.far_plane = 20.0f;
+      avr_render_params render;
+      std::memset(&render, 0, sizeof(render));
+      render.width = W;
+      render.height = H;
+      render.box_transparency = transparency;
+      render.antialiasing = antialiasing;
+      render.use_visibility_graph = 1;
+      render.draw_bounds = 1;
 
-      std::vector<std::unique_ptr<avr::RankFrame>> ranks;
-      for (int r = 0; r < n_ranks; ++r) {
-        ranks.push_back(std::make_unique<avr::RankFrame>(context, boxes, owner, r, n_ranks, transform));
-        ranks.back()->plan(params, camera);
-        ranks.back()->paint();
-      }
-      context.synchronize();
-      // the all-to-all: block for peer d in rank s's send buffer -> block from s in d's recv buffer
-      for (int s = 0; s < n_ranks; ++s) {
-        int64_t send_at = 0;
-        for (int d = 0; d < n_ranks; ++d) {
-          const int64_t count = ranks[static_cast<size_t>(s)]->send_splits()[static_cast<size_t>(d)];
-          int64_t recv_at = 0;
-          for (int k = 0; k < s; ++k) recv_at += ranks[static_cast<size_t>(d)]->recv_splits()[static_cast<size_t>(k)];
-          if (ranks[static_cast<size_t>(d)]->recv_splits()[static_cast<size_t>(s)] != count) {
-            throw std::runtime_error("send / recv splits disagree");
-          }
-          if (count > 0) {
-            avr::hip_ok(hipMemcpy(ranks[static_cast<size_t>(d)]->recv_buffer() + recv_at,
-                                  ranks[static_cast<size_t>(s)]->paint_buffer() + send_at,
-                                  static_cast<size_t>(count) * sizeof(float), hipMemcpyDeviceToDevice),
-                        "hipMemcpy(exchange)");
-          }
-          send_at += count;
-        }
-      }
-      // fold + Gather (pieces concatenated by region begin) + overlay + bytes
+      // one host thread per rank, connected by the in-process rehearsal communicator
+      auto comms = avr::Communicator::local(n_ranks);
       const size_t n_pixels = static_cast<size_t>(W) * H;
-      avr::DeviceBuffer<float> full(n_pixels * 5 + 1);
-      avr::DeviceBuffer<unsigned char> full8(n_pixels * 3 + 1);
-      double tight_min[3], tight_max[3];
-      avr::check(avr_tight_bounds(boxes.data(), n_boxes, bmin, bmax, tight_min, tight_max));
+      avr::DeviceBuffer<float> image(n_pixels * 5 + 1);
+      avr::DeviceBuffer<unsigned char> bytes(n_pixels * 3 + 1);
+      std::vector<std::string> errors(static_cast<size_t>(n_ranks));
+      std::vector<std::thread> threads;
       for (int r = 0; r < n_ranks; ++r) {
-        avr::DeviceBuffer<float> piece;
-        ranks[static_cast<size_t>(r)]->fold(&piece, nullptr);
-        const avr_frame_plan_info& info = ranks[static_cast<size_t>(r)]->info();
-        const size_t n = static_cast<size_t>(info.piece_end - info.piece_begin);
-        // each rank overlays its own piece and converts it to bytes (pixels are independent)
-        avr::check(avr_bbox_overlay(context.get(), tight_min, tight_max, &camera, 1, W, H,
-                                    info.piece_begin, info.piece_end, piece.data(),
-                                    full8.data() + static_cast<size_t>(info.piece_begin) * 3));
-        context.synchronize();
-        if (n > 0) {
-          avr::hip_ok(hipMemcpy(full.data() + static_cast<size_t>(info.piece_begin) * 5, piece.data(),
-                                n * 5 * sizeof(float), hipMemcpyDeviceToDevice), "hipMemcpy(gather)");
-        }
+        threads.emplace_back([&, r] {
+          try {
+            avr::hip_ok(hipSetDevice(0), "hipSetDevice");
+            avr::FrameDriver driver(0, r, n_ranks, n_ranks > 1 ? comms[static_cast<size_t>(r)].get() : nullptr,
+                                    boxes, owner, transform, bmin, bmax);
+            for (int frame = 0; frame < frames; ++frame) {  // pipelined: no synchronisation between
+              driver.render(render, camera, r == 0 ? bytes.data() : nullptr, true,
+                            r == 0 ? image.data() : nullptr);
+            }
+            driver.synchronize();
+          } catch (const std::exception& e) {
+            errors[static_cast<size_t>(r)] = e.what();
+          }
+        });
       }
-      std::vector<float> image(n_pixels * 5);
-      std::vector<unsigned char> bytes(n_pixels * 3);
-      full.download(image.data(), image.size());
-      full8.download(bytes.data(), bytes.size());
-      write_file(argv[7], image.data(), image.size());
-      FILE* out = std::fopen(argv[8], "wb");
-      if (!out || std::fwrite(bytes.data(), 1, bytes.size(), out) != bytes.size()) {
+      for (std::thread& t : threads) t.join();
+      for (const std::string& e : errors) {
+        if (!e.empty()) throw std::runtime_error("rank failed: " + e);
+      }
+      std::vector<float> host_image(n_pixels * 5);
+      std::vector<unsigned char> host_bytes(n_pixels * 3);
+      image.download(host_image.data(), host_image.size());
+      bytes.download(host_bytes.data(), host_bytes.size());
+      write_file(argv[9], host_image.data(), host_image.size());
+      FILE* out = std::fopen(argv[10], "wb");
+      if (!out || std::fwrite(host_bytes.data(), 1, host_bytes.size(), out) != host_bytes.size()) {
         throw std::runtime_error("cannot write rgb8");
       }
       std::fclose(out);
       return 0;
     }
-    std::fprintf(stderr, "usage: adapter_test paint|compose|frame ...\n");
+    if (mode == "compose_ranks" && argc == 11) {
+      const int n_layers = std::atoi(argv[3]);
+      const int n_ranks = std::atoi(argv[4]);
+      const int W = std::atoi(argv[5]), H = std::atoi(argv[6]);
+      const size_t n_pixels = static_cast<size_t>(W) * H;
+      const std::vector<float> all = read_file<float>(argv[2], static_cast<size_t>(n_layers) * n_pixels * 5);
+      const std::vector<float> hints = read_file<float>(argv[7], static_cast<size_t>(n_layers));
+      const std::vector<int32_t> owners = read_file<int32_t>(argv[8], static_cast<size_t>(n_layers));
+      const std::vector<int32_t> group32 = read_file<int32_t>(argv[9], static_cast<size_t>(n_ranks));
+      const std::vector<int> group(group32.begin(), group32.end());
+      standin::ThreadWorld world;
+      world.n = n_ranks;
+      std::vector<float> result(n_pixels * 5, -1.0f);
+      std::vector<std::string> errors(static_cast<size_t>(n_ranks));
+      std::vector<std::thread> threads;
+      for (int r = 0; r < n_ranks; ++r) {
+        threads.emplace_back([&, r] {
+          try {
+            avr::hip_ok(hipSetDevice(0), "hipSetDevice");
+            standin::ThreadControl control{&world, r};
+            // (in the reference tree the communicator is RCCL over xGMI, built from MPI_COMM_WORLD;
+            //  here the ranks share one GPU, so they are wired with the in-process communicator)
+            standin::Layered layered;  // geometry.localBoxes' layers of this rank, in order
+            layered.width = W;
+            layered.height = H;
+            for (int l = 0; l < n_layers; ++l) {
+              if (owners[static_cast<size_t>(l)] != r) continue;
+              auto img = std::make_unique<standin::DepthSortImage>(W, H);
+              std::memcpy(img->getColorBuffer(), all.data() + static_cast<size_t>(l) * n_pixels * 5,
+                          sizeof(float) * n_pixels * 5);
+              layered.layers.push_back(std::move(img));
+              layered.hints.push_back(hints[static_cast<size_t>(l)]);
+            }
+            static std::vector<std::unique_ptr<avr::Communicator>> comms;
+            static std::once_flag once;
+            std::call_once(once, [&] { comms = avr::Communicator::local(n_ranks); });
+            world.barrier();
+            avr::HipDirectSend<standin::ThreadControl> compositor(control, 0, comms[static_cast<size_t>(r)].get());
+            auto piece = compositor.compose<standin::DepthSortImage>(&layered, group, 0);
+            std::memcpy(result.data() + static_cast<size_t>(piece->regionBegin) * 5, piece->getColorBuffer(),
+                        sizeof(float) * static_cast<size_t>(piece->getNumberOfPixels()) * 5);
+          } catch (const std::exception& e) {
+            errors[static_cast<size_t>(r)] = e.what();
+          }
+        });
+      }
+      for (std::thread& t : threads) t.join();
+      for (const std::string& e : errors) {
+        if (!e.empty()) throw std::runtime_error("rank failed: " + e);
+      }
+      write_file(argv[10], result.data(), result.size());
+      return 0;
+    }
+    std::fprintf(stderr, "usage: adapter_test paint|compose|frame|compose_ranks ...\n");
     return 2;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "adapter_test: %s\n", e.what());

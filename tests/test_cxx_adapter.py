@@ -28,7 +28,7 @@ def test_adapter_paint_host_fab_with_ghost_cells(O, avr_lib, tmp_path):
     fab = np.random.default_rng(5).random((nz + 2 * ghost, ny + 2 * ghost, nx + 2 * ghost))
     fab.tofile(tmp_path / "cells.bin")
     subprocess.run([EXE, "paint", str(tmp_path / "cells.bin"), str(nx), str(ny), str(nz),
-                    str(ghost), str(W), str(H), str(tmp_path / "out.bin")], check=True)
+                    str(ghost), str(W), str(H), str(tmp_path / "out.bin")], check=True, timeout=180)
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     valid = np.ascontiguousarray(fab[ghost:-ghost, ghost:-ghost, ghost:-ghost])
     box = O.make_box(valid, (0.1, 0.2, -0.3), (0.8, 0.65, 0.8))
@@ -47,26 +47,30 @@ def test_adapter_single_rank_compose(O, avr_lib, tmp_path):
     np.asarray(hints, np.float32).tofile(tmp_path / "h.bin")
     n_pixels = layers[0].shape[0]
     subprocess.run([EXE, "compose", str(tmp_path / "l.bin"), str(len(layers)), str(n_pixels),
-                    str(tmp_path / "h.bin"), str(tmp_path / "out.bin")], check=True)
+                    str(tmp_path / "h.bin"), str(tmp_path / "out.bin")], check=True, timeout=180)
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     want, _, _ = O.compose_layered(layers, hints, [0] * len(layers), list(range(len(layers))), 1)
     assert_bit_equal(got, want, "C++ single-rank compose")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ranks,policy", [(1, "morton"), (3, "morton"), (4, "round_robin")])
-def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, policy):
-    """The whole frame of INTEGRATION.md section 3 driven from C++ over the C ABI alone
-    (avr::RankFrame: visibility order, frame plan, classify + march, all-to-all as device copies,
-    fold, per-piece overlay + bytes): every rank of the frame is played in one process."""
+@pytest.mark.parametrize("n_ranks,policy,antialiasing", [(1, "morton", 1), (3, "morton", 1),
+                                                         (4, "round_robin", 1), (2, "morton", 4)])
+def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, policy,
+                                                 antialiasing):
+    """The whole frame driven from C++ over the C ABI alone: one avr::FrameDriver (the pipelined
+    avr_renderer: visibility order, frame plan, classify + march on their streams, exchange, fold,
+    overlay, gather, downsample, bytes) per rank, every rank a host thread of one process, wired
+    with the in-process rehearsal communicator; three frames back to back without synchronising."""
     import struct
     from amrvolumerenderer_amd import scenes
     from test_frame_plan import local_indices, oracle_overlay, painted_scene
     subprocess.run(["make", "-C", CXX, "adapter_test"], check=True, stdout=subprocess.DEVNULL)
     W, H, transparency = 96, 64, 0.8
+    root = int(round(antialiasing ** 0.5))
     spec = scenes.make_amr_scene(32, 2, 8, "smooth")
     cam = scenes.default_camera()
-    cells, layers, hints, _ = painted_scene(O, spec, cam, W, H, transparency)
+    cells, layers, hints, _ = painted_scene(O, spec, cam, W * root, H * root, transparency)
     scenes.assign_owners(spec, n_ranks, policy)
     owners = [b.owner for b in spec.boxes]
     with open(tmp_path / "scene.bin", "wb") as fh:
@@ -76,11 +80,48 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
             fh.write(struct.pack("<4i", c.shape[2], c.shape[1], c.shape[0], b.owner))
             fh.write(np.ascontiguousarray(c, dtype="<f8").tobytes())
     subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
-                    str(transparency), str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin")],
-                   check=True)
+                    str(transparency), str(antialiasing), "3", str(tmp_path / "image.bin"),
+                    str(tmp_path / "rgb8.bin")], check=True, timeout=180)
     want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
+    if root > 1:
+        want = O.downsample(want, W, H, root).reshape(-1, 5)
     want = oracle_overlay(O, spec, cells, cam, want, W, H)
     got = np.fromfile(tmp_path / "image.bin", dtype=np.float32)
     assert_bit_equal(got, want, "C++ multi-rank frame")
     got8 = np.fromfile(tmp_path / "rgb8.bin", dtype=np.uint8).reshape(H, W, 3)
-    assert np.array_equal(got8[::-1], O.quantize_rgb8(want, W, H))
+    assert np.array_equal(got8, O.quantize_rgb8(want, W, H))   # rows top-down, the file's bytes
+    scenes.assign_owners(spec, 1, "morton")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,ownership,group", [(2, "round_robin", [1, 0]),
+                                                     (3, "block", [2, 0, 1]),
+                                                     (4, "round_robin", [0, 1, 2, 3])])
+def test_adapter_compositor_plugin_compose(O, avr_lib, tmp_path, n_ranks, ownership, group):
+    """avr::HipDirectSend::compose(Image*, group, communicator) -- the Compositor plugin interface
+    (Common/Compositor.hpp:35-37) over already painted host layers of a LayeredImageInterface:
+    allgather of counts / hints, global order, owner-side run fold, exchange, fold; each rank
+    returns its piece.  Threads as ranks; against the oracle's N-rank composeLayered."""
+    from test_frame_plan import local_indices
+    from test_oracle_compose import synthetic_layers
+    subprocess.run(["make", "-C", CXX, "adapter_test"], check=True, stdout=subprocess.DEVNULL)
+    W, H, n_layers = 61, 43, 9     # 2623 pixels: every piece boundary splits a row
+    layers, hints = synthetic_layers(n_layers, W, H)
+    if ownership == "round_robin":
+        owners = [i % n_ranks for i in range(n_layers)]
+    else:
+        chunk = -(-n_layers // n_ranks)
+        owners = [min(i // chunk, n_ranks - 1) for i in range(n_layers)]
+    # the C++ side sees each rank's layers in local order and allgathers the hints rank-major,
+    # exactly as DirectSendBase.cpp:329-361 does
+    np.concatenate([l.reshape(-1) for l in layers]).astype(np.float32).tofile(tmp_path / "l.bin")
+    np.asarray(hints, np.float32).tofile(tmp_path / "h.bin")
+    np.asarray(owners, np.int32).tofile(tmp_path / "o.bin")
+    np.asarray(group, np.int32).tofile(tmp_path / "g.bin")
+    subprocess.run([EXE, "compose_ranks", str(tmp_path / "l.bin"), str(n_layers), str(n_ranks),
+                    str(W), str(H), str(tmp_path / "h.bin"), str(tmp_path / "o.bin"),
+                    str(tmp_path / "g.bin"), str(tmp_path / "out.bin")], check=True, timeout=180)
+    want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks,
+                                   group_order=group)
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    assert_bit_equal(got, want, "C++ Compositor plugin compose")

@@ -213,3 +213,54 @@ def test_two_ranks_render_a_plotfile(tmp_path):
     assert data.startswith(header)
     got = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)
     assert np.array_equal(got, O.quantize_rgb8(want, W, H))
+
+
+@pytest.mark.gpu
+def test_native_rccl_exchange_and_gather_with_one_rank(O):
+    """The C ABI's own collectives (avr_comm_create / avr_exchange / avr_gather: grouped ncclSend /
+    ncclRecv on the context's stream) on a one-rank RCCL communicator -- there the block a rank
+    keeps for itself is deliberately routed through RCCL -- together with the generic layered
+    plan (avr_layered_plan_create, avr_pack_layers, avr_fold_plan), against the oracle."""
+    import ctypes as C
+    import torch
+    from amrvolumerenderer_amd import _capi, runtime
+    from test_oracle_compose import synthetic_layers
+    L = _capi.lib()
+    ctx = runtime.Context(0)
+    comm = runtime.Comm(0, 0, 1, lambda ident: ident)
+    W, H, n_layers = 61, 43, 7
+    layers, hints = synthetic_layers(n_layers, W, H)
+    want, _, _ = O.compose_layered(layers, hints, [0] * n_layers, list(range(n_layers)), 1)
+    hints_c = (C.c_float * n_layers)(*[float(h) for h in hints])
+    owner_c = (C.c_int32 * n_layers)(*([0] * n_layers))
+    plan = C.c_void_p()
+    _capi.check(L.avr_layered_plan_create(hints_c, owner_c, n_layers, 1, 0, None, W, H,
+                                          C.byref(plan)))
+    info = _capi.FramePlanInfo()
+    _capi.check(L.avr_frame_plan_get_info(plan, C.byref(info)))
+    assert info.n_runs_total == 1 and info.send_floats == W * H * 5 == info.recv_floats
+    dev = [torch.from_numpy(np.ascontiguousarray(l)).to(ctx.device) for l in layers]
+    pointers = (C.c_void_p * n_layers)(*[t.data_ptr() for t in dev])
+    with torch.cuda.stream(ctx.stream):
+        send = torch.full((info.send_floats,), float("nan"), device=ctx.device)
+        recv = torch.full((info.recv_floats,), float("nan"), device=ctx.device)
+        piece = torch.empty((W * H, 5), device=ctx.device)
+        rgb8 = torch.empty((W * H, 3), dtype=torch.uint8, device=ctx.device)
+        full = torch.zeros((W * H, 5), device=ctx.device)
+        full8 = torch.zeros((W * H, 3), dtype=torch.uint8, device=ctx.device)
+    ctx.join()
+    _capi.check(L.avr_pack_layers(ctx._handle, plan, pointers, n_layers, C.c_void_p(send.data_ptr())))
+    _capi.check(L.avr_exchange(ctx._handle, plan, comm._handle, C.c_void_p(send.data_ptr()),
+                               C.c_void_p(recv.data_ptr())))
+    _capi.check(L.avr_fold_plan(ctx._handle, plan, C.c_void_p(recv.data_ptr()),
+                                C.c_void_p(piece.data_ptr()), C.c_void_p(rgb8.data_ptr())))
+    _capi.check(L.avr_gather(ctx._handle, plan, comm._handle, C.c_void_p(piece.data_ptr()), 20,
+                             C.c_void_p(full.data_ptr()), 0))
+    _capi.check(L.avr_gather(ctx._handle, plan, comm._handle, C.c_void_p(rgb8.data_ptr()), 3,
+                             C.c_void_p(full8.data_ptr()), 0))
+    ctx.synchronize()
+    assert torch.equal(recv.view(torch.int32), send.view(torch.int32))   # through ncclSend/ncclRecv
+    assert np.array_equal(full.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(full8.cpu().numpy().reshape(H, W, 3)[::-1], O.quantize_rgb8(want, W, H))
+    L.avr_frame_plan_destroy(plan)
+    comm.close()
