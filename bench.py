@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--march-occupancy", type=int, default=None,
                     help="resident march workgroups per CU (0 = uncapped; default: 5 for one "
                          "rank, uncapped otherwise); see DESIGN.md")
+    ap.add_argument("--check-collectives", action="store_true",
+                    help="N > 1: also render one untimed frame through the torch.distributed "
+                         "collectives (all_to_all_single / gather) and require rank 0's bytes to "
+                         "equal the C++ driver's (grouped ncclSend / ncclRecv)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="debug: all ranks share cuda:0 and talk over gloo through host copies "
                          "(exercises the N>1 code path on a 1-GPU box; not a measurement)")
@@ -265,6 +269,37 @@ def main():
     total_runs = renderer.last_plan.n_runs_total
     send_floats = renderer.last_plan.send_floats
 
+    # ---- untimed self-checks of the N-rank frame (no oracle here: properties only) ------------
+    checks = {}
+    default_scene = (args.config == "config4" and args.field == "smooth" and not args.width
+                     and not args.height and args.transparency == 0.97 and args.antialiasing == 1
+                     and args.orbit == 0)
+    if default_scene:
+        # the ranks' shares of the frame add up to the one-rank frame's samples, whatever N
+        # (the count tests/test_full_size_gpu.py checks against the oracle)
+        checks["samples_sum_equals_one_rank_frame"] = frame_samples[0] == 759136367
+    if world > 1 and renderer.native is not None and args.check_collectives:
+        # the same frame through the other implementation of the collectives: the C++ driver's
+        # grouped ncclSend / ncclRecv (avr_exchange / avr_gather) against torch.distributed's
+        # all_to_all_single / gather on the same RCCL transport -- rank 0's bytes must agree
+        twin = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
+                             spec.scalar_range, rank, world, group, native=False)
+        _, a = renderer.render(rparams, cameras[0])
+        _, b = twin.render(rparams, cameras[0])
+        renderer.synchronize()
+        twin.synchronize()
+        torch.cuda.synchronize()
+        same = torch.ones(1, device=ctx.device)
+        if rank == 0:
+            same[0] = float(torch.equal(a, b) and bool(a.any()))
+        dist.broadcast(same, 0, group=group)
+        checks["native_collectives_equal_torch_distributed"] = bool(same.item())
+        del twin
+    if not all(checks.values()):
+        if rank == 0:
+            print(f"bench.py: self-check failed: {checks}", file=sys.stderr)
+        raise SystemExit(3)
+
     def step(i):
         return renderer.render(rparams, cameras[i % len(cameras)])
 
@@ -392,6 +427,7 @@ def main():
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
             "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,
+            "self_checks": checks,
         },
         "roofline": roofline,
     }
