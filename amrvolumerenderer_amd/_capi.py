@@ -185,6 +185,7 @@ SIGNATURES = {
     "avr_comm_unique_id": (C.c_int, [C.c_char_p]),
     "avr_comm_create": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "avr_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "avr_comm_create_solo": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "avr_comm_destroy": (None, [_vp]),
     "avr_comm_rank": (C.c_int, [_vp]),
     "avr_comm_size": (C.c_int, [_vp]),
@@ -198,12 +199,14 @@ SIGNATURES = {
     "avr_renderer_set_options": (C.c_int, [_vp, C.c_int, C.c_int]),
     "avr_renderer_set_scalar_range": (C.c_int, [_vp, _fp]),
     "avr_renderer_invalidate": (C.c_int, [_vp]),
+    "avr_renderer_set_overlap": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_reference_sample_distance": (C.c_int, [_vp, _fp]),
     "avr_renderer_render": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip, _vp,
                                        _vp, C.c_int, _vp, _vp]),
     "avr_renderer_synchronize": (C.c_int, [_vp]),
     "avr_renderer_stream": (_vp, [_vp, C.c_int]),
     "avr_renderer_plan_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),
+    "avr_renderer_host_profile": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),
     "avr_renderer_set_timing": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_timings": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.POINTER(C.c_int)]),

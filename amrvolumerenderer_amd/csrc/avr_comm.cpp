@@ -122,6 +122,7 @@ struct avr_comm {
   int device = 0;
   ncclComm_t nccl = nullptr;                      // RCCL flavour
   std::shared_ptr<avr::LocalWorld> local;         // in-process flavour
+  bool solo = false;                              // one rank of N played alone (timing studies)
 };
 
 namespace {
@@ -208,6 +209,18 @@ int avr_comm_create_local(int n_ranks, avr_comm** out_comms) {
   });
 }
 
+int avr_comm_create_solo(int rank, int n_ranks, avr_comm** out_comm) {
+  return guarded([&]() -> int {
+    require(out_comm != nullptr && n_ranks >= 1 && rank >= 0 && rank < n_ranks, "invalid argument");
+    auto* comm = new avr_comm();
+    comm->rank = rank;
+    comm->n_ranks = n_ranks;
+    comm->solo = true;
+    *out_comm = comm;
+    return AVR_OK;
+  });
+}
+
 void avr_comm_destroy(avr_comm* comm) {
   if (comm == nullptr) return;
   if (comm->nccl != nullptr) {
@@ -237,6 +250,15 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
     }
     if (plan->send_splits[static_cast<size_t>(me)] != plan->recv_splits[static_cast<size_t>(me)]) {
       throw std::runtime_error("frame plan: a rank's block for itself differs between send and receive layout");
+    }
+    if (comm->solo) {  // only the block the rank keeps for itself moves
+      const int64_t own = plan->send_splits[static_cast<size_t>(me)];
+      if (own > 0) {
+        avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(me)], send + send_at[static_cast<size_t>(me)],
+                                   static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
+                    "hipMemcpyAsync(exchange)");
+      }
+      return AVR_OK;
     }
     if (comm->local) {
       // in-process rehearsal: publish, meet, pull, meet
@@ -323,6 +345,14 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
     require(my_end == my_begin || piece != nullptr, "null piece");
     require(me != root || full != nullptr || n_pixels == 0, "null destination on the root");
     char* dst = static_cast<char*>(full);
+    if (comm->solo) {
+      if (me == root && my_end > my_begin) {
+        avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
+                                   static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
+                                   hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+      }
+      return AVR_OK;
+    }
     if (comm->local) {
       avr::LocalWorld& world = *comm->local;
       drain(stream);

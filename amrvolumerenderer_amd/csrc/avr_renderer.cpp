@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -108,6 +109,7 @@ struct avr_renderer {
   float reference_sample_distance = 0.0f;
   int march_cap = -1;  // -1: default (5 for one rank without classification cache, else 0)
   bool cache_classification = false;
+  int overlap_classify = -1;  // -1: default (1 for one rank, 0 otherwise); see avr_renderer_set_overlap
 
   avr_frame_plan* plan = nullptr;
   PlanKey key;
@@ -120,6 +122,10 @@ struct avr_renderer {
   hipEvent_t input_event = nullptr;
   bool marched_pending[2] = {false, false}, composed_pending[2] = {false, false};
   unsigned frame = 0;
+
+  // host time spent inside avr_renderer_render, by section (avr_renderer_host_profile)
+  double host_seconds[6] = {0, 0, 0, 0, 0, 0};  // plan, classify, march, exchange, fold, gather + tail
+  long host_frames = 0;
 
   bool timing = false;
   hipEvent_t epoch = nullptr;
@@ -301,6 +307,15 @@ int avr_renderer_invalidate(avr_renderer* r) {
   });
 }
 
+int avr_renderer_set_overlap(avr_renderer* r, int overlap_classify) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    r->drain_all();
+    r->overlap_classify = overlap_classify;
+    return AVR_OK;
+  });
+}
+
 int avr_renderer_reference_sample_distance(const avr_renderer* r, float* out) {
   return guarded([&]() -> int {
     require(r != nullptr && out != nullptr, "null argument");
@@ -332,6 +347,19 @@ int avr_renderer_plan_info(const avr_renderer* r, avr_frame_plan_info* out) {
     require(r != nullptr && out != nullptr, "null argument");
     require(r->have_plan, "no frame has been rendered yet");
     return avr_frame_plan_get_info(r->plan, out);
+  });
+}
+
+int avr_renderer_host_profile(avr_renderer* r, double seconds_out[6], long* frames_out, int reset) {
+  return guarded([&]() -> int {
+    require(r != nullptr && seconds_out != nullptr && frames_out != nullptr, "null argument");
+    std::copy(r->host_seconds, r->host_seconds + 6, seconds_out);
+    *frames_out = r->host_frames;
+    if (reset) {
+      std::fill(r->host_seconds, r->host_seconds + 6, 0.0);
+      r->host_frames = 0;
+    }
+    return AVR_OK;
   });
 }
 
@@ -408,6 +436,13 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     const int width = render->width, height = render->height;
     const int render_w = width * root, render_h = height * root;
 
+    using Clock = std::chrono::steady_clock;
+    auto mark = Clock::now();
+    auto lap = [&](int section) {
+      const auto now = Clock::now();
+      r->host_seconds[section] += std::chrono::duration<double>(now - mark).count();
+      mark = now;
+    };
     // ---- host plan (re-used while camera and parameters repeat) --------------------------------
     PlanKey key;
     key.render = *render;
@@ -455,7 +490,14 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     if (cap < 0) cap = (r->n_ranks == 1 && !r->cache_classification) ? 5 : 0;
     abi_ok(avr_context_set_march_occupancy(r->march, cap));
 
-    hipStream_t stream_c = r->stream_of(r->classify);
+    // One rank: the classify pass of the next frame runs beside the march of this one (HBM-bound
+    // beside issue-bound).  A rank's share of an N-rank frame is two SHORT kernels whose time is
+    // their slowest workgroups': side by side each stretched the other (N = 8, slowest rank:
+    // 77 us + 151 us alone, 0.26 + 0.27 ms overlapped), so there they run back to back on the
+    // march stream and only the exchange / fold / gather of the previous frame overlaps them.
+    const bool overlap = (r->overlap_classify < 0) ? (r->n_ranks == 1) : (r->overlap_classify != 0);
+    avr_context* classify_ctx = overlap ? r->classify : r->march;
+    hipStream_t stream_c = r->stream_of(classify_ctx);
     hipStream_t stream_m = r->stream_of(r->march);
     hipStream_t stream_x = r->stream_of(r->compose);
     const int slot = static_cast<int>(r->frame & 1u);
@@ -470,6 +512,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       timed.march_end = make_event(true);
     }
 
+    lap(0);
     // ---- stream C: classify pass of this frame into classified volume `slot` -------------------
     if (input_stream != nullptr) {  // the caller's cell data is produced on that stream
       hip_ok(hipEventRecord(r->input_event, static_cast<hipStream_t>(input_stream)), "hipEventRecord");
@@ -478,17 +521,23 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     if (r->marched_pending[slot]) {  // the frame before last still marches this volume
       hip_ok(hipStreamWaitEvent(stream_c, r->marched_event[slot], 0), "hipStreamWaitEvent");
     }
-    if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
-    abi_ok(avr_classify_plan(r->classify, r->scene, plan, slot));
-    hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[slot];
-    hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
-
-    // ---- stream M: march into send buffer `slot` ------------------------------------------------
     float* send = static_cast<float*>(
         r->send[slot].reserve(static_cast<size_t>(std::max<int64_t>(info.send_floats, 1)) * 4, drain));
-    hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
-    if (r->composed_pending[slot]) {  // the frame before last is still exchanged / folded from it
+    if (!overlap && r->composed_pending[slot]) {  // (back to back: both waits precede the pair)
       hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
+    }
+    if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
+    abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, slot));
+    hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[slot];
+    if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
+
+    lap(1);
+    // ---- stream M: march into send buffer `slot` ------------------------------------------------
+    if (overlap) {
+      hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
+      if (r->composed_pending[slot]) {  // the frame before last is still exchanged / folded from it
+        hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
+      }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
     abi_ok(avr_march_plan(r->march, r->scene, plan, slot, send, samples_out));
@@ -497,6 +546,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     r->marched_pending[slot] = true;
     if (r->timing) r->timed.push_back(timed);
 
+    lap(2);
     // ---- stream X: exchange, fold, gather, frame tail ------------------------------------------
     hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[slot], 0), "hipStreamWaitEvent");
     const float* received = send;
@@ -506,6 +556,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       abi_ok(avr_exchange(r->compose, plan, r->comm, send, recv));
       received = recv;
     }
+    lap(3);
     // 8-bit conversion is per pixel, so without antialiasing it is done on each rank's piece
     // before the gather (3 bytes per pixel on the wire instead of 20); the wireframe of the tight
     // bounds is per pixel too, so each rank overlays its own piece
@@ -531,6 +582,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     hip_ok(hipEventRecord(r->composed_event[slot], stream_x), "hipEventRecord");
     r->composed_pending[slot] = true;
 
+    lap(4);
     const int64_t n_pixels = info.n_pixels;
     if (early_rgb8) {
       // pieces are pixel ranges of the bottom-up image; the output file's rows run top-down
@@ -568,6 +620,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         abi_ok(avr_quantize_rgb8(r->compose, small, width, height, 5, rgb8_out));
       }
     }
+    lap(5);
+    ++r->host_frames;
     return AVR_OK;
   });
 }

@@ -567,6 +567,16 @@ class Comm:
         self._handle = handle
 
     @classmethod
+    def solo(cls, rank: int, n_ranks: int) -> "Comm":
+        """avr_comm_create_solo: one rank of an N-rank frame played alone (timing studies)."""
+        self = cls.__new__(cls)
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_comm_create_solo(self.rank, self.n_ranks, C.byref(handle)))
+        self._handle = handle
+        return self
+
+    @classmethod
     def from_process_group(cls, device_index: int, group=None) -> "Comm":
         """Bootstraps over an initialised torch.distributed group (any backend)."""
         import torch.distributed as dist
@@ -647,6 +657,10 @@ class NativeRenderer:
     def synchronize(self) -> None:
         _capi.check(_capi.lib().avr_renderer_synchronize(self._handle))
 
+    def set_overlap(self, overlap_classify: int) -> None:
+        """avr_renderer_set_overlap (-1 default, 0 back to back, 1 classify beside the march)."""
+        _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
+
     def set_scalar_range(self, scalar_range) -> None:
         rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))
         _capi.check(_capi.lib().avr_renderer_set_scalar_range(self._handle, rng))
@@ -658,6 +672,15 @@ class NativeRenderer:
         info = _capi.FramePlanInfo()
         _capi.check(_capi.lib().avr_renderer_plan_info(self._handle, C.byref(info)))
         return info
+
+    def host_profile(self, reset: bool = True):
+        """({section: microseconds per frame}, frames) spent inside avr_renderer_render."""
+        sec = (C.c_double * 6)()
+        n = C.c_long()
+        _capi.check(_capi.lib().avr_renderer_host_profile(self._handle, sec, C.byref(n), int(reset)))
+        names = ("plan", "classify", "march", "exchange", "fold", "gather+tail")
+        frames = max(n.value, 1)
+        return {k: 1e6 * v / frames for k, v in zip(names, sec)}, n.value
 
     def set_timing(self, enabled: bool) -> None:
         _capi.check(_capi.lib().avr_renderer_set_timing(self._handle, int(bool(enabled))))

@@ -375,6 +375,10 @@ int avr_comm_create(int device_id, const char id[AVR_COMM_ID_BYTES], int rank, i
  * host threads of this process (host-synchronous device copies).  Not a performance path -- RCCL
  * cannot place two ranks on one device, and this keeps the N-rank frame testable there. */
 int avr_comm_create_local(int n_ranks, avr_comm **out_comms /* [n_ranks] */);
+/* ONE rank of an N-rank frame played alone (timing studies of a rank's share on a single GPU,
+ * tools/rank_share.py): only the block a rank keeps for itself moves, the peers' blocks of the
+ * receive buffer keep whatever they held.  Frames rendered this way are not images. */
+int avr_comm_create_solo(int rank, int n_ranks, avr_comm **out_comm);
 void avr_comm_destroy(avr_comm *comm);
 int avr_comm_rank(const avr_comm *comm);
 int avr_comm_size(const avr_comm *comm);
@@ -429,6 +433,10 @@ int avr_renderer_set_scalar_range(avr_renderer *renderer, const float scalar_ran
 /* avr_scene_invalidate for the renderer's scene: call after changing cell data in place while
  * cache_classification is on. */
 int avr_renderer_invalidate(avr_renderer *renderer);
+/* Whether the classify pass of frame i+1 runs on its own stream beside the march of frame i
+ * (1), or both run back to back on the march stream (0); -1 = default: beside for one rank,
+ * back to back for a rank's share of an N-rank frame.  Never changes results. */
+int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream
@@ -452,6 +460,12 @@ int avr_renderer_plan_info(const avr_renderer *renderer, avr_frame_plan_info *ou
  * classify pass and its march on the streams they are launched on.  avr_renderer_timings drains
  * the streams and returns the averages per frame since timing was enabled: each kernel's own
  * duration and the length of the union of their execution intervals (they overlap by design). */
+/* Host seconds spent inside avr_renderer_render since the last reset, by section: plan,
+ * classify call, march call, exchange, fold (+ piece overlay), gather + frame tail; and the number
+ * of frames they cover.  (A host that runs ahead of the GPU waits inside these calls for a staging
+ * slot: under back-pressure the sum approaches the GPU's frame time.) */
+int avr_renderer_host_profile(avr_renderer *renderer, double seconds_out[6], long *frames_out,
+                              int reset);
 int avr_renderer_set_timing(avr_renderer *renderer, int enabled);
 int avr_renderer_timings(avr_renderer *renderer, double *classify_ms, double *march_ms,
                          double *busy_ms, int *frames);
