@@ -118,7 +118,7 @@ class FrameRenderer:
         # short runs whose tail, not their throughput, sets the time; there the cap costs
         # (N = 4: 0.355 -> 0.387 ms, N = 8: 0.223 -> 0.237 ms; N = 2 neutral), so it is off.
         if march_workgroups_per_cu is None:
-            march_workgroups_per_cu = 5 if (n_ranks == 1 and not cache_classification) else 0
+            march_workgroups_per_cu = 0   # uncapped: best for the present march (6 per CU fit)
         self.march_ctx.set_march_occupancy(march_workgroups_per_cu)
         self.march_workgroups_per_cu = march_workgroups_per_cu
         self.compositor = DirectSendCompositor(self.comm_ctx, process_group, stage_through_host,
@@ -207,7 +207,18 @@ class FrameRenderer:
         send buffer `slot`; classified volume `slot` carries the table indices between them."""
         need = max(plan.send_floats, 1)
         if self._send[slot] is None or self._send[slot].numel() < need:
-            self._send[slot] = self.ctx.empty(need)
+            # the old block may still be read by the exchange / fold of the frame before last on
+            # the compositing stream (and written by nothing else): wait for those users on the
+            # host before the caching allocator may hand the block to someone else, and allocate
+            # with headroom so that an orbit's growing plans rarely get here
+            if self._send_free[slot] is not None:
+                self._send_free[slot].synchronize()
+            if self._classified_free[slot] is not None:
+                self._classified_free[slot].synchronize()
+            with torch.cuda.stream(self.march_ctx.stream):
+                self._send[slot] = torch.empty(need + need // 4, dtype=torch.float32,
+                                               device=self.ctx.device)
+            self._send[slot].record_stream(self.comm_ctx.stream)
         ctx, cls = self.march_ctx, self.classify_ctx
         timed = self.kernel_events is not None
         if self._classified_free[slot] is not None:

@@ -52,8 +52,9 @@ def parse_args():
     ap.add_argument("--priorities", default="-1,-1,0",
                     help="HIP stream priorities of the march, compositing and classify streams")
     ap.add_argument("--march-occupancy", type=int, default=None,
-                    help="resident march workgroups per CU (0 = uncapped; default: 5 for one "
-                         "rank, uncapped otherwise); see DESIGN.md")
+                    help="resident march workgroups per CU (0 = uncapped, the default); see DESIGN.md")
+    ap.add_argument("--autotune", action="store_true",
+                    help="pick the march occupancy cap (0 or 5) by timing 30 frames of each first")
     ap.add_argument("--check-collectives", action="store_true",
                     help="N > 1: also render one untimed frame through the torch.distributed "
                          "collectives (all_to_all_single / gather) and require rank 0's bytes to "
@@ -116,14 +117,14 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
 
 def profiled_traffic(args, world):
     """HBM bytes per paint-stage launch from the committed rocprofv3 PMC summary of THIS command
-    (profiles/r1_final/pmc_summary.txt: separate --pmc passes, tools/pmc_passes.sh).  FETCH_SIZE
+    (profiles/r2_final/pmc_summary.txt: separate --pmc passes, tools/pmc_passes.sh).  FETCH_SIZE
     and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane)
     coalesced stream, so the classify kernel's reads are doubled and the march's byte gathers
     are not (MI355X_MICROARCH.md, HBM).  Only valid for the default single-GPU workload."""
     default = (world == 1 and args.config == "config4" and args.field == "smooth"
                and args.transparency == 0.97 and not args.width and not args.height
                and args.antialiasing == 1 and args.orbit == 0)
-    path = os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.txt")
+    path = os.path.join(ROOT, "profiles", "r2_final", "pmc_summary.txt")
     if not default or not os.path.exists(path):
         return None, None
     counters, kernel = {}, None
@@ -141,7 +142,7 @@ def profiled_traffic(args, world):
                + counters[("render_runs_kernel", "WRITE_SIZE")])
     except KeyError:
         return None, None
-    return int(kib * 1024), "profiles/r1_final/pmc_summary.txt"
+    return int(kib * 1024), "profiles/r2_final/pmc_summary.txt"
 
 
 def launcher_command(n_ranks, port, argv):
@@ -303,10 +304,9 @@ def main():
     def step(i):
         return renderer.render(rparams, cameras[i % len(cameras)])
 
-    # Untimed setup: unless the cap was given, let the renderer pick the march occupancy cap for
-    # this workload (one rank only; a rank's share of an N-rank frame runs uncapped)
-    if args.march_occupancy is None and world == 1:
-        renderer.autotune(rparams, cameras[0])
+    # Untimed setup (optional): pick the march occupancy cap for this workload
+    if args.autotune and world == 1:
+        renderer.autotune(rparams, cameras[0], frames=30)
     # Untimed setup, like the sample counting above: about a third of a second of frames brings
     # the GPU to its working clocks and fills the allocator pools, so that a run timing very few
     # steps (the driver's --steps 20 is a 20 ms timed region) measures the steady state a
@@ -396,8 +396,15 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "classify_kernel + render_runs_kernel (the paint stage of one frame)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "traffic_source": traffic_source,
+        # `frac` is the ALGORITHMIC fraction the task defines (8 B per sample + 20 B per stored
+        # layer pixel over the paint stage's GPU time).  The kernels move far fewer bytes -- the
+        # f64 cells are read once per frame by the classify pass and the march gathers one
+        # classified byte per sample from cache -- so the fraction of the HBM peak the MEASURED
+        # traffic amounts to is reported beside it and the two must be quoted together.
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),
+        "traffic": traffic, "traffic_source": traffic_source,
+        "traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                         if traffic else None),
         "kernel_ms": round(kernel_ms, 4), "classify_ms": round(classify_ms, 4),
         "march_ms": round(march_ms, 4), "algorithmic_bytes": int(algo_bytes),
         "samples_this_rank": my_samples,

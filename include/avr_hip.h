@@ -424,8 +424,7 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm *comm,
                         const avr_colormap_point *colormap, int colormap_count,
                         avr_renderer **out_renderer);
 void avr_renderer_destroy(avr_renderer *renderer);
-/* march_workgroups_per_cu: -1 default (5 for one rank re-classifying every frame, else uncapped),
- * 0..8 as avr_context_set_march_occupancy.  cache_classification: avr_scene_set_classification_cache. */
+/* march_workgroups_per_cu: -1 default (uncapped), 0..8 as avr_context_set_march_occupancy.  cache_classification: avr_scene_set_classification_cache. */
 int avr_renderer_set_options(avr_renderer *renderer, int march_workgroups_per_cu,
                              int cache_classification);
 /* geometry.scalarRange of the scene (VolumeRenderer.hpp:74-89) for the frames that follow. */

@@ -204,3 +204,35 @@ def test_classification_cache_is_exact_and_invalidates(O, ctx):
                    cams[:2])
     assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(truth, fresh))
     assert not all(np.array_equal(a, b) for (a, _), (b, _) in zip(before, fresh))
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_growing_send_buffers_under_allocator_churn(O, ctx, native):
+    """Frames whose sparse send layout grows from frame to frame (larger images), rendered back
+    to back without synchronising while the caller allocates and frees device memory on its own
+    stream in between: the driver's buffers are replaced while earlier frames may still be in
+    flight on the other streams, and every frame must still equal a fresh renderer's."""
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    sizes = [(40, 32), (72, 48), (72, 48), (130, 96), (200, 150), (200, 150), (333, 240)]
+    cams = [scenes.orbit_camera(v) for v in range(len(sizes))]
+    renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
+                             native=native)
+    junk, frames = [], []
+    for (w, h), cam in zip(sizes, cams):
+        frames.append(renderer.render(RenderParameters(w, h, 0.8, 1), cam, want_image=True))
+        junk.append(torch.full((1 << 20,), 7.0, device=ctx.device))   # churn on the caller's stream
+        if len(junk) > 2:
+            junk.pop(0)
+    renderer.synchronize()
+    torch.cuda.synchronize()
+    for (w, h), cam, (image, rgb8) in zip(sizes, cams, frames):
+        fresh = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
+                              native=native)
+        want_image, want_rgb8 = fresh.render(RenderParameters(w, h, 0.8, 1), cam, want_image=True)
+        fresh.synchronize()
+        assert torch.equal(image.view(torch.int32), want_image.view(torch.int32)), (w, h)
+        assert torch.equal(rgb8, want_rgb8), (w, h)
