@@ -181,6 +181,7 @@ SIGNATURES = {
     "avr_quantize_rgb8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "avr_flip_rows": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "avr_context_create_with_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "avr_context_set_cu_mask_pattern": (C.c_int, [_vp, C.c_uint32]),
     "avr_context_stream": (_vp, [_vp]),
     "avr_comm_unique_id": (C.c_int, [C.c_char_p]),
     "avr_comm_create": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),

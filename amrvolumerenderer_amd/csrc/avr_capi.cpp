@@ -210,6 +210,7 @@ struct avr_context {
   avr_scene scratch_scene;         // classified storage of avr_paint_box
   std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
   int priority = 0;                            // 1: own stream in the highest priority class
+  uint32_t cu_mask_pattern = 0;                // non-zero: own stream restricted to these CUs
   int march_workgroups_per_cu = 0;             // 0 = uncapped
   uint64_t* march_counters = nullptr;          // diagnostics (avr_context_set_march_counters)
 };
@@ -245,7 +246,13 @@ void bind_device(avr_context* ctx) {
   require(ctx != nullptr, "null context");
   avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
   if (ctx->stream == nullptr) {  // no external stream was supplied: create the context's own
-    if (ctx->priority != 0) {
+    if (ctx->cu_mask_pattern != 0) {
+      // experiment hook (avr_context_set_cu_mask_pattern): the stream's kernels only run on the
+      // CUs whose bit is set in the pattern, repeated over the device
+      std::vector<uint32_t> mask(8, ctx->cu_mask_pattern);   // 256 CUs
+      avr::hip_check(hipExtStreamCreateWithCUMask(&ctx->own_stream, static_cast<uint32_t>(mask.size()),
+                                                  mask.data()), "hipExtStreamCreateWithCUMask");
+    } else if (ctx->priority != 0) {
       int least = 0, greatest = 0;  // numerically lower = more urgent
       avr::hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
       avr::hip_check(hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, greatest),
@@ -419,6 +426,15 @@ int avr_context_create_with_priority(int device_id, int high_priority, avr_conte
   const int status = avr_context_create(device_id, out_ctx);
   if (status == AVR_OK) (*out_ctx)->priority = high_priority ? 1 : 0;
   return status;
+}
+
+int avr_context_set_cu_mask_pattern(avr_context* ctx, uint32_t pattern) {
+  return guarded([&]() -> int {
+    require(ctx != nullptr && ctx->own_stream == nullptr && ctx->stream == nullptr,
+            "the CU mask must be set before the context's stream exists");
+    ctx->cu_mask_pattern = pattern;
+    return AVR_OK;
+  });
 }
 
 void* avr_context_stream(avr_context* ctx) {

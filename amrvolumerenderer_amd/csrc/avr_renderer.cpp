@@ -25,6 +25,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -246,6 +247,10 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     abi_ok(avr_context_create_with_priority(device_id, 1, &r->march));
     abi_ok(avr_context_create_with_priority(device_id, 1, &r->compose));
     abi_ok(avr_context_create_with_priority(device_id, 0, &r->classify));
+    if (const char* pattern = std::getenv("AVR_CLASSIFY_CU_MASK")) {  // experiment: see DESIGN.md
+      abi_ok(avr_context_set_cu_mask_pattern(r->classify,
+                                             static_cast<uint32_t>(std::strtoul(pattern, nullptr, 0))));
+    }
     std::vector<avr_box> local;
     for (int b = 0; b < n_boxes; ++b) {
       require(owner[b] >= 0 && owner[b] < n_ranks, "box owner out of range");

@@ -105,6 +105,11 @@ void avr_context_destroy(avr_context *ctx);
  * (high_priority != 0) or in the default class. */
 int avr_context_create_with_priority(int device_id, int high_priority, avr_context **out_ctx);
 
+/* Restricts the context's OWN stream (before it is first used) to the compute units whose bit is
+ * set in `pattern`, the 32-bit pattern being repeated over the device's CUs
+ * (hipExtStreamCreateWithCUMask).  0 = no restriction. */
+int avr_context_set_cu_mask_pattern(avr_context *ctx, uint32_t pattern);
+
 /* The stream the context launches on (hipStream_t as void*), for ordering other work against it. */
 void *avr_context_stream(avr_context *ctx);
 

@@ -280,91 +280,6 @@ std::vector<float> compose_single_rank(Context& context, LayeredT& layers, int64
   return out;
 }
 
-// ---- one rank's share of renderSingleTrial (VolumeRenderer/VolumeRenderer.cpp:1200-1314) --------
-// The frame of INTEGRATION.md section 3 as a class: the caller supplies the exchange (RCCL
-// ncclSend/ncclRecv group, hipMemcpyPeerAsync, or MPI_Alltoallv on device pointers) between
-// paint() and fold().  `all_boxes` is the replicated metadata of every box (cells may be null for
-// boxes of other ranks), `owner[b]` its rank; this rank's boxes must carry device pointers.
-class RankFrame {
- public:
-  RankFrame(Context& context, std::vector<avr_box> all_boxes, std::vector<int32_t> owner, int rank,
-            int n_ranks, const avr_scalar_transform& transform)
-      : context_(context), all_boxes_(std::move(all_boxes)), owner_(std::move(owner)), rank_(rank),
-        n_ranks_(n_ranks) {
-    std::vector<avr_box> local;
-    for (std::size_t b = 0; b < all_boxes_.size(); ++b) {
-      if (owner_[b] == rank_) local.push_back(all_boxes_[b]);
-    }
-    check(avr_scene_create(context_.get(), local.data(), static_cast<int>(local.size()), &transform,
-                           &scene_));
-    check(avr_visibility_graph_create(all_boxes_.data(), owner_.data(),
-                                      static_cast<int>(all_boxes_.size()), n_ranks_, &visibility_));
-  }
-  ~RankFrame() {
-    if (plan_ != nullptr) avr_frame_plan_destroy(plan_);
-    if (visibility_ != nullptr) avr_visibility_graph_destroy(visibility_);
-    if (scene_ != nullptr) avr_scene_destroy(scene_);
-  }
-  RankFrame(const RankFrame&) = delete;
-  RankFrame& operator=(const RankFrame&) = delete;
-
-  // buildVisibilityOrderedGroup + the layer order / run grouping / exchange layout that
-  // composeLayered derives from its allgathers (DirectSendBase.cpp:329-410).
-  const avr_frame_plan_info& plan(const avr_paint_params& params, const avr_camera& camera,
-                                  bool use_visibility_graph = true) {
-    if (plan_ != nullptr) avr_frame_plan_destroy(plan_);
-    plan_ = nullptr;
-    std::vector<int32_t> group(static_cast<std::size_t>(n_ranks_));
-    const float aspect = static_cast<float>(params.width) / static_cast<float>(params.height);
-    int succeeded = 1;
-    check(avr_visibility_order(visibility_, &camera, aspect, use_visibility_graph ? 1 : 0, nullptr,
-                               group.data(), &succeeded, nullptr));
-    check(avr_frame_plan_create(all_boxes_.data(), owner_.data(), static_cast<int>(all_boxes_.size()),
-                                n_ranks_, rank_, group.data(), &params, &camera, &plan_));
-    check(avr_frame_plan_get_info(plan_, &info_));
-    send_splits_.assign(static_cast<std::size_t>(n_ranks_), 0);
-    recv_splits_.assign(static_cast<std::size_t>(n_ranks_), 0);
-    check(avr_frame_plan_splits(plan_, send_splits_.data(), recv_splits_.data()));
-    if (send_.size() < static_cast<std::size_t>(info_.send_floats) + 1) {
-      send_.resize(static_cast<std::size_t>(info_.send_floats) + 1);
-    }
-    if (recv_.size() < static_cast<std::size_t>(info_.recv_floats) + 1) {
-      recv_.resize(static_cast<std::size_t>(info_.recv_floats) + 1);
-    }
-    return info_;
-  }
-  // classify + march of the local boxes, owner-side run fold: the all-to-all's send buffer
-  float* paint() {
-    check(avr_render_plan(context_.get(), scene_, plan_, send_.data(), nullptr));
-    return send_.data();
-  }
-  float* paint_buffer() { return send_.data(); }
-  float* recv_buffer() { return recv_.data(); }
-  const std::vector<int64_t>& send_splits() const { return send_splits_; }  // floats per peer
-  const std::vector<int64_t>& recv_splits() const { return recv_splits_; }
-  const avr_frame_plan_info& info() const { return info_; }
-  // receiver-side fold of this rank's pixel piece (+ RGB8) from the received blocks
-  void fold(DeviceBuffer<float>* piece, DeviceBuffer<unsigned char>* rgb8) {
-    const std::size_t n = static_cast<std::size_t>(info_.piece_end - info_.piece_begin);
-    if (piece->size() < n * 5 + 1) piece->resize(n * 5 + 1);
-    if (rgb8 != nullptr && rgb8->size() < n * 3 + 1) rgb8->resize(n * 3 + 1);
-    check(avr_fold_plan(context_.get(), plan_, recv_.data(), piece->data(),
-                        rgb8 != nullptr ? rgb8->data() : nullptr));
-  }
-
- private:
-  Context& context_;
-  std::vector<avr_box> all_boxes_;
-  std::vector<int32_t> owner_;
-  int rank_, n_ranks_;
-  avr_scene* scene_ = nullptr;
-  avr_visibility_graph* visibility_ = nullptr;
-  avr_frame_plan* plan_ = nullptr;
-  avr_frame_plan_info info_{};
-  std::vector<int64_t> send_splits_, recv_splits_;
-  DeviceBuffer<float> send_, recv_;
-};
-
 // ---- rank communicator ---------------------------------------------------------------------------
 // RAII over avr_comm.  `Control` is the caller's control plane for the three tiny host collectives
 // the compositor needs besides the GPU exchange; inside the reference tree it is MPI
