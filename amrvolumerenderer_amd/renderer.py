@@ -152,9 +152,24 @@ class FrameRenderer:
                 import torch.distributed as dist
                 native = (process_group is not None or dist.is_initialized()) and \
                     dist.get_backend(process_group) == "nccl"
-        if native:
-            if n_ranks > 1 and comm is None:
+        self.native_error = None
+        if native and n_ranks > 1 and comm is None:
+            try:
                 comm = runtime.Comm.from_process_group(ctx.device_index, process_group)
+            except Exception as error:   # e.g. RCCL not loadable: say so, keep the frame on the GPU
+                # NOT a CPU fallback: the same HIP kernels, with torch.distributed's RCCL
+                # collectives (all_to_all_single / gather) instead of the C++ driver's; every rank
+                # must take the same path, so the decision is agreed on below
+                self.native_error = f"{type(error).__name__}: {error}"
+            import torch.distributed as dist
+            failed = torch.tensor([1 if self.native_error else 0], device=ctx.device)
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=process_group)
+            if int(failed.item()):
+                import warnings
+                warnings.warn("native RCCL communicator unavailable on some rank "
+                              f"({self.native_error}); using the torch.distributed frame loop")
+                native, comm = False, None
+        if native:
             merged = []   # replicated metadata, this rank's boxes with their cells
             mine = iter(self.local_boxes)
             for b in self.all_boxes:

@@ -429,7 +429,10 @@ def main():
             "ownership": args.ownership, "runs_total": total_runs,
             "frame_driver": ("C++ (avr_renderer: 3 HIP streams" +
                              (", RCCL exchange + gather" if world > 1 else "") + ")") if native
-                            else "Python rehearsal pipeline (torch streams, gloo through host copies)",
+                            else ("Python pipeline (torch streams; gloo through host copies)"
+                                  if args.rehearse_on_one_gpu else
+                                  "Python pipeline with torch.distributed RCCL collectives -- the "
+                                  f"C++ driver's communicator failed: {renderer.native_error}"),
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
