@@ -116,6 +116,7 @@ SIGNATURES = {
     "avr_context_destroy": (None, [_vp]),
     "avr_context_set_stream": (C.c_int, [_vp, _vp]),
     "avr_context_set_march_occupancy": (C.c_int, [_vp, C.c_int]),
+    "avr_context_set_classify_lds_reserve": (C.c_int, [_vp, C.c_int]),
     "avr_context_set_march_counters": (C.c_int, [_vp, _vp]),
     "avr_context_synchronize": (C.c_int, [_vp]),
     "avr_build_color_table": (C.c_int, [C.c_float, C.c_float, _fp, C.POINTER(ColormapPoint),
@@ -201,6 +202,8 @@ SIGNATURES = {
     "avr_renderer_set_scalar_range": (C.c_int, [_vp, _fp]),
     "avr_renderer_invalidate": (C.c_int, [_vp]),
     "avr_renderer_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_classify_share": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_classify_share": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "avr_renderer_reference_sample_distance": (C.c_int, [_vp, _fp]),
     "avr_renderer_render": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip, _vp,
                                        _vp, C.c_int, _vp, _vp]),

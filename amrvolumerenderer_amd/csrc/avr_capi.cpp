@@ -212,6 +212,7 @@ struct avr_context {
   int priority = 0;                            // 1: own stream in the highest priority class
   uint32_t cu_mask_pattern = 0;                // non-zero: own stream restricted to these CUs
   int march_workgroups_per_cu = 0;             // 0 = uncapped
+  uint32_t classify_lds_pad = 0;               // avr_context_set_classify_lds_reserve
   uint64_t* march_counters = nullptr;          // diagnostics (avr_context_set_march_counters)
 };
 
@@ -292,6 +293,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   launch.consts = plan.consts;
   launch.n_boxes = n_boxes;
   launch.n_classify_tiles = plan.classify_tile_begin.back();
+  launch.classify_lds_pad = ctx->classify_lds_pad;
   launch.classified = scene->classified_slot(slot, plan.classified_bytes, ctx->stream);
 
   if ((phases & kClassify) && scene->cache_classification) {
@@ -471,6 +473,16 @@ int avr_context_set_march_occupancy(avr_context* ctx, int workgroups_per_cu) {
     require(ctx != nullptr, "null context");
     require(workgroups_per_cu >= 0 && workgroups_per_cu <= 8, "workgroups_per_cu must be in [0, 8]");
     ctx->march_workgroups_per_cu = (workgroups_per_cu == 8) ? 0 : workgroups_per_cu;
+    return AVR_OK;
+  });
+}
+
+int avr_context_set_classify_lds_reserve(avr_context* ctx, int bytes) {
+  return guarded([&]() -> int {
+    require(ctx != nullptr, "null context");
+    require(bytes >= 0 && bytes <= AVR_CLASSIFY_LDS_RESERVE_MAX,
+            "bytes must be in [0, AVR_CLASSIFY_LDS_RESERVE_MAX]");
+    ctx->classify_lds_pad = static_cast<uint32_t>(bytes);
     return AVR_OK;
   });
 }

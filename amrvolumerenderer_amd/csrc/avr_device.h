@@ -74,6 +74,34 @@ __device__ __forceinline__ int table_index(double raw, const FrameConsts& fc) {
   return idx;
 }
 
+// Table indices of two cells, index(a) in byte 0 and index(b) in byte 1.  On the SIMPLE path the
+// non-finite test selects the (wave-uniform) scaled value of 0.0 after the arithmetic instead of
+// replacing the f64 operand before it: the same value, one select fewer per cell.
+// (v_cvt_pk_u8_f32 would convert and place the byte in one instruction, but it rounds to nearest
+// where the reference's int cast truncates: tools/ubench/cvt_pk_u8.hip.)
+template <bool SIMPLE>
+__device__ __forceinline__ uint32_t table_index_pair(double a, double b, const FrameConsts& fc) {
+#if defined(AVR_EXP_CLASSIFY_NO_MATH)  // experiment: the pass's memory traffic without its VALU
+  return (static_cast<uint32_t>(__double2loint(a)) ^ static_cast<uint32_t>(__double2hiint(b))) &
+         0xffffu;
+#endif
+  if (SIMPLE) {
+    const float at_zero =
+        __builtin_amdgcn_fmed3f(static_cast<float>((0.0 - fc.norm_min) * fc.inv_norm_span), 0.0f,
+                                1.0f) * 255.0f;
+    float sa = __builtin_amdgcn_fmed3f(static_cast<float>((a - fc.norm_min) * fc.inv_norm_span),
+                                       0.0f, 1.0f) * 255.0f;
+    float sb = __builtin_amdgcn_fmed3f(static_cast<float>((b - fc.norm_min) * fc.inv_norm_span),
+                                       0.0f, 1.0f) * 255.0f;
+    sa = __builtin_isfinite(a) ? sa : at_zero;
+    sb = __builtin_isfinite(b) ? sb : at_zero;
+    return static_cast<uint32_t>(static_cast<int>(sa)) |
+           (static_cast<uint32_t>(static_cast<int>(sb)) << 8);
+  }
+  return static_cast<uint32_t>(table_index<false>(a, fc)) |
+         (static_cast<uint32_t>(table_index<false>(b, fc)) << 8);
+}
+
 }  // namespace
 }  // namespace avr
 

@@ -146,6 +146,8 @@ struct RenderLaunch {
   const uint32_t* tile_begin_dev;   // n_boxes + 1 prefix of classify workgroups
   int n_boxes;
   uint32_t n_classify_tiles;
+  uint32_t classify_lds_pad;  // bytes of LDS each classify workgroup claims beyond its own
+                              // (0 = none): caps its occupancy beside the march
   const MarchItemDev* items_dev;  // n_items entries (multiple of kXcds)
   uint32_t n_items;
   int only_mode;                        // the IndexMode shared by every box, or -1

@@ -660,6 +660,11 @@ __global__ void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__
 // one byte in 8 x 4 x 4 bricklets.  One workgroup = 4 k-planes x 4 j-rows x 128 cells of x:
 // 16 rows of 1 KiB in, 16 complete bricklets (2 KiB, contiguous) out through LDS.
 constexpr int kStagedStride = 34;  // dwords per staged bricklet (32 + 2: conflict-free LDS writes)
+constexpr int kRawBufferFlags = 0x00020000;  // word 3 of a raw (untyped) gfx9 buffer resource
+// Cache policy of the cell loads (buffer_load aux bits: 1 = sc0, 2 = nt, 16 = sc1): every cell is
+// read once per frame, so non-temporal.  Measured beside the march, the policy does not matter
+// (0, nt, sc1, nt|sc1, sc0|sc1|nt: 1.049-1.063 ms per frame).
+constexpr int kStreamingLoad = 2;
 
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
@@ -696,50 +701,60 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
   const int t = static_cast<int>(threadIdx.x);
   // 16-byte loads (two cells per lane) need every row to start 16-byte aligned
   const bool paired = ((reinterpret_cast<uintptr_t>(box.cells) & 15u) == 0) &&
-                      ((jstride & 1u) == 0) && ((kstride & 1u) == 0);
+                      ((jstride & 1u) == 0) && ((kstride & 1u) == 0) && jstride < (1u << 27);
   if (paired && nx >= 2) {
     typedef double double2_t __attribute__((ext_vector_type(2)));
+    // One j-row per wave, one k-plane per pass, two x-cells (one 16-byte load) per lane.  The
+    // lane's byte offset inside the plane is the same in all four passes, so the addresses are a
+    // wave-uniform base per pass plus one 32-bit lane offset (global_load ... saddr: no vector
+    // address arithmetic per pass).  To keep the loads unconditional, the last cell of an odd row
+    // is read as the second half of the pair before it (an 8-byte aligned 16-byte load), lanes
+    // outside the box read the chunk's first pair and planes past the box re-read the last plane.
+    const int jj = t >> 6;
     const int xi = (t & 63) * 2;  // first of this lane's two cells inside the 128-cell chunk
-    const int i = chunk * kClassifyChunk + xi;
-    // All four rows' 16-byte loads are issued before the first is used: four round trips in
-    // flight per lane, so that a few resident workgroups already keep HBM busy -- what the
-    // classify pass gets when it shares the CUs with the march of the previous frame.  To keep
-    // the loads unconditional, the last cell of an odd row is read as the second half of the
-    // pair before it (an 8-byte aligned 16-byte load) and lanes outside the box read the box's
-    // first two cells.
+    const int i0 = chunk * kClassifyChunk;
+    const int i = i0 + xi;
+    const int j = bj * kBrickY + jj;
+    const bool valid = i < nx && j < ny;
+    const bool whole = valid && (i + 1 < nx);
+    const uint32_t lead = (i0 + 1 < nx) ? 0u : 1u;  // the chunk's first cell is the odd last one
+    const uint32_t lane_cell =
+        valid ? (static_cast<uint32_t>(xi) + static_cast<uint32_t>(jj) * jstride + lead -
+                 (whole ? 0u : 1u))
+              : 0u;
+    // buffer addressing: the box's cells as the resource, the tile's first pair + the lane's
+    // offset in the vector offset, the plane in the scalar offset (host: spans stay below 2^28
+    // cells, so every byte offset fits 31 bits) -- no vector address arithmetic per pass
+    const uint32_t row0 = (static_cast<uint32_t>(i0) - lead) +
+                          static_cast<uint32_t>(bj * kBrickY) * jstride;
+    const uint32_t lane_bytes = (row0 + lane_cell) * 8u;
+    const __amdgpu_buffer_rsrc_t resource = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(box.cells), 0, 0x7fffffff, kRawBufferFlags);
+    // All four planes' loads are issued before the first is used: four round trips in flight per
+    // lane, so that a few resident workgroups already keep HBM busy -- what the classify pass
+    // gets when it shares the CUs with the march of the previous frame.
     double2_t raw[4];
-    bool valid[4], whole[4];
-    uint32_t at[4];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-      const int row = pass * 4 + (t >> 6);  // 0..15 = kk * 4 + jj (one row per wave)
-      const int j = bj * kBrickY + (row & 3);
-      const int k = bk * kBrickZ + (row >> 2);
-      valid[pass] = i < nx && j < ny && k < nz;
-      whole[pass] = valid[pass] && (i + 1 < nx);
-      at[pass] = static_cast<uint32_t>(i) + static_cast<uint32_t>(j) * jstride +
-                 static_cast<uint32_t>(k) * kstride;
+      const int k = bk * kBrickZ + pass;
+      const uint32_t plane_bytes = static_cast<uint32_t>(k < nz ? k : nz - 1) * kstride * 8u;
+      // every f64 cell is read exactly once per frame: a streaming load keeps it from evicting
+      // the classified bricklets the co-resident march gathers through the same L1 / L2
+      raw[pass] = __builtin_bit_cast(
+          double2_t, __builtin_amdgcn_raw_buffer_load_b128(resource, lane_bytes, plane_bytes,
+                                                           kStreamingLoad));
     }
+    // bricklet row (pass * 4 + jj) of bricklet xi / 8, bytes xi % 8 and xi % 8 + 1
+    char* const staged_at = reinterpret_cast<char*>(staged) + (xi >> 3) * (kStagedStride * 4) +
+                            jj * 8 + (xi & 7);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-      const uint32_t from = whole[pass] ? at[pass] : (valid[pass] ? at[pass] - 1u : 0u);
-      // every f64 cell is read exactly once per frame: a streaming (non-temporal) load keeps it
-      // from evicting the classified bricklets the co-resident march gathers from L2
-      raw[pass] = __builtin_nontemporal_load(
-          (const double2_t __attribute__((address_space(1)))*)(cells + from));
-    }
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int row = pass * 4 + (t >> 6);
-      const uint32_t first = static_cast<uint32_t>(
-          table_index<SIMPLE>(whole[pass] ? raw[pass].x : raw[pass].y, fc));
-      const uint32_t second = static_cast<uint32_t>(table_index<SIMPLE>(raw[pass].y, fc));
-      const uint32_t two = whole[pass] ? (first | (second << 8)) : (valid[pass] ? first : 0u);
-      // merge with the neighbouring lane: cells xi .. xi+3 of this row in one dword
-      uint32_t packed = two << (16 * (t & 1));
-      packed |= static_cast<uint32_t>(
-          __builtin_amdgcn_update_dpp(0, static_cast<int>(packed), 0xB1, 0xF, 0xF, false));
-      if ((t & 1) == 0) staged[(xi >> 3) * kStagedStride + row * 2 + ((xi & 7) >> 2)] = packed;
+      uint32_t two = 0;
+      if (bk * kBrickZ + pass < nz) {  // wave-uniform
+        two = table_index_pair<SIMPLE>(raw[pass].x, raw[pass].y, fc);
+        if (__builtin_expect(!whole, 0)) two = valid ? (two >> 8) : 0u;
+      }
+      *reinterpret_cast<uint16_t*>(staged_at + pass * 32) = static_cast<uint16_t>(two);
     }
   } else {
     const int xi = t & 127;
@@ -771,13 +786,17 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
   const int bricks_here = (bricks_x - first_brick_x < 16) ? (bricks_x - first_brick_x) : 16;
   const int bricks_z = (nz + kBrickZ - 1) >> 2;
   if (t * 8 < bricks_here * kBrickBytes) {
-    const uint64_t brick = (static_cast<uint64_t>(first_brick_x + (t >> 4)) *
-                                static_cast<uint64_t>(bricks_y) + static_cast<uint64_t>(bj)) *
-                               static_cast<uint64_t>(bricks_z) + static_cast<uint64_t>(bk);
+    // wave-uniform line of the chunk's first bricklet + a 32-bit lane offset (the host keeps
+    // bricks_y * bricks_z * 128 below 2^24, avr_host.cpp plan_frame)
+    const uint64_t brick0 = (static_cast<uint64_t>(first_brick_x) * static_cast<uint64_t>(bricks_y) +
+                             static_cast<uint64_t>(bj)) * static_cast<uint64_t>(bricks_z) +
+                            static_cast<uint64_t>(bk);
+    const uint32_t x_pitch = static_cast<uint32_t>(bricks_y * bricks_z) * kBrickBytes;
+    const uint32_t lane_off = static_cast<uint32_t>(__umul24(static_cast<unsigned>(t >> 4), x_pitch)) +
+                              static_cast<uint32_t>(t & 15) * 8u;
     const uint2 v =
         *reinterpret_cast<const uint2*>(&staged[(t >> 4) * kStagedStride + (t & 15) * 2]);
-    *reinterpret_cast<uint2*>(classified + box.cls_offset + brick * kBrickBytes +
-                              static_cast<uint64_t>(t & 15) * 8) = v;
+    *reinterpret_cast<uint2*>(classified + box.cls_offset + brick0 * kBrickBytes + lane_off) = v;
   }
 }
 
@@ -1148,11 +1167,12 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   // the standard API path (normalise on, scalarRange {0,1}, no log, no soft clip)
   const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
                       fc.inverse_range == 1.0f;
+  const size_t pad = L.classify_lds_pad;  // occupancy cap beside the march (avr_renderer)
   if (simple) {
-    hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
+    hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
   } else {
-    hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), 0,
+    hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
   }
   return check_launch("classify_kernel");

@@ -132,12 +132,26 @@ struct avr_renderer {
   hipEvent_t epoch = nullptr;
   std::vector<FrameEvents> timed;
 
+  // Balance of the two overlapped kernels (avr_renderer_set_classify_share): one frame in
+  // kProbeEvery is bracketed by timing events; when they have completed the reserve moves one
+  // step towards equal durations.
+  int share_fixed = -1;   // >= 0: the caller's reserve
+  int share_bytes = 0;    // the reserve in use
+  long share_probes = 0;
+  FrameEvents probe;      // persistent timing events
+  bool probe_armed = false;
+  unsigned probe_frame = 0;
+  bool pipeline_idle = true;  // nothing in flight: the next classify pass has the GPU to itself
+
   ~avr_renderer() {
     (void)hipSetDevice(device);
     for (avr_context* ctx : {classify, march, compose}) {
       if (ctx != nullptr) (void)avr_context_synchronize(ctx);
     }
     clear_timing();
+    for (hipEvent_t ev : {probe.classify_begin, probe.classify_end, probe.march_begin, probe.march_end}) {
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
     for (hipEvent_t* list : {classified_event, marched_event, composed_event}) {
       for (int s = 0; s < 2; ++s) {
         if (list[s] != nullptr) (void)hipEventDestroy(list[s]);
@@ -164,6 +178,7 @@ struct avr_renderer {
 
   void drain_all() {
     for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
+    pipeline_idle = true;
   }
 };
 
@@ -204,6 +219,33 @@ hipEvent_t make_event(bool timing) {
   hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : hipEventDisableTiming),
          "hipEventCreate");
   return event;
+}
+
+constexpr unsigned kProbeEvery = 12;      // frames between timed probes of the kernel pair
+constexpr int kShareStep = 2048;          // bytes of LDS reserve per adjustment
+constexpr int kShareMax = 57344;          // <= AVR_CLASSIFY_LDS_RESERVE_MAX: two workgroups per CU
+constexpr float kShareDeadBand = 0.03f;   // relative difference of the durations left alone
+
+// Reads a completed probe and moves the reserve; false while the events are still pending.
+bool settle_probe(avr_renderer* r) {
+  if (hipEventQuery(r->probe.march_end) != hipSuccess ||
+      hipEventQuery(r->probe.classify_end) != hipSuccess) {
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    return false;
+  }
+  float classify_ms = 0.0f, march_ms = 0.0f;
+  hip_ok(hipEventElapsedTime(&classify_ms, r->probe.classify_begin, r->probe.classify_end),
+         "hipEventElapsedTime");
+  hip_ok(hipEventElapsedTime(&march_ms, r->probe.march_begin, r->probe.march_end),
+         "hipEventElapsedTime");
+  r->probe_armed = false;
+  ++r->share_probes;
+  if (march_ms > classify_ms * (1.0f + kShareDeadBand)) {
+    r->share_bytes = std::min(r->share_bytes + kShareStep, kShareMax);
+  } else if (classify_ms > march_ms * (1.0f + kShareDeadBand)) {
+    r->share_bytes = std::max(r->share_bytes - kShareStep, 0);
+  }
+  return true;
 }
 
 }  // namespace
@@ -250,6 +292,10 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     if (const char* pattern = std::getenv("AVR_CLASSIFY_CU_MASK")) {  // experiment: see DESIGN.md
       abi_ok(avr_context_set_cu_mask_pattern(r->classify,
                                              static_cast<uint32_t>(std::strtoul(pattern, nullptr, 0))));
+    }
+    if (const char* bytes = std::getenv("AVR_CLASSIFY_LDS_RESERVE")) {  // experiment: fixed share
+      r->share_fixed = r->share_bytes =
+          std::clamp(std::atoi(bytes), 0, static_cast<int>(AVR_CLASSIFY_LDS_RESERVE_MAX));
     }
     std::vector<avr_box> local;
     for (int b = 0; b < n_boxes; ++b) {
@@ -309,6 +355,26 @@ int avr_renderer_invalidate(avr_renderer* r) {
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
     return avr_scene_invalidate(r->scene);
+  });
+}
+
+int avr_renderer_set_classify_share(avr_renderer* r, int bytes) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    require(bytes >= -1 && bytes <= AVR_CLASSIFY_LDS_RESERVE_MAX,
+            "bytes must be -1 or in [0, AVR_CLASSIFY_LDS_RESERVE_MAX]");
+    r->share_fixed = bytes;
+    if (bytes >= 0) r->share_bytes = bytes;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_classify_share(const avr_renderer* r, int* bytes_out, long* probes_out) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    if (bytes_out != nullptr) *bytes_out = r->share_bytes;
+    if (probes_out != nullptr) *probes_out = r->share_probes;
+    return AVR_OK;
   });
 }
 
@@ -518,6 +584,27 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       timed.march_begin = make_event(true);
       timed.march_end = make_event(true);
     }
+    // the balance of the overlapped pair: settle the last probe, maybe time this frame
+    const bool balancing = overlap && r->share_fixed < 0 && !r->cache_classification;
+    bool probing = false;
+    if (balancing) {
+      if (r->probe_armed) settle_probe(r);
+      if (!r->probe_armed && r->frame - r->probe_frame >= kProbeEvery) {
+        if (r->probe.classify_begin == nullptr) {
+          r->probe.classify_begin = make_event(true);
+          r->probe.classify_end = make_event(true);
+          r->probe.march_begin = make_event(true);
+          r->probe.march_end = make_event(true);
+        }
+        probing = true;
+        r->probe_frame = r->frame;
+      }
+    }
+    // (the first frame after a drain classifies alone: no march to leave room for)
+    abi_ok(avr_context_set_classify_lds_reserve(
+        classify_ctx, (overlap && !r->pipeline_idle) ? r->share_bytes : 0));
+    if (r->pipeline_idle) probing = false;
+    r->pipeline_idle = false;
 
     lap(0);
     // ---- stream C: classify pass of this frame into classified volume `slot` -------------------
@@ -534,7 +621,9 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
+    if (probing) hip_ok(hipEventRecord(r->probe.classify_begin, stream_c), "hipEventRecord");
     abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, slot));
+    if (probing) hip_ok(hipEventRecord(r->probe.classify_end, stream_c), "hipEventRecord");
     hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[slot];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
 
@@ -547,7 +636,10 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
+    if (probing) hip_ok(hipEventRecord(r->probe.march_begin, stream_m), "hipEventRecord");
     abi_ok(avr_march_plan(r->march, r->scene, plan, slot, send, samples_out));
+    if (probing) hip_ok(hipEventRecord(r->probe.march_end, stream_m), "hipEventRecord");
+    if (probing) r->probe_armed = true;
     if (r->timing) hip_ok(hipEventRecord(timed.march_end, stream_m), "hipEventRecord");
     hip_ok(hipEventRecord(r->marched_event[slot], stream_m), "hipEventRecord");
     r->marched_pending[slot] = true;
@@ -629,6 +721,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     lap(5);
     ++r->host_frames;
+    r->pipeline_idle = false;  // (a buffer that grew drained the streams in between)
     return AVR_OK;
   });
 }

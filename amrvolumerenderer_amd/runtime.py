@@ -661,6 +661,19 @@ class NativeRenderer:
         """avr_renderer_set_overlap (-1 default, 0 back to back, 1 classify beside the march)."""
         _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
 
+    def set_classify_share(self, lds_reserve_bytes: int = -1) -> None:
+        """avr_renderer_set_classify_share: -1 = balanced by the driver (default), >= 0 = fixed
+        LDS reserve per classify workgroup while the pass runs beside the march."""
+        _capi.check(_capi.lib().avr_renderer_set_classify_share(self._handle,
+                                                                int(lds_reserve_bytes)))
+
+    def classify_share(self):
+        """(LDS reserve in use, timed probes so far)."""
+        reserve, probes = C.c_int(0), C.c_long(0)
+        _capi.check(_capi.lib().avr_renderer_classify_share(self._handle, C.byref(reserve),
+                                                            C.byref(probes)))
+        return reserve.value, probes.value
+
     def set_scalar_range(self, scalar_range) -> None:
         rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))
         _capi.check(_capi.lib().avr_renderer_set_scalar_range(self._handle, rng))

@@ -55,6 +55,11 @@ def parse_args():
                     help="resident march workgroups per CU (0 = uncapped, the default); see DESIGN.md")
     ap.add_argument("--autotune", action="store_true",
                     help="pick the march occupancy cap (0 or 5) by timing 30 frames of each first")
+    ap.add_argument("--classify-share", type=int, default=-1,
+                    help="LDS reserve (bytes) per classify workgroup beside the march; -1 = "
+                         "balanced by the C++ driver (avr_renderer_set_classify_share)")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="experiment builds only (tools/ab_*.sh variants that change results)")
     ap.add_argument("--check-collectives", action="store_true",
                     help="N > 1: also render one untimed frame through the torch.distributed "
                          "collectives (all_to_all_single / gather) and require rank 0's bytes to "
@@ -246,6 +251,8 @@ def main():
                              march_workgroups_per_cu=args.march_occupancy,
                              stream_priorities=tuple(int(v) for v in args.priorities.split(",")),
                              cache_classification=args.cache_classification)
+    if renderer.native is not None and args.classify_share >= 0:
+        renderer.native.set_classify_share(args.classify_share)
     rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
                                antialiasing=args.antialiasing,
                                draw_bounds=False)  # not part of the metric
@@ -275,7 +282,7 @@ def main():
     default_scene = (args.config == "config4" and args.field == "smooth" and not args.width
                      and not args.height and args.transparency == 0.97 and args.antialiasing == 1
                      and args.orbit == 0)
-    if default_scene:
+    if default_scene and not args.no_self_check:
         # the ranks' shares of the frame add up to the one-rank frame's samples, whatever N
         # (the count tests/test_full_size_gpu.py checks against the oracle)
         checks["samples_sum_equals_one_rank_frame"] = frame_samples[0] == 759136367
@@ -434,6 +441,9 @@ def main():
                                   "Python pipeline with torch.distributed RCCL collectives -- the "
                                   f"C++ driver's communicator failed: {renderer.native_error}"),
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
+            "classify_lds_reserve": (dict(zip(("bytes", "probes"), renderer.native.classify_share()),
+                                          mode="fixed" if args.classify_share >= 0 else "balanced")
+                                     if native else None),
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
             "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,

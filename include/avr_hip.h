@@ -127,6 +127,15 @@ int avr_context_synchronize(avr_context *ctx);
  * changes results. */
 int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
 
+/* LDS (bytes, 0 = none) each classify workgroup of this context's launches claims beyond the
+ * 2 KiB it stages bricklets in: caps how many of them a CU holds at once.  Beside the march the
+ * classify pass takes memory-system time from the march in proportion to the bandwidth it
+ * reaches, whatever its arithmetic, occupancy or cache policy; the
+ * renderer's frame driver uses this to make both kernels of a frame take equally long
+ * (avr_renderer_set_classify_share).  Never changes results. */
+#define AVR_CLASSIFY_LDS_RESERVE_MAX 61440
+int avr_context_set_classify_lds_reserve(avr_context *ctx, int bytes);
+
 /* Diagnostics for the parity tests: while set (device pointer to 4 x uint64; NULL = off), every
  * march launched with a samples_out counter also ADDS
  *   counters[0]  samples whose cell index took the exact IEEE divide of
@@ -441,6 +450,14 @@ int avr_renderer_invalidate(avr_renderer *renderer);
  * (1), or both run back to back on the march stream (0); -1 = default: beside for one rank,
  * back to back for a rank's share of an N-rank frame.  Never changes results. */
 int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
+/* How the classify pass shares the GPU with the march beside it (only when they overlap):
+ * bytes >= 0 fixes avr_context_set_classify_lds_reserve; -1 (default) = balanced by the driver:
+ * every few frames it times both kernels with HIP events and moves the reserve one step towards
+ * equal durations (more reserve = fewer resident classify workgroups = slower classify pass,
+ * faster march), which is where the frame is shortest.  Never changes results.
+ * avr_renderer_classify_share: the reserve in use and the number of timed probes so far. */
+int avr_renderer_set_classify_share(avr_renderer *renderer, int bytes);
+int avr_renderer_classify_share(const avr_renderer *renderer, int *bytes_out, long *probes_out);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream

@@ -236,3 +236,43 @@ def test_growing_send_buffers_under_allocator_churn(O, ctx, native):
         fresh.synchronize()
         assert torch.equal(image.view(torch.int32), want_image.view(torch.int32)), (w, h)
         assert torch.equal(rgb8, want_rgb8), (w, h)
+
+
+def test_classify_share_never_changes_results_and_the_balance_moves(O, ctx):
+    """avr_renderer_set_classify_share: the LDS reserve that caps the classify pass beside the
+    march is scheduling only -- frames rendered back to back with a fixed reserve of 0, of the
+    maximum, and with the driver's balance are bit-identical to a fresh renderer's; the balance
+    times the kernel pair (probes > 0) once the pipeline is running."""
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    p = RenderParameters(160, 120, 0.9, 1)
+    cams = [scenes.orbit_camera(v) for v in range(3)]
+
+    def run(share, frames):
+        renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+        assert renderer.native is not None
+        renderer.native.set_classify_share(share)
+        out = []
+        for f in range(frames):   # back to back: no synchronisation between frames
+            out.append(renderer.render(p, cams[f % len(cams)], want_image=True))
+        renderer.synchronize()
+        torch.cuda.synchronize()
+        return renderer, out
+
+    _, want = run(0, 3)
+    for share in (61440, -1):
+        renderer, got = run(share, 60)
+        reserve, probes = renderer.native.classify_share()
+        if share >= 0:
+            assert (reserve, probes) == (share, 0)
+        else:
+            assert probes >= 2 and 0 <= reserve <= 57344
+        for f, (image, rgb8) in enumerate(got):
+            w_image, w_rgb8 = want[f % len(cams)]
+            assert torch.equal(image.view(torch.int32), w_image.view(torch.int32)), (share, f)
+            assert torch.equal(rgb8, w_rgb8), (share, f)
+    with pytest.raises(Exception):
+        renderer.native.set_classify_share(61441)

@@ -89,6 +89,20 @@ def test_classify_row_tails_and_alignment(O, ctx, sl):
                 80, 64, cells_view=(storage, sl))
 
 
+def test_classify_chunk_that_starts_on_the_odd_last_cell(O, ctx):
+    """nx = 129 on 16-byte aligned rows: the second 128-cell chunk of every row holds one cell,
+    which the classify pass reads as the second half of the pair that ends the first chunk (the
+    buffer addressing of classify_kernel starts that tile one cell early); nz = 6 leaves the
+    last bricklet layer with two of its four planes."""
+    storage = np.random.default_rng(19).random((6, 7, 130))
+    storage[2, 3, 128] = np.nan
+    storage[5, 6, 128] = np.inf
+    sl = (slice(0, 6), slice(0, 7), slice(0, 129))
+    cells = np.ascontiguousarray(storage[sl])
+    compare_box(O, ctx, cells, (0.0, 0.3, 0.3), (1.0, 0.7, 0.65), scenes.default_camera(),
+                96, 64, cells_view=(storage, sl))
+
+
 @pytest.mark.parametrize("cam", [
     CameraParameters((0.5, 0.5, 0.5), (0.9, 0.6, 0.1), (0, 1, 0), 60.0),       # eye inside the box
     CameraParameters((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0, 1, 0), 30.0),       # axis aligned (dir ~ 0)
