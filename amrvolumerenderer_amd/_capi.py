@@ -203,7 +203,8 @@ SIGNATURES = {
     "avr_renderer_invalidate": (C.c_int, [_vp]),
     "avr_renderer_set_overlap": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_classify_share": (C.c_int, [_vp, C.c_int]),
-    "avr_renderer_classify_share": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_long)]),
+    "avr_renderer_corun_state": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "avr_renderer_reference_sample_distance": (C.c_int, [_vp, _fp]),
     "avr_renderer_render": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip, _vp,
                                        _vp, C.c_int, _vp, _vp]),

@@ -92,6 +92,89 @@ struct FrameEvents {
 
 }  // namespace
 
+// How the classify pass and the march of a rank share the GPU is MEASURED, not assumed.  Beside
+// the march the classify pass takes memory-system time from it in proportion to the bandwidth it
+// reaches -- whatever its arithmetic, occupancy or cache policy -- so the
+// frame is shortest where the two take equally long; how many classify workgroups a CU admits
+// (an LDS reserve per workgroup, avr_context_set_classify_lds_reserve) moves that balance, and
+// for the short kernels of an N-rank share running them back to back can win outright.  The
+// candidates are tried in turn on the running pipeline -- back to back, then side by side with a
+// reserve of 0, 2, 4 ... KiB -- each for a window of frames whose period is timed with two HIP
+// events on the march stream; the search stops three clearly worse steps past the best period and the driver
+// holds the best candidate, re-timing it now and then and searching again if it has drifted.
+// Scheduling only: never changes results.
+struct CoRunTuner {
+  static constexpr int kBackToBack = -1;       // candidate: both kernels on the march stream
+  static constexpr int kReserveStep = 2048;    // candidate k >= 0: side by side, reserve k * step
+  static constexpr int kLastCandidate = 28;    // 56 KiB: two classify workgroups per CU
+  static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate
+  static constexpr int kWindowFrames = 6;      // frames timed per candidate
+  static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
+  static constexpr float kWorse = 1.04f;       // "clearly worse than the best so far"
+  static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
+
+  enum Phase { kSearch, kHold } phase = kSearch;
+  int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
+  int candidate = kBackToBack;
+  int best = kBackToBack;
+  float best_ms = 0.0f;
+  int worse_in_a_row = 0;
+  long windows = 0;
+  // the window in progress
+  int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
+  bool open = false, closing = false;
+
+  void restrict_to(int first_candidate, int last_candidate) {
+    if (first_candidate == first && last_candidate == last) return;
+    first = first_candidate;
+    last = last_candidate;
+    restart();
+  }
+  void restart() {
+    phase = kSearch;
+    candidate = best = first;
+    best_ms = 0.0f;
+    worse_in_a_row = 0;
+    interrupt();
+  }
+  void interrupt() {  // the pipeline drained or the candidate changed: the window is void
+    frames_at_candidate = 0;
+    open = closing = false;
+  }
+  bool tuning() const { return first != last; }
+
+  // one timed window of the current candidate
+  void report(float period_ms) {
+    ++windows;
+    if (phase == kHold) {
+      if (period_ms > best_ms * kDrift) {
+        restart();
+      } else {
+        best_ms = 0.75f * best_ms + 0.25f * period_ms;
+        interrupt();
+      }
+      return;
+    }
+    if (best_ms == 0.0f || period_ms < best_ms) {
+      best_ms = period_ms;
+      best = candidate;
+    }
+    // the reserve only matters side by side, and there the period falls, then rises
+    if (candidate > 0 && period_ms > best_ms * kWorse) {
+      ++worse_in_a_row;
+    } else {
+      worse_in_a_row = 0;
+    }
+    if (candidate >= last || worse_in_a_row >= 3) {
+      phase = kHold;
+      candidate = best;
+    } else {
+      ++candidate;
+    }
+    interrupt();
+  }
+};
+
 struct avr_renderer {
   int device = 0, rank = 0, n_ranks = 1;
   avr_comm* comm = nullptr;
@@ -132,15 +215,13 @@ struct avr_renderer {
   hipEvent_t epoch = nullptr;
   std::vector<FrameEvents> timed;
 
-  // Balance of the two overlapped kernels (avr_renderer_set_classify_share): one frame in
-  // kProbeEvery is bracketed by timing events; when they have completed the reserve moves one
-  // step towards equal durations.
-  int share_fixed = -1;   // >= 0: the caller's reserve
-  int share_bytes = 0;    // the reserve in use
-  long share_probes = 0;
-  FrameEvents probe;      // persistent timing events
-  bool probe_armed = false;
-  unsigned probe_frame = 0;
+  // How the two kernels of a frame share the GPU (CoRunTuner below): the caller's wishes ...
+  int share_fixed = -1;   // >= 0: the caller's LDS reserve (avr_renderer_set_classify_share)
+  // ... and the tuner's state
+  CoRunTuner tuner;
+  hipEvent_t window_begin = nullptr, window_end = nullptr;  // timing events on the march stream
+  bool last_overlap = false;  // what the last frame did (avr_renderer_corun_state)
+  int last_reserve = 0;
   bool pipeline_idle = true;  // nothing in flight: the next classify pass has the GPU to itself
 
   ~avr_renderer() {
@@ -149,7 +230,7 @@ struct avr_renderer {
       if (ctx != nullptr) (void)avr_context_synchronize(ctx);
     }
     clear_timing();
-    for (hipEvent_t ev : {probe.classify_begin, probe.classify_end, probe.march_begin, probe.march_end}) {
+    for (hipEvent_t ev : {window_begin, window_end}) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
     }
     for (hipEvent_t* list : {classified_event, marched_event, composed_event}) {
@@ -179,6 +260,7 @@ struct avr_renderer {
   void drain_all() {
     for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
     pipeline_idle = true;
+    tuner.interrupt();
   }
 };
 
@@ -219,33 +301,6 @@ hipEvent_t make_event(bool timing) {
   hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : hipEventDisableTiming),
          "hipEventCreate");
   return event;
-}
-
-constexpr unsigned kProbeEvery = 12;      // frames between timed probes of the kernel pair
-constexpr int kShareStep = 2048;          // bytes of LDS reserve per adjustment
-constexpr int kShareMax = 57344;          // <= AVR_CLASSIFY_LDS_RESERVE_MAX: two workgroups per CU
-constexpr float kShareDeadBand = 0.03f;   // relative difference of the durations left alone
-
-// Reads a completed probe and moves the reserve; false while the events are still pending.
-bool settle_probe(avr_renderer* r) {
-  if (hipEventQuery(r->probe.march_end) != hipSuccess ||
-      hipEventQuery(r->probe.classify_end) != hipSuccess) {
-    (void)hipGetLastError();  // hipErrorNotReady is not an error here
-    return false;
-  }
-  float classify_ms = 0.0f, march_ms = 0.0f;
-  hip_ok(hipEventElapsedTime(&classify_ms, r->probe.classify_begin, r->probe.classify_end),
-         "hipEventElapsedTime");
-  hip_ok(hipEventElapsedTime(&march_ms, r->probe.march_begin, r->probe.march_end),
-         "hipEventElapsedTime");
-  r->probe_armed = false;
-  ++r->share_probes;
-  if (march_ms > classify_ms * (1.0f + kShareDeadBand)) {
-    r->share_bytes = std::min(r->share_bytes + kShareStep, kShareMax);
-  } else if (classify_ms > march_ms * (1.0f + kShareDeadBand)) {
-    r->share_bytes = std::max(r->share_bytes - kShareStep, 0);
-  }
-  return true;
 }
 
 }  // namespace
@@ -294,8 +349,7 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
                                              static_cast<uint32_t>(std::strtoul(pattern, nullptr, 0))));
     }
     if (const char* bytes = std::getenv("AVR_CLASSIFY_LDS_RESERVE")) {  // experiment: fixed share
-      r->share_fixed = r->share_bytes =
-          std::clamp(std::atoi(bytes), 0, static_cast<int>(AVR_CLASSIFY_LDS_RESERVE_MAX));
+      r->share_fixed = std::clamp(std::atoi(bytes), 0, static_cast<int>(AVR_CLASSIFY_LDS_RESERVE_MAX));
     }
     std::vector<avr_box> local;
     for (int b = 0; b < n_boxes; ++b) {
@@ -364,16 +418,19 @@ int avr_renderer_set_classify_share(avr_renderer* r, int bytes) {
     require(bytes >= -1 && bytes <= AVR_CLASSIFY_LDS_RESERVE_MAX,
             "bytes must be -1 or in [0, AVR_CLASSIFY_LDS_RESERVE_MAX]");
     r->share_fixed = bytes;
-    if (bytes >= 0) r->share_bytes = bytes;
     return AVR_OK;
   });
 }
 
-int avr_renderer_classify_share(const avr_renderer* r, int* bytes_out, long* probes_out) {
+int avr_renderer_corun_state(const avr_renderer* r, int* overlap_out, int* reserve_bytes_out,
+                             int* settled_out, long* windows_out) {
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
-    if (bytes_out != nullptr) *bytes_out = r->share_bytes;
-    if (probes_out != nullptr) *probes_out = r->share_probes;
+    const CoRunTuner& t = r->tuner;
+    if (overlap_out != nullptr) *overlap_out = r->last_overlap ? 1 : 0;
+    if (reserve_bytes_out != nullptr) *reserve_bytes_out = r->last_reserve;
+    if (settled_out != nullptr) *settled_out = (!t.tuning() || t.phase == CoRunTuner::kHold) ? 1 : 0;
+    if (windows_out != nullptr) *windows_out = t.windows;
     return AVR_OK;
   });
 }
@@ -568,7 +625,29 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // their slowest workgroups': side by side each stretched the other (N = 8, slowest rank:
     // 77 us + 151 us alone, 0.26 + 0.27 ms overlapped), so there they run back to back on the
     // march stream and only the exchange / fold / gather of the previous frame overlaps them.
-    const bool overlap = (r->overlap_classify < 0) ? (r->n_ranks == 1) : (r->overlap_classify != 0);
+    // Which of the two, and how many classify workgroups a CU admits beside the march, is measured
+    // on the running pipeline (CoRunTuner) unless the caller fixed it: avr_renderer_set_overlap,
+    // avr_renderer_set_classify_share.  (A cached classification leaves nothing to tune.)
+    CoRunTuner& tuner = r->tuner;
+    {
+      int first = CoRunTuner::kBackToBack, last = CoRunTuner::kLastCandidate;
+      if (r->cache_classification) {  // no classify pass to place
+        first = last = (r->overlap_classify == 0) ? CoRunTuner::kBackToBack : 0;
+      } else if (r->overlap_classify == 0) {
+        last = first;
+      } else {
+        if (r->overlap_classify > 0) first = 0;
+        if (r->share_fixed >= 0) {
+          // one side-by-side candidate: the caller's reserve (kept outside the candidate scale)
+          last = (first == CoRunTuner::kBackToBack) ? 0 : first;
+        }
+      }
+      tuner.restrict_to(first, last);
+    }
+    const bool overlap = tuner.candidate != CoRunTuner::kBackToBack;
+    const int reserve = !overlap ? 0
+                        : (r->share_fixed >= 0) ? r->share_fixed
+                                                : tuner.candidate * CoRunTuner::kReserveStep;
     avr_context* classify_ctx = overlap ? r->classify : r->march;
     hipStream_t stream_c = r->stream_of(classify_ctx);
     hipStream_t stream_m = r->stream_of(r->march);
@@ -584,26 +663,11 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       timed.march_begin = make_event(true);
       timed.march_end = make_event(true);
     }
-    // the balance of the overlapped pair: settle the last probe, maybe time this frame
-    const bool balancing = overlap && r->share_fixed < 0 && !r->cache_classification;
-    bool probing = false;
-    if (balancing) {
-      if (r->probe_armed) settle_probe(r);
-      if (!r->probe_armed && r->frame - r->probe_frame >= kProbeEvery) {
-        if (r->probe.classify_begin == nullptr) {
-          r->probe.classify_begin = make_event(true);
-          r->probe.classify_end = make_event(true);
-          r->probe.march_begin = make_event(true);
-          r->probe.march_end = make_event(true);
-        }
-        probing = true;
-        r->probe_frame = r->frame;
-      }
-    }
     // (the first frame after a drain classifies alone: no march to leave room for)
-    abi_ok(avr_context_set_classify_lds_reserve(
-        classify_ctx, (overlap && !r->pipeline_idle) ? r->share_bytes : 0));
-    if (r->pipeline_idle) probing = false;
+    abi_ok(avr_context_set_classify_lds_reserve(classify_ctx,
+                                                (overlap && !r->pipeline_idle) ? reserve : 0));
+    r->last_overlap = overlap;
+    r->last_reserve = reserve;
     r->pipeline_idle = false;
 
     lap(0);
@@ -621,9 +685,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
-    if (probing) hip_ok(hipEventRecord(r->probe.classify_begin, stream_c), "hipEventRecord");
     abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, slot));
-    if (probing) hip_ok(hipEventRecord(r->probe.classify_end, stream_c), "hipEventRecord");
     hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[slot];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
 
@@ -636,10 +698,35 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
-    if (probing) hip_ok(hipEventRecord(r->probe.march_begin, stream_m), "hipEventRecord");
     abi_ok(avr_march_plan(r->march, r->scene, plan, slot, send, samples_out));
-    if (probing) hip_ok(hipEventRecord(r->probe.march_end, stream_m), "hipEventRecord");
-    if (probing) r->probe_armed = true;
+    // the tuner's window: the period of kWindowFrames frames between two events after the march
+    if (tuner.tuning()) {
+      if (tuner.closing && hipEventQuery(r->window_end) == hipSuccess) {
+        float elapsed_ms = 0.0f;
+        hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end),
+               "hipEventElapsedTime");
+        tuner.report(elapsed_ms / static_cast<float>(CoRunTuner::kWindowFrames));
+      } else if (tuner.closing) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+      } else {
+        ++tuner.frames_at_candidate;
+        const int start = (tuner.phase == CoRunTuner::kHold) ? CoRunTuner::kHoldFrames
+                                                             : CoRunTuner::kSettleFrames;
+        if (!tuner.open && tuner.frames_at_candidate >= start) {
+          if (r->window_begin == nullptr) {
+            r->window_begin = make_event(true);
+            r->window_end = make_event(true);
+          }
+          hip_ok(hipEventRecord(r->window_begin, stream_m), "hipEventRecord");
+          tuner.open = true;
+        } else if (tuner.open &&
+                   tuner.frames_at_candidate >= start + CoRunTuner::kWindowFrames) {
+          hip_ok(hipEventRecord(r->window_end, stream_m), "hipEventRecord");
+          tuner.open = false;
+          tuner.closing = true;
+        }
+      }
+    }
     if (r->timing) hip_ok(hipEventRecord(timed.march_end, stream_m), "hipEventRecord");
     hip_ok(hipEventRecord(r->marched_event[slot], stream_m), "hipEventRecord");
     r->marched_pending[slot] = true;

@@ -662,17 +662,20 @@ class NativeRenderer:
         _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
 
     def set_classify_share(self, lds_reserve_bytes: int = -1) -> None:
-        """avr_renderer_set_classify_share: -1 = balanced by the driver (default), >= 0 = fixed
+        """avr_renderer_set_classify_share: -1 = measured by the driver (default), >= 0 = fixed
         LDS reserve per classify workgroup while the pass runs beside the march."""
         _capi.check(_capi.lib().avr_renderer_set_classify_share(self._handle,
                                                                 int(lds_reserve_bytes)))
 
-    def classify_share(self):
-        """(LDS reserve in use, timed probes so far)."""
-        reserve, probes = C.c_int(0), C.c_long(0)
-        _capi.check(_capi.lib().avr_renderer_classify_share(self._handle, C.byref(reserve),
-                                                            C.byref(probes)))
-        return reserve.value, probes.value
+    def corun_state(self) -> dict:
+        """avr_renderer_corun_state: how the last frame placed the classify pass and the march."""
+        overlap, reserve, settled, windows = C.c_int(0), C.c_int(0), C.c_int(0), C.c_long(0)
+        _capi.check(_capi.lib().avr_renderer_corun_state(self._handle, C.byref(overlap),
+                                                         C.byref(reserve), C.byref(settled),
+                                                         C.byref(windows)))
+        return {"classify": "beside the march" if overlap.value else "before the march",
+                "lds_reserve_bytes": reserve.value, "settled": bool(settled.value),
+                "timed_windows": windows.value}
 
     def set_scalar_range(self, scalar_range) -> None:
         rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))

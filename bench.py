@@ -441,9 +441,7 @@ def main():
                                   "Python pipeline with torch.distributed RCCL collectives -- the "
                                   f"C++ driver's communicator failed: {renderer.native_error}"),
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
-            "classify_lds_reserve": (dict(zip(("bytes", "probes"), renderer.native.classify_share()),
-                                          mode="fixed" if args.classify_share >= 0 else "balanced")
-                                     if native else None),
+            "corun": renderer.native.corun_state() if native else None,
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
             "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,

@@ -447,17 +447,21 @@ int avr_renderer_set_scalar_range(avr_renderer *renderer, const float scalar_ran
  * cache_classification is on. */
 int avr_renderer_invalidate(avr_renderer *renderer);
 /* Whether the classify pass of frame i+1 runs on its own stream beside the march of frame i
- * (1), or both run back to back on the march stream (0); -1 = default: beside for one rank,
- * back to back for a rank's share of an N-rank frame.  Never changes results. */
+ * (1), or both run back to back on the march stream (0); -1 = default: whichever the driver
+ * measures to be faster (avr_renderer_set_classify_share).  Never changes results. */
 int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
-/* How the classify pass shares the GPU with the march beside it (only when they overlap):
- * bytes >= 0 fixes avr_context_set_classify_lds_reserve; -1 (default) = balanced by the driver:
- * every few frames it times both kernels with HIP events and moves the reserve one step towards
- * equal durations (more reserve = fewer resident classify workgroups = slower classify pass,
- * faster march), which is where the frame is shortest.  Never changes results.
- * avr_renderer_classify_share: the reserve in use and the number of timed probes so far. */
+/* How the classify pass and the march of this rank share the GPU is measured by the driver on
+ * the running pipeline, unless fixed here and / or by avr_renderer_set_overlap: the candidates --
+ * back to back on one stream, or side by side with an LDS reserve of 0, 2, 4 ... KiB per classify
+ * workgroup (avr_context_set_classify_lds_reserve) -- are each held for a few frames whose
+ * period is timed with HIP events on the march stream, and the best is kept (re-timed now and
+ * then; searched again when it drifts).  bytes >= 0 fixes the reserve of the side-by-side mode,
+ * -1 (default) leaves it to the driver.  Never changes results.
+ * avr_renderer_corun_state: what the last frame used, whether the search has settled, and the
+ * number of timed windows so far. */
 int avr_renderer_set_classify_share(avr_renderer *renderer, int bytes);
-int avr_renderer_classify_share(const avr_renderer *renderer, int *bytes_out, long *probes_out);
+int avr_renderer_corun_state(const avr_renderer *renderer, int *overlap_out,
+                             int *reserve_bytes_out, int *settled_out, long *windows_out);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream

@@ -238,11 +238,12 @@ def test_growing_send_buffers_under_allocator_churn(O, ctx, native):
         assert torch.equal(rgb8, want_rgb8), (w, h)
 
 
-def test_classify_share_never_changes_results_and_the_balance_moves(O, ctx):
-    """avr_renderer_set_classify_share: the LDS reserve that caps the classify pass beside the
-    march is scheduling only -- frames rendered back to back with a fixed reserve of 0, of the
-    maximum, and with the driver's balance are bit-identical to a fresh renderer's; the balance
-    times the kernel pair (probes > 0) once the pipeline is running."""
+def test_corun_tuning_never_changes_results(O, ctx):
+    """avr_renderer_set_classify_share / avr_renderer_set_overlap: where the classify pass runs
+    (before or beside the march) and the LDS reserve that caps it there are scheduling only --
+    frames rendered back to back while the driver tries its candidates, and with either choice
+    fixed by the caller, are bit-identical to a fresh renderer's; the driver times windows of
+    frames once the pipeline is running and reports what it used."""
     spec = scenes.make_amr_scene(32, 2, 8, "smooth")
     cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
     meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
@@ -251,10 +252,11 @@ def test_classify_share_never_changes_results_and_the_balance_moves(O, ctx):
     p = RenderParameters(160, 120, 0.9, 1)
     cams = [scenes.orbit_camera(v) for v in range(3)]
 
-    def run(share, frames):
+    def run(share, overlap, frames):
         renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
         assert renderer.native is not None
         renderer.native.set_classify_share(share)
+        renderer.native.set_overlap(overlap)
         out = []
         for f in range(frames):   # back to back: no synchronisation between frames
             out.append(renderer.render(p, cams[f % len(cams)], want_image=True))
@@ -262,14 +264,19 @@ def test_classify_share_never_changes_results_and_the_balance_moves(O, ctx):
         torch.cuda.synchronize()
         return renderer, out
 
-    _, want = run(0, 3)
-    for share in (61440, -1):
-        renderer, got = run(share, 60)
-        reserve, probes = renderer.native.classify_share()
-        if share >= 0:
-            assert (reserve, probes) == (share, 0)
+    _, want = run(0, 0, 3)
+    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 700), (4096, -1, 60)):
+        renderer, got = run(share, overlap, frames)
+        state = renderer.native.corun_state()
+        if overlap == 1:
+            assert state == {"classify": "beside the march", "lds_reserve_bytes": share,
+                             "settled": True, "timed_windows": 0}
+        elif share < 0:
+            assert state["timed_windows"] >= 4 and state["settled"]
+            assert 0 <= state["lds_reserve_bytes"] <= 57344
         else:
-            assert probes >= 2 and 0 <= reserve <= 57344
+            assert state["timed_windows"] >= 2 and state["settled"]
+            assert state["lds_reserve_bytes"] in (0, share)
         for f, (image, rgb8) in enumerate(got):
             w_image, w_rgb8 = want[f % len(cams)]
             assert torch.equal(image.view(torch.int32), w_image.view(torch.int32)), (share, f)

@@ -8,5 +8,7 @@ for v in "$@"; do
   for rep in 1 2; do
   python3 bench.py --no-cpu-baseline --cache-classification --march-occupancy 0 --steps 300 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v march-only  frame %.4f ms  march kernel %.4f ms' % (d['ms_per_step'], d['roofline']['march_ms']))"
   done
-  python3 bench.py --no-cpu-baseline --steps 300 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v pipelined   frame %.4f ms  classify %.4f march %.4f cap %s' % (d['ms_per_step'], d['roofline']['classify_ms'], d['roofline']['march_ms'], d['config']['march_workgroups_per_cu']))"
+  for rep in 1 2; do
+  python3 bench.py --no-cpu-baseline --steps 300 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v pipelined   frame %.4f ms  classify %.4f march %.4f share %s' % (d['ms_per_step'], d['roofline']['classify_ms'], d['roofline']['march_ms'], d['config'].get('corun')))"
+  done
 done
