@@ -25,6 +25,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -107,18 +108,22 @@ struct CoRunTuner {
   static constexpr int kBackToBack = -1;       // candidate: both kernels on the march stream
   static constexpr int kReserveStep = 2048;    // candidate k >= 0: side by side, reserve k * step
   static constexpr int kLastCandidate = 28;    // 56 KiB: two classify workgroups per CU
+  static constexpr int kCoarse = 2;            // the first pass takes every second reserve
   static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate
-  static constexpr int kWindowFrames = 6;      // frames timed per candidate
+  static constexpr int kWindowFrames = 8;      // frames timed per candidate
   static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
-  static constexpr float kWorse = 1.04f;       // "clearly worse than the best so far"
   static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
 
-  enum Phase { kSearch, kHold } phase = kSearch;
+  // kSearch: back to back, then reserves 0, 4, 8 ... KiB; kRefine: the two reserves either side
+  // of the best one; kVerify: back to back and the best reserve once more; kHold: the winner.  (No early exit: over the reserve the
+  // period is flat, dips and rises again, and for the short kernels of an N-rank share the dip
+  // lies at the far end -- a search that stopped on the flat stretch missed it.)
+  enum Phase { kSearch, kRefine, kVerify, kHold } phase = kSearch;
   int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
   int candidate = kBackToBack;
-  int best = kBackToBack;
-  float best_ms = 0.0f;
-  int worse_in_a_row = 0;
+  int best = kBackToBack, best_beside = 0;
+  float best_ms = 0.0f, best_beside_ms = 0.0f;
+  int refined = 0;
   long windows = 0;
   // the window in progress
   int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
@@ -133,19 +138,29 @@ struct CoRunTuner {
   void restart() {
     phase = kSearch;
     candidate = best = first;
-    best_ms = 0.0f;
-    worse_in_a_row = 0;
+    best_beside = 0;
+    best_ms = best_beside_ms = 0.0f;
+    refined = 0;
     interrupt();
   }
   void interrupt() {  // the pipeline drained or the candidate changed: the window is void
     frames_at_candidate = 0;
     open = closing = false;
   }
+  void drained() {  // a window whose last frame was already queued stays valid
+    if (!closing) interrupt();
+  }
   bool tuning() const { return first != last; }
+  bool settled() const { return !tuning() || phase == kHold; }
 
   // one timed window of the current candidate
   void report(float period_ms) {
     ++windows;
+    static const bool trace = std::getenv("AVR_CORUN_TRACE") != nullptr;  // diagnostics
+    if (trace) {
+      std::fprintf(stderr, "corun: phase %d candidate %d period %.4f ms\n", static_cast<int>(phase),
+                   candidate, period_ms);
+    }
     if (phase == kHold) {
       if (period_ms > best_ms * kDrift) {
         restart();
@@ -159,17 +174,47 @@ struct CoRunTuner {
       best_ms = period_ms;
       best = candidate;
     }
-    // the reserve only matters side by side, and there the period falls, then rises
-    if (candidate > 0 && period_ms > best_ms * kWorse) {
-      ++worse_in_a_row;
-    } else {
-      worse_in_a_row = 0;
+    if (candidate >= 0 && (best_beside_ms == 0.0f || period_ms < best_beside_ms)) {
+      best_beside_ms = period_ms;
+      best_beside = candidate;
     }
-    if (candidate >= last || worse_in_a_row >= 3) {
-      phase = kHold;
-      candidate = best;
-    } else {
-      ++candidate;
+    if (phase == kSearch) {
+      const int next = (candidate < 0) ? 0 : candidate + kCoarse;
+      if (next <= last) {
+        candidate = next;
+      } else {
+        phase = kRefine;
+      }
+    }
+    if (phase == kRefine) {
+      // best_beside - 1, then best_beside + 1 (those inside the range; the centre may move once)
+      int next = -1;
+      while (refined < 2 && next < 0) {
+        const int probe = best_beside + (refined == 0 ? -1 : 1);
+        ++refined;
+        if (probe >= 0 && probe <= last && last > 0) next = probe;
+      }
+      if (next >= 0) {
+        candidate = next;
+      } else if (first == kBackToBack && last >= 0) {
+        // the two modes once more, now that the pipeline has run for a while (the very first
+        // windows after start-up have read up to 20 % fast): back to back, then the best reserve
+        phase = kVerify;
+        candidate = kBackToBack;
+        best_ms = 0.0f;
+        interrupt();
+        return;
+      } else {
+        phase = kHold;
+        candidate = best;
+      }
+    } else if (phase == kVerify) {
+      if (candidate == kBackToBack) {
+        candidate = best_beside;
+      } else {
+        phase = kHold;
+        candidate = best;  // of the two re-timed windows (best_ms was reset before them)
+      }
     }
     interrupt();
   }
@@ -260,7 +305,7 @@ struct avr_renderer {
   void drain_all() {
     for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
     pipeline_idle = true;
-    tuner.interrupt();
+    tuner.drained();
   }
 };
 
@@ -429,7 +474,7 @@ int avr_renderer_corun_state(const avr_renderer* r, int* overlap_out, int* reser
     const CoRunTuner& t = r->tuner;
     if (overlap_out != nullptr) *overlap_out = r->last_overlap ? 1 : 0;
     if (reserve_bytes_out != nullptr) *reserve_bytes_out = r->last_reserve;
-    if (settled_out != nullptr) *settled_out = (!t.tuning() || t.phase == CoRunTuner::kHold) ? 1 : 0;
+    if (settled_out != nullptr) *settled_out = t.settled() ? 1 : 0;
     if (windows_out != nullptr) *windows_out = t.windows;
     return AVR_OK;
   });

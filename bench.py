@@ -317,13 +317,22 @@ def main():
     # Untimed setup, like the sample counting above: about a third of a second of frames brings
     # the GPU to its working clocks and fills the allocator pools, so that a run timing very few
     # steps (the driver's --steps 20 is a 20 ms timed region) measures the steady state a
-    # 200-step run does; then the W warm-up steps of the contract.
-    burst_end = time.perf_counter() + 0.35
+    # 200-step run does -- and the C++ frame driver finishes measuring how this rank's two
+    # kernels share the GPU (avr_renderer_corun_state; bounded at 2 s); then the W warm-up steps
+    # of the contract.
+    burst_begin = time.perf_counter()
     burst = 0
-    while time.perf_counter() < burst_end or burst < 20:
+
+    def settled():
+        return renderer.native is None or renderer.native.corun_state()["settled"]
+
+    while True:
+        elapsed = time.perf_counter() - burst_begin
+        if burst >= 20 and elapsed >= 0.35 and (elapsed >= 2.0 or settled()):
+            break
         step(burst)
         burst += 1
-        if burst % 16 == 0:
+        if burst % 64 == 0:
             renderer.synchronize()   # keep the queue short so the clock check means GPU time
     renderer.synchronize()
     for i in range(args.warmup):

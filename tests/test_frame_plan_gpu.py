@@ -265,7 +265,7 @@ def test_corun_tuning_never_changes_results(O, ctx):
         return renderer, out
 
     _, want = run(0, 0, 3)
-    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 700), (4096, -1, 60)):
+    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 700), (4096, -1, 150)):
         renderer, got = run(share, overlap, frames)
         state = renderer.native.corun_state()
         if overlap == 1:

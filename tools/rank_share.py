@@ -17,19 +17,22 @@ readings are printed:
   serial    share + exchange + gather          (nothing overlaps: an upper bound)
   pipelined max(share, exchange + fold + gather)   (what the three streams are built for)
 
+Every share is measured in a process of its own, as a rank of the N-GPU job would run it: HIP
+maps streams onto a few hardware queues in creation order, and in a process that had already
+created and destroyed other renderers the classify and the march stream of a later one were seen
+to land on one queue -- "side by side" then means one after the other, and the driver's co-run
+search (avr_renderer_corun_state) rightly but unrepresentatively chose "back to back".
+
 An estimate tool -- not a bench line.  The 8-GPU measurement is the driver's.
 """
 import argparse
+import json
 import os
+import subprocess
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-
-from amrvolumerenderer_amd import runtime, scenes
-from amrvolumerenderer_amd.renderer import build_scene_on_device
-from amrvolumerenderer_amd.types import CameraParameters
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="config4")
@@ -45,10 +48,71 @@ ap.add_argument("--rccl-latency-us", type=float, default=None,
                      "measured here on a one-rank RCCL communicator")
 ap.add_argument("--only-rank", type=int, default=-1)
 ap.add_argument("--overlap", type=int, default=-1, help="avr_renderer_set_overlap")
+ap.add_argument("--classify-share", type=int, default=-1, help="avr_renderer_set_classify_share")
+ap.add_argument("--worker", type=int, nargs=2, metavar=("N_RANKS", "RANK"), default=None,
+                help="internal: measure this one share and print it as a JSON line")
+ap.add_argument("--latency-worker", action="store_true", help="internal: RCCL round latency")
 args = ap.parse_args()
 
-cam = scenes.default_camera()
-device = torch.device("cuda", 0)
+
+def measure_share(n_ranks, rank):
+    import torch
+    from amrvolumerenderer_amd import runtime, scenes
+    from amrvolumerenderer_amd.renderer import build_scene_on_device
+
+    cam = scenes.default_camera()
+    device = torch.device("cuda", 0)
+    spec = getattr(scenes, args.config)("smooth")
+    scenes.assign_owners(spec, n_ranks, args.ownership)
+    ctx = runtime.Context(0)
+    all_boxes, local = build_scene_on_device(ctx, spec, rank)
+    merged, mine = [], iter(local)
+    for b in all_boxes:
+        merged.append(next(mine) if b.owner == rank else b)
+    comm = runtime.Comm.solo(rank, n_ranks) if n_ranks > 1 else None
+    r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, rank,
+                               n_ranks, comm)
+    r.set_options(args.march_occupancy, False)
+    r.set_overlap(args.overlap)
+    r.set_classify_share(args.classify_share)
+    counter = torch.zeros(1, dtype=torch.int64, device=device)
+    kw = dict(use_visibility_graph=True, draw_bounds=False)
+    r.render(args.size, args.size, args.transparency, 1, cam, samples=counter, **kw)
+    r.synchronize()
+    samples = int(counter.item())
+    info = r.plan_info()
+    # clocks and allocator pools settle, and the driver finishes measuring how the rank's two
+    # kernels share the GPU (bounded at 3 s)
+    begin = time.perf_counter()
+    warm = 0
+    while True:
+        elapsed = time.perf_counter() - begin
+        if warm >= 30 and elapsed >= 0.5 and (elapsed >= 3.0 or r.corun_state()["settled"]):
+            break
+        r.render(args.size, args.size, args.transparency, 1, cam, **kw)
+        warm += 1
+        if warm % 64 == 0:
+            r.synchronize()
+    r.synchronize()
+    torch.cuda.synchronize()
+    r.set_timing(True)
+    r.host_profile(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.frames):
+        r.render(args.size, args.size, args.transparency, 1, cam, **kw)
+    host = (time.perf_counter() - t0) / args.frames
+    r.synchronize()
+    torch.cuda.synchronize()
+    share = (time.perf_counter() - t0) / args.frames
+    sections, _ = r.host_profile()
+    classify_ms, march_ms, busy_ms, _ = r.timings()
+    r.set_timing(False)
+    return dict(rank=rank, boxes=len(local), share_ms=1e3 * share, host_ms=1e3 * host,
+                classify_ms=classify_ms, march_ms=march_ms, busy_ms=busy_ms,
+                send_mb=info.send_floats * 4 / 1e6, recv_mb=info.recv_floats * 4 / 1e6,
+                runs=info.n_local_runs, samples=samples,
+                piece_px=info.piece_end - info.piece_begin, corun=r.corun_state(),
+                host_us={k: round(v) for k, v in sections.items()})
 
 
 def measure_rccl_latency():
@@ -56,7 +120,9 @@ def measure_rccl_latency():
     the only RCCL configuration a one-GPU box can run)."""
     import ctypes as C
     import numpy as np
-    from amrvolumerenderer_amd import _capi
+    import torch
+    from amrvolumerenderer_amd import _capi, runtime
+    device = torch.device("cuda", 0)
     L = _capi.lib()
     ctx = runtime.Context(0)
     comm = runtime.Comm(0, 0, 1, lambda ident: ident)
@@ -81,67 +147,40 @@ def measure_rccl_latency():
     return 1e6 * float(np.median(times))
 
 
-print(f"{args.config}, {args.size}^2, ownership {args.ownership}")
+if args.worker is not None:
+    print(json.dumps(measure_share(*args.worker)), flush=True)
+    raise SystemExit(0)
+if args.latency_worker:
+    print(json.dumps({"latency_us": measure_rccl_latency()}), flush=True)
+    raise SystemExit(0)
 
+
+def child(extra):
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    for line in out.stdout.splitlines():
+        if line.startswith("{"):
+            return json.loads(line)
+    raise SystemExit(f"worker failed: {' '.join(cmd)}\n{out.stdout[-2000:]}\n{out.stderr[-2000:]}")
+
+
+print(f"{args.config}, {args.size}^2, ownership {args.ownership}", flush=True)
 summary = []
 for n_ranks in args.ranks:
-    spec = getattr(scenes, args.config)("smooth")
-    scenes.assign_owners(spec, n_ranks, args.ownership)
-    worst = {"share": 0.0, "host": 0.0}
     per_rank = []
     for rank in (range(n_ranks) if args.only_rank < 0 else [args.only_rank]):
-        ctx = runtime.Context(0)
-        all_boxes, local = build_scene_on_device(ctx, spec, rank)
-        merged, mine = [], iter(local)
-        for b in all_boxes:
-            merged.append(next(mine) if b.owner == rank else b)
-        comm = runtime.Comm.solo(rank, n_ranks) if n_ranks > 1 else None
-        r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, rank,
-                                   n_ranks, comm)
-        r.set_options(args.march_occupancy, False)
-        r.set_overlap(args.overlap)
-        counter = torch.zeros(1, dtype=torch.int64, device=device)
-        kw = dict(use_visibility_graph=True, draw_bounds=False)
-        r.render(args.size, args.size, args.transparency, 1, cam, samples=counter, **kw)
-        r.synchronize()
-        samples = int(counter.item())
-        info = r.plan_info()
-        warm_until = time.perf_counter() + 0.5   # clocks and allocator pools settle
-        warm = 0
-        while time.perf_counter() < warm_until or warm < 30:
-            r.render(args.size, args.size, args.transparency, 1, cam, **kw)
-            warm += 1
-            if warm % 16 == 0:
-                r.synchronize()
-        r.synchronize()
-        torch.cuda.synchronize()
-        r.set_timing(True)
-        r.host_profile(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.frames):
-            r.render(args.size, args.size, args.transparency, 1, cam, **kw)
-        host = (time.perf_counter() - t0) / args.frames
-        r.synchronize()
-        torch.cuda.synchronize()
-        share = (time.perf_counter() - t0) / args.frames
-        sections, _ = r.host_profile()
-        classify_ms, march_ms, busy_ms, _ = r.timings()
-        r.set_timing(False)
-        # exchange volume per peer from the plan (floats -> bytes)
-        send_mb = info.send_floats * 4 / 1e6
-        recv_mb = info.recv_floats * 4 / 1e6
-        per_rank.append(dict(rank=rank, boxes=len(local), share_ms=1e3 * share, host_ms=1e3 * host,
-                             classify_ms=classify_ms, march_ms=march_ms, busy_ms=busy_ms,
-                             send_mb=send_mb, recv_mb=recv_mb, runs=info.n_local_runs,
-                             samples=samples, piece_px=info.piece_end - info.piece_begin))
-        print(f"  N={n_ranks} rank {rank}: boxes {len(local):3d} runs {info.n_local_runs:3d} "
-              f"share {1e3 * share:6.3f} ms (host {1e3 * host:5.3f}; classify {classify_ms:5.3f} "
-              f"march {march_ms:5.3f} union {busy_ms:5.3f})  send {send_mb:6.2f} MB recv "
-              f"{recv_mb:6.2f} MB  samples {samples / 1e6:6.1f} M")
-        print("      host us/frame inside the C ABI: " +
-              "  ".join(f"{k} {v:.0f}" for k, v in sections.items()))
-        del r, comm, local, all_boxes, merged
-        torch.cuda.empty_cache()
+        d = child(["--worker", str(n_ranks), str(rank)])
+        per_rank.append(d)
+        corun = d["corun"]
+        print(f"  N={n_ranks} rank {rank}: boxes {d['boxes']:3d} runs {d['runs']:3d} "
+              f"share {d['share_ms']:6.3f} ms (host {d['host_ms']:5.3f}; classify "
+              f"{d['classify_ms']:5.3f} march {d['march_ms']:5.3f} union {d['busy_ms']:5.3f})  send "
+              f"{d['send_mb']:6.2f} MB recv {d['recv_mb']:6.2f} MB  samples "
+              f"{d['samples'] / 1e6:6.1f} M")
+        print(f"      classify {corun['classify']}, LDS reserve {corun['lds_reserve_bytes']} "
+              f"({'settled' if corun['settled'] else 'still searching'} after "
+              f"{corun['timed_windows']} timed windows); host us/frame inside the C ABI: " +
+              "  ".join(f"{k} {v}" for k, v in d["host_us"].items()), flush=True)
     slowest = max(per_rank, key=lambda d: d["share_ms"])
     # busiest link: a rank sends / receives at most its whole buffer split over N-1 peers; the
     # pessimistic reading puts a rank's whole receive volume on ONE link
@@ -153,25 +192,25 @@ for n_ranks in args.ranks:
             worst_even = max(max(d["send_mb"], d["recv_mb"]) for d in per_rank) / (n_ranks - 1)
             worst_one = max(max(d["send_mb"], d["recv_mb"]) for d in per_rank)
             ex = worst_even / gbs      # MB / (GB/s) = ms; the RCCL latency is added below
-            ex_pess = worst_one / gbs
             ga = (args.size * args.size * 3 / n_ranks / 1e6) / gbs
-            line[f"ex_pess@{gbs:g}"] = ex_pess
+            line[f"ex_pess@{gbs:g}"] = worst_one / gbs
         line[f"ex@{gbs:g}"] = ex
         line[f"ga@{gbs:g}"] = ga
     summary.append(line)
 
-# RCCL is initialised only now: merely creating a communicator in this process was measured to
-# change how kernels of different streams share the GPU afterwards (one rank, classify beside
-# march: 1.06 ms per frame before, 1.33 ms after) -- which is also why a rank of an N-rank frame
-# runs its two kernels back to back by default (avr_renderer_set_overlap).
-latency_us = args.rccl_latency_us if args.rccl_latency_us is not None else measure_rccl_latency()
+# (RCCL in a process of its own too: merely creating a communicator was measured to change how
+# kernels of different streams share the GPU afterwards -- one rank, classify beside march,
+# 1.06 ms per frame before and 1.33 ms after -- one more reason why the driver MEASURES whether
+# a rank's two kernels run back to back or side by side: on the 8-GPU node each rank decides
+# with RCCL present.)
+latency_us = (args.rccl_latency_us if args.rccl_latency_us is not None
+              else child(["--latency-worker"])["latency_us"])
 print(f"RCCL round latency {latency_us:.1f} us "
       f"({'given' if args.rccl_latency_us is not None else 'measured, one-rank communicator'})")
 for line in summary:
-    n_ranks = line["n"]
+    if line["n"] == 1:
+        continue
     for gbs in args.link_gbs:
-        if n_ranks == 1:
-            continue
         line[f"ex@{gbs:g}"] += latency_us * 1e-3
         line[f"ex_pess@{gbs:g}"] += latency_us * 1e-3
         line[f"ga@{gbs:g}"] += latency_us * 1e-3
