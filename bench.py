@@ -327,11 +327,20 @@ def main():
         return renderer.native is None or renderer.native.corun_state()["settled"]
 
     while True:
+        # every rank runs the same number of frames (each one is a collective): the ranks agree
+        # on stopping, chunk by chunk
+        for _ in range(16):
+            step(burst)
+            burst += 1
         elapsed = time.perf_counter() - burst_begin
-        if burst >= 20 and elapsed >= 0.35 and (elapsed >= 2.0 or settled()):
+        done = burst >= 32 and elapsed >= 0.35 and (elapsed >= 2.0 or settled())
+        if world > 1:
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32,
+                                device="cpu" if args.rehearse_on_one_gpu else ctx.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            done = bool(flag.item())
+        if done:
             break
-        step(burst)
-        burst += 1
         if burst % 64 == 0:
             renderer.synchronize()   # keep the queue short so the clock check means GPU time
     renderer.synchronize()
