@@ -54,14 +54,18 @@ def test_adapter_single_rank_compose(O, avr_lib, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ranks,policy,antialiasing", [(1, "morton", 1), (3, "morton", 1),
-                                                         (4, "round_robin", 1), (2, "morton", 4)])
+@pytest.mark.parametrize("n_ranks,policy,antialiasing,frames", [
+    (1, "morton", 1, 3), (3, "morton", 1, 3), (4, "round_robin", 1, 3), (2, "morton", 4, 3),
+    # long enough for every rank's driver to try all its ways of running the classify pass and
+    # the march (back to back, side by side with each LDS reserve) and settle: the last frame
+    # must still be the oracle's
+    (3, "round_robin", 1, 330)])
 def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, policy,
-                                                 antialiasing):
+                                                 antialiasing, frames):
     """The whole frame driven from C++ over the C ABI alone: one avr::FrameDriver (the pipelined
     avr_renderer: visibility order, frame plan, classify + march on their streams, exchange, fold,
     overlay, gather, downsample, bytes) per rank, every rank a host thread of one process, wired
-    with the in-process rehearsal communicator; three frames back to back without synchronising."""
+    with the in-process rehearsal communicator; the frames back to back without synchronising."""
     import struct
     from amrvolumerenderer_amd import scenes
     from test_frame_plan import local_indices, oracle_overlay, painted_scene
@@ -80,7 +84,7 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
             fh.write(struct.pack("<4i", c.shape[2], c.shape[1], c.shape[0], b.owner))
             fh.write(np.ascontiguousarray(c, dtype="<f8").tobytes())
     subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
-                    str(transparency), str(antialiasing), "3", str(tmp_path / "image.bin"),
+                    str(transparency), str(antialiasing), str(frames), str(tmp_path / "image.bin"),
                     str(tmp_path / "rgb8.bin")], check=True, timeout=180)
     want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
     if root > 1:
