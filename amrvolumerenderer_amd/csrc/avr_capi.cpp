@@ -173,15 +173,16 @@ struct avr_scene {
   avr_context* ctx = nullptr;
   std::vector<avr_box> boxes;
   avr_scalar_transform transform{};
-  // two classified volumes, so that the classify pass of frame i+1 can overlap the march of
-  // frame i (grow-only; a frame of the same scene never reallocates)
-  void* classified[2] = {nullptr, nullptr};
-  size_t classified_capacity[2] = {0, 0};
+  // classified volumes (allocated on first use, grow-only; a frame of the same scene never
+  // reallocates): two let the classify pass of frame i+1 overlap the march of frame i, the third
+  // lets it run ahead so that neither stream waits for the other's launch (avr_renderer)
+  void* classified[AVR_CLASSIFIED_SLOTS] = {};
+  size_t classified_capacity[AVR_CLASSIFIED_SLOTS] = {};
   int device = 0;
   // optional re-use of a slot's classified volume across frames (avr_scene_set_classification_cache):
   // what the classify pass of the slot's current contents depended on
   bool cache_classification = false;
-  std::vector<uint64_t> classified_key[2];
+  std::vector<uint64_t> classified_key[AVR_CLASSIFIED_SLOTS];
 
   ~avr_scene() {
     for (void* buffer : classified) {
@@ -279,7 +280,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const std::vector<avr::RunBlockDev>& run_blocks, avr_scene* scene, int slot,
            float* out_layers, uint64_t* samples_out, avr::FramePlan* cached) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
-  require(slot == 0 || slot == 1, "classified slot must be 0 or 1");
+  require(slot >= 0 && slot < AVR_CLASSIFIED_SLOTS, "classified slot out of range");
   avr::FramePlan local;
   avr::FramePlan& plan = cached ? *cached : local;
   if (plan.boxes.size() != static_cast<size_t>(n_boxes) || !plan.ready) {

@@ -245,11 +245,12 @@ struct avr_renderer {
   bool have_plan = false;
 
   DeviceBuffer send[2], recv, piece, piece_rgb8, full_rgb8, full_image, small_image;
-  hipEvent_t classified_event[2] = {nullptr, nullptr};  // classify pass of the slot finished
-  hipEvent_t marched_event[2] = {nullptr, nullptr};     // march finished reading classified[slot]
-  hipEvent_t composed_event[2] = {nullptr, nullptr};    // stream X finished reading send[slot]
+  // classified volume f % 3, send buffer f % 2
+  hipEvent_t classified_event[AVR_CLASSIFIED_SLOTS] = {};  // classify pass of the volume finished
+  hipEvent_t marched_event[AVR_CLASSIFIED_SLOTS] = {};     // march finished reading the volume
+  hipEvent_t composed_event[2] = {nullptr, nullptr};       // stream X finished reading send[slot]
   hipEvent_t input_event = nullptr;
-  bool marched_pending[2] = {false, false}, composed_pending[2] = {false, false};
+  bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[2] = {false, false};
   unsigned frame = 0;
 
   // host time spent inside avr_renderer_render, by section (avr_renderer_host_profile)
@@ -278,10 +279,14 @@ struct avr_renderer {
     for (hipEvent_t ev : {window_begin, window_end}) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
     }
-    for (hipEvent_t* list : {classified_event, marched_event, composed_event}) {
-      for (int s = 0; s < 2; ++s) {
-        if (list[s] != nullptr) (void)hipEventDestroy(list[s]);
-      }
+    for (hipEvent_t ev : classified_event) {
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
+    for (hipEvent_t ev : marched_event) {
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
+    for (hipEvent_t ev : composed_event) {
+      if (ev != nullptr) (void)hipEventDestroy(ev);
     }
     if (input_event != nullptr) (void)hipEventDestroy(input_event);
     if (epoch != nullptr) (void)hipEventDestroy(epoch);
@@ -415,11 +420,9 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
       abi_ok(avr_visibility_graph_create(all_boxes, owner, n_boxes, n_ranks, &r->visibility));
     }
     hip_ok(hipSetDevice(device_id), "hipSetDevice");
-    for (int s = 0; s < 2; ++s) {
-      r->classified_event[s] = make_event(false);
-      r->marched_event[s] = make_event(false);
-      r->composed_event[s] = make_event(false);
-    }
+    for (hipEvent_t& ev : r->classified_event) ev = make_event(false);
+    for (hipEvent_t& ev : r->marched_event) ev = make_event(false);
+    for (hipEvent_t& ev : r->composed_event) ev = make_event(false);
     r->input_event = make_event(false);
     *out_renderer = r.release();
     return AVR_OK;
@@ -697,7 +700,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     hipStream_t stream_c = r->stream_of(classify_ctx);
     hipStream_t stream_m = r->stream_of(r->march);
     hipStream_t stream_x = r->stream_of(r->compose);
+    // Send buffers alternate; the classified volumes rotate through three, so that the classify
+    // stream may run a whole frame ahead of the march: with two, classify(f+1) and march(f) both
+    // had to wait for the later of classify(f) and march(f-1) and started in lockstep, a launch
+    // latency apart from the kernels before them, every frame.
     const int slot = static_cast<int>(r->frame & 1u);
+    const int volume = static_cast<int>(r->frame % static_cast<unsigned>(AVR_CLASSIFIED_SLOTS));
     ++r->frame;
     auto drain = [&] { r->drain_all(); };
 
@@ -721,8 +729,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       hip_ok(hipEventRecord(r->input_event, static_cast<hipStream_t>(input_stream)), "hipEventRecord");
       hip_ok(hipStreamWaitEvent(stream_c, r->input_event, 0), "hipStreamWaitEvent");
     }
-    if (r->marched_pending[slot]) {  // the frame before last still marches this volume
-      hip_ok(hipStreamWaitEvent(stream_c, r->marched_event[slot], 0), "hipStreamWaitEvent");
+    if (r->marched_pending[volume]) {  // three frames ago this volume was marched
+      hip_ok(hipStreamWaitEvent(stream_c, r->marched_event[volume], 0), "hipStreamWaitEvent");
     }
     float* send = static_cast<float*>(
         r->send[slot].reserve(static_cast<size_t>(std::max<int64_t>(info.send_floats, 1)) * 4, drain));
@@ -730,8 +738,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
-    abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, slot));
-    hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[slot];
+    abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
+    hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[volume];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
 
     lap(1);
@@ -743,7 +751,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
-    abi_ok(avr_march_plan(r->march, r->scene, plan, slot, send, samples_out));
+    abi_ok(avr_march_plan(r->march, r->scene, plan, volume, send, samples_out));
     // the tuner's window: the period of kWindowFrames frames between two events after the march
     if (tuner.tuning()) {
       if (tuner.closing && hipEventQuery(r->window_end) == hipSuccess) {
@@ -773,13 +781,13 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_end, stream_m), "hipEventRecord");
-    hip_ok(hipEventRecord(r->marched_event[slot], stream_m), "hipEventRecord");
-    r->marched_pending[slot] = true;
+    hip_ok(hipEventRecord(r->marched_event[volume], stream_m), "hipEventRecord");
+    r->marched_pending[volume] = true;
     if (r->timing) r->timed.push_back(timed);
 
     lap(2);
     // ---- stream X: exchange, fold, gather, frame tail ------------------------------------------
-    hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[slot], 0), "hipStreamWaitEvent");
+    hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[volume], 0), "hipStreamWaitEvent");
     const float* received = send;
     if (r->n_ranks > 1) {
       float* recv = static_cast<float*>(

@@ -306,9 +306,13 @@ int avr_render_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_pl
                     float *send_buffer, uint64_t *samples_out);
 
 /* The two halves of avr_render_plan as separate calls, for pipelining frames: the classify pass
- * of frame i+1 (any context / stream) may run while frame i is still marched.  `slot` (0 or 1)
- * selects one of the scene's two classified volumes; the caller orders march(slot) after
- * classify(slot) of the same frame and classify(slot) after the previous march(slot). */
+ * of frame i+1 (any context / stream) may run while frame i is still marched.  `slot`
+ * (0 .. AVR_CLASSIFIED_SLOTS-1) selects one of the scene's classified volumes (each allocated
+ * when first used); the caller orders march(slot) after classify(slot) of the same frame and
+ * classify(slot) after the previous march(slot).  Two slots are enough to overlap; with three
+ * the classify stream can run a frame further ahead, so that neither stream waits for a launch
+ * on the other (avr_renderer does). */
+#define AVR_CLASSIFIED_SLOTS 3
 int avr_classify_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
                       int slot);
 int avr_march_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan, int slot,

@@ -191,17 +191,18 @@ def test_classification_cache_is_exact_and_invalidates(O, ctx):
     for (a, a8), (b, b8) in zip(frames(wide, cams[:2]), frames(cached, cams[:2])):
         assert np.array_equal(a, b) and np.array_equal(a8, b8)
     cached.scalar_range = spec.scalar_range
-    # cells changed in place: stale until invalidate()
-    before = frames(cached, cams[:2])   # both classified slots now hold the original cells
+    # cells changed in place: stale until invalidate() (three frames: every one of the driver's
+    # AVR_CLASSIFIED_SLOTS classified volumes then holds the original cells under the current key)
+    before = frames(cached, cams[:3])
     local[0].values.mul_(0.25)
     ctx.synchronize()
     torch.cuda.synchronize()
-    stale = frames(cached, cams[:2])
+    stale = frames(cached, cams[:3])
     assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(before, stale))
     cached.invalidate()
-    fresh = frames(cached, cams[:2])
+    fresh = frames(cached, cams[:3])
     truth = frames(FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range),
-                   cams[:2])
+                   cams[:3])
     assert all(np.array_equal(a, b) for (a, _), (b, _) in zip(truth, fresh))
     assert not all(np.array_equal(a, b) for (a, _), (b, _) in zip(before, fresh))
 
