@@ -326,19 +326,18 @@ def main():
     def settled():
         return renderer.native is None or renderer.native.corun_state()["settled"]
 
+    # (N ranks: every frame is a collective, so every rank must run the same number of them --
+    # a fixed count, well past the ~260 frames the search takes, instead of a clock)
+    fixed_burst = 640 if world > 1 else None
     while True:
-        # every rank runs the same number of frames (each one is a collective): the ranks agree
-        # on stopping, chunk by chunk
         for _ in range(16):
             step(burst)
             burst += 1
         elapsed = time.perf_counter() - burst_begin
-        done = burst >= 32 and elapsed >= 0.35 and (elapsed >= 2.0 or settled())
-        if world > 1:
-            flag = torch.tensor([1 if done else 0], dtype=torch.int32,
-                                device="cpu" if args.rehearse_on_one_gpu else ctx.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            done = bool(flag.item())
+        if fixed_burst is not None:
+            done = burst >= fixed_burst
+        else:
+            done = burst >= 32 and elapsed >= 0.35 and (elapsed >= 2.0 or settled())
         if done:
             break
         if burst % 64 == 0:
