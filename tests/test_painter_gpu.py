@@ -103,6 +103,36 @@ def test_classify_chunk_that_starts_on_the_odd_last_cell(O, ctx):
                 96, 64, cells_view=(storage, sl))
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_classify_random_box_shapes_and_views(O, ctx, seed):
+    """Randomised shapes for the classify pass's addressing: nx from 1 to 300 (several 128-cell
+    chunks, odd and even row ends, a chunk that starts on the row's last cell), ny / nz that leave
+    partial bricklets, sub-boxes at random offsets of a larger fab (16-byte aligned rows or not,
+    even or odd row pitch), non-finite cells, the standard and the general scalar transform."""
+    rng = np.random.default_rng(4200 + seed)
+    total = 0
+    for case in range(14):
+        nx = int(rng.choice([1, 2, 3, 7, 8, 9, 127, 128, 129, 130, 255, 257, 300,
+                             int(rng.integers(1, 301))]))
+        ny, nz = int(rng.integers(1, 10)), int(rng.integers(1, 10))
+        pad = [int(v) for v in rng.integers(0, 4, size=6)]   # ghost cells: z lo/hi, y lo/hi, x lo/hi
+        storage = rng.random((nz + pad[0] + pad[1], ny + pad[2] + pad[3], nx + pad[4] + pad[5]))
+        holes = rng.integers(0, storage.size, size=max(storage.size // 200, 1))
+        storage.reshape(-1)[holes] = rng.choice([np.nan, np.inf, -np.inf, -3.0, 7.5],
+                                                 size=holes.size)
+        sl = (slice(pad[0], pad[0] + nz), slice(pad[2], pad[2] + ny), slice(pad[4], pad[4] + nx))
+        cells = np.ascontiguousarray(storage[sl])
+        lo = (0.1, 0.35, 0.3)
+        hi = (0.1 + 0.8 * min(nx, 64) / 64.0, 0.35 + 0.03 * ny, 0.3 + 0.04 * nz)
+        general = case % 4 == 3
+        _, n = compare_box(O, ctx, cells, lo, hi, scenes.default_camera(), 72, 48,
+                           transform=ScalarTransform() if general else NORM,
+                           scalar_range=(-0.2, 1.3) if general else (0.0, 1.0),
+                           transparency=0.6, cells_view=(storage, sl))
+        total += n
+    assert total > 20000   # the boxes are in view: the classified cells were sampled
+
+
 @pytest.mark.parametrize("cam", [
     CameraParameters((0.5, 0.5, 0.5), (0.9, 0.6, 0.1), (0, 1, 0), 60.0),       # eye inside the box
     CameraParameters((0.5, 0.5, 3.0), (0.5, 0.5, 0.5), (0, 1, 0), 30.0),       # axis aligned (dir ~ 0)
