@@ -1,5 +1,7 @@
 #!/bin/bash
-# PMC counters of the march kernel for one simulated rank.  usage: share_pmc.sh <outdir> <rank_share args>
+# PMC counters of the march kernel for one simulated rank.
+# usage: share_pmc.sh <outdir> --worker <n_ranks> <rank> [rank_share args]   (the worker itself: under
+# rocprofv3 the process must not start children)
 set -u
 OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}

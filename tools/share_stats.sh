@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one simulated rank (tools/rank_share.py).  usage: share_stats.sh <outdir> <rank_share args>
+# rocprofv3 kernel stats of one simulated rank (tools/rank_share.py).
+# usage: share_stats.sh <outdir> --worker <n_ranks> <rank> [rank_share args]
 set -u
 OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
