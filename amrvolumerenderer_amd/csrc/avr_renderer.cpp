@@ -109,8 +109,9 @@ struct CoRunTuner {
   static constexpr int kReserveStep = 2048;    // candidate k >= 0: side by side, reserve k * step
   static constexpr int kLastCandidate = 28;    // 56 KiB: two classify workgroups per CU
   static constexpr int kCoarse = 2;            // the first pass takes every second reserve
-  static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate
-  static constexpr int kWindowFrames = 8;      // frames timed per candidate
+  static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate (at most)
+  static constexpr int kWindowFrames = 8;      // frames timed per candidate (at most)
+  static constexpr float kWindowMs = 10.0f;    // ... but no longer than this, two frames at least
   static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
   static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
 
@@ -128,6 +129,15 @@ struct CoRunTuner {
   // the window in progress
   int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
   bool open = false, closing = false;
+  int window_length = kWindowFrames;  // of the open / closing window
+  float last_period_ms = 0.0f;
+
+  // long frames (config-5: 35 ms) get short windows: the search should take seconds, not minutes
+  int frames_per_window() const {
+    if (last_period_ms <= 0.0f) return 4;
+    const int frames = static_cast<int>(std::ceil(kWindowMs / last_period_ms));
+    return std::min(std::max(frames, 2), kWindowFrames);
+  }
 
   void restrict_to(int first_candidate, int last_candidate) {
     if (first_candidate == first && last_candidate == last) return;
@@ -156,6 +166,7 @@ struct CoRunTuner {
   // one timed window of the current candidate
   void report(float period_ms) {
     ++windows;
+    last_period_ms = period_ms;
     static const bool trace = std::getenv("AVR_CORUN_TRACE") != nullptr;  // diagnostics
     if (trace) {
       std::fprintf(stderr, "corun: phase %d candidate %d period %.4f ms\n", static_cast<int>(phase),
@@ -752,19 +763,20 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
     abi_ok(avr_march_plan(r->march, r->scene, plan, volume, send, samples_out));
-    // the tuner's window: the period of kWindowFrames frames between two events after the march
+    // the tuner's window: the period of a few frames between two events after the march
     if (tuner.tuning()) {
       if (tuner.closing && hipEventQuery(r->window_end) == hipSuccess) {
         float elapsed_ms = 0.0f;
         hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end),
                "hipEventElapsedTime");
-        tuner.report(elapsed_ms / static_cast<float>(CoRunTuner::kWindowFrames));
+        tuner.report(elapsed_ms / static_cast<float>(tuner.window_length));
       } else if (tuner.closing) {
         (void)hipGetLastError();  // hipErrorNotReady is not an error here
       } else {
         ++tuner.frames_at_candidate;
-        const int start = (tuner.phase == CoRunTuner::kHold) ? CoRunTuner::kHoldFrames
-                                                             : CoRunTuner::kSettleFrames;
+        const int start = (tuner.phase == CoRunTuner::kHold)
+                              ? CoRunTuner::kHoldFrames
+                              : std::min(CoRunTuner::kSettleFrames, tuner.frames_per_window());
         if (!tuner.open && tuner.frames_at_candidate >= start) {
           if (r->window_begin == nullptr) {
             r->window_begin = make_event(true);
@@ -772,8 +784,9 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
           }
           hip_ok(hipEventRecord(r->window_begin, stream_m), "hipEventRecord");
           tuner.open = true;
+          tuner.window_length = tuner.frames_per_window();
         } else if (tuner.open &&
-                   tuner.frames_at_candidate >= start + CoRunTuner::kWindowFrames) {
+                   tuner.frames_at_candidate >= start + tuner.window_length) {
           hip_ok(hipEventRecord(r->window_end, stream_m), "hipEventRecord");
           tuner.open = false;
           tuner.closing = true;
