@@ -115,10 +115,11 @@ struct CoRunTuner {
   static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
   static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
 
-  // kSearch: back to back, then reserves 0, 4, 8 ... KiB; kRefine: the two reserves either side
-  // of the best one; kVerify: back to back and the best reserve once more; kHold: the winner.  (No early exit: over the reserve the
-  // period is flat, dips and rises again, and for the short kernels of an N-rank share the dip
-  // lies at the far end -- a search that stopped on the flat stretch missed it.)
+  // kSearch: (back to back, then) reserves 0, 4, 8 ... KiB; kRefine: the two reserves either
+  // side of the best one; kVerify: back to back and the best reserve once more; kHold: the
+  // winner.  (No early exit: over the reserve the period is flat, dips and rises again, and for
+  // the short kernels of an N-rank share the dip lies at the far end -- a search that stopped
+  // on the flat stretch missed it.)
   enum Phase { kSearch, kRefine, kVerify, kHold } phase = kSearch;
   int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
   int candidate = kBackToBack;
@@ -139,15 +140,23 @@ struct CoRunTuner {
     return std::min(std::max(frames, 2), kWindowFrames);
   }
 
-  void restrict_to(int first_candidate, int last_candidate) {
-    if (first_candidate == first && last_candidate == last) return;
+  // Where the search starts is what a caller keeps who never renders enough frames back to back
+  // for a window to complete (bursts of a few frames between synchronisations): side by side
+  // without a reserve for one rank (there back to back is 1.29 ms against 1.05), back to back
+  // for a rank of several (there the unreserved pair can be the worst choice).  Back to back
+  // is always re-timed at the end (kVerify).
+  bool start_beside = false;
+
+  void restrict_to(int first_candidate, int last_candidate, bool beside_first) {
+    if (first_candidate == first && last_candidate == last && beside_first == start_beside) return;
     first = first_candidate;
     last = last_candidate;
+    start_beside = beside_first;
     restart();
   }
   void restart() {
     phase = kSearch;
-    candidate = best = first;
+    candidate = best = (start_beside && last >= 0) ? 0 : first;
     best_beside = 0;
     best_ms = best_beside_ms = 0.0f;
     refined = 0;
@@ -701,7 +710,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
           last = (first == CoRunTuner::kBackToBack) ? 0 : first;
         }
       }
-      tuner.restrict_to(first, last);
+      tuner.restrict_to(first, last, r->n_ranks == 1);
     }
     const bool overlap = tuner.candidate != CoRunTuner::kBackToBack;
     const int reserve = !overlap ? 0
