@@ -366,8 +366,9 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
         const float w_ = (sample).w * (1.0f - ba.y);                              \
         const float_pair color_ = {(sample).x, (sample).y};                       \
         const float_pair zw_ = {(sample).z * w_, w_};                             \
-        rg = rg + color_ * w_;                                                    \
         ba = ba + zw_;                                                            \
+        rg = rg + color_ * w_;                                                    \
+        asm volatile("" : "+v"(rg));                                              \
       }
       AVR_STEP(s1)
       AVR_STEP(s2)
