@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libavr_hip.so")
-SOURCES = ["avr_kernels.hip", "avr_scene_stats.hip", "avr_overlay.hip", "avr_device.h", "avr_host.cpp", "avr_visibility.cpp", "avr_plan.cpp", "avr_plan.h", "avr_capi.cpp", "avr_comm.cpp", "avr_renderer.cpp",
+SOURCES = ["avr_kernels.hip", "avr_scene_stats.hip", "avr_overlay.hip", "avr_device.h", "avr_host.cpp", "avr_visibility.cpp", "avr_plan.cpp", "avr_plan.h", "avr_corun.h", "avr_capi.cpp", "avr_comm.cpp", "avr_renderer.cpp",
            "avr_internal.h", "Makefile"]
 
 

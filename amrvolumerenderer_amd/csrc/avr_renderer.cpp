@@ -33,6 +33,7 @@
 #include <string>
 #include <vector>
 
+#include "avr_corun.h"
 #include "avr_internal.h"
 #include "avr_plan.h"
 
@@ -92,153 +93,6 @@ struct FrameEvents {
 };
 
 }  // namespace
-
-// How the classify pass and the march of a rank share the GPU is MEASURED, not assumed.  Beside
-// the march the classify pass takes memory-system time from it in proportion to the bandwidth it
-// reaches -- whatever its arithmetic, occupancy or cache policy -- so the
-// frame is shortest where the two take equally long; how many classify workgroups a CU admits
-// (an LDS reserve per workgroup, avr_context_set_classify_lds_reserve) moves that balance, and
-// for the short kernels of an N-rank share running them back to back can win outright.  The
-// candidates are tried in turn on the running pipeline -- back to back, then side by side with a
-// reserve of 0, 2, 4 ... KiB -- each for a window of frames whose period is timed with two HIP
-// events on the march stream; the search stops three clearly worse steps past the best period and the driver
-// holds the best candidate, re-timing it now and then and searching again if it has drifted.
-// Scheduling only: never changes results.
-struct CoRunTuner {
-  static constexpr int kBackToBack = -1;       // candidate: both kernels on the march stream
-  static constexpr int kReserveStep = 2048;    // candidate k >= 0: side by side, reserve k * step
-  static constexpr int kLastCandidate = 28;    // 56 KiB: two classify workgroups per CU
-  static constexpr int kCoarse = 2;            // the first pass takes every second reserve
-  static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate (at most)
-  static constexpr int kWindowFrames = 8;      // frames timed per candidate (at most)
-  static constexpr float kWindowMs = 10.0f;    // ... but no longer than this, two frames at least
-  static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
-  static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
-
-  // kSearch: (back to back, then) reserves 0, 4, 8 ... KiB; kRefine: the two reserves either
-  // side of the best one; kVerify: back to back and the best reserve once more; kHold: the
-  // winner.  (No early exit: over the reserve the period is flat, dips and rises again, and for
-  // the short kernels of an N-rank share the dip lies at the far end -- a search that stopped
-  // on the flat stretch missed it.)
-  enum Phase { kSearch, kRefine, kVerify, kHold } phase = kSearch;
-  int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
-  int candidate = kBackToBack;
-  int best = kBackToBack, best_beside = 0;
-  float best_ms = 0.0f, best_beside_ms = 0.0f;
-  int refined = 0;
-  long windows = 0;
-  // the window in progress
-  int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
-  bool open = false, closing = false;
-  int window_length = kWindowFrames;  // of the open / closing window
-  float last_period_ms = 0.0f;
-
-  // long frames (config-5: 35 ms) get short windows: the search should take seconds, not minutes
-  int frames_per_window() const {
-    if (last_period_ms <= 0.0f) return 4;
-    const int frames = static_cast<int>(std::ceil(kWindowMs / last_period_ms));
-    return std::min(std::max(frames, 2), kWindowFrames);
-  }
-
-  // Where the search starts is what a caller keeps who never renders enough frames back to back
-  // for a window to complete (bursts of a few frames between synchronisations): side by side
-  // without a reserve for one rank (there back to back is 1.29 ms against 1.05), back to back
-  // for a rank of several (there the unreserved pair can be the worst choice).  Back to back
-  // is always re-timed at the end (kVerify).
-  bool start_beside = false;
-
-  void restrict_to(int first_candidate, int last_candidate, bool beside_first) {
-    if (first_candidate == first && last_candidate == last && beside_first == start_beside) return;
-    first = first_candidate;
-    last = last_candidate;
-    start_beside = beside_first;
-    restart();
-  }
-  void restart() {
-    phase = kSearch;
-    candidate = best = (start_beside && last >= 0) ? 0 : first;
-    best_beside = 0;
-    best_ms = best_beside_ms = 0.0f;
-    refined = 0;
-    interrupt();
-  }
-  void interrupt() {  // the pipeline drained or the candidate changed: the window is void
-    frames_at_candidate = 0;
-    open = closing = false;
-  }
-  void drained() {  // a window whose last frame was already queued stays valid
-    if (!closing) interrupt();
-  }
-  bool tuning() const { return first != last; }
-  bool settled() const { return !tuning() || phase == kHold; }
-
-  // one timed window of the current candidate
-  void report(float period_ms) {
-    ++windows;
-    last_period_ms = period_ms;
-    static const bool trace = std::getenv("AVR_CORUN_TRACE") != nullptr;  // diagnostics
-    if (trace) {
-      std::fprintf(stderr, "corun: phase %d candidate %d period %.4f ms\n", static_cast<int>(phase),
-                   candidate, period_ms);
-    }
-    if (phase == kHold) {
-      if (period_ms > best_ms * kDrift) {
-        restart();
-      } else {
-        best_ms = 0.75f * best_ms + 0.25f * period_ms;
-        interrupt();
-      }
-      return;
-    }
-    if (best_ms == 0.0f || period_ms < best_ms) {
-      best_ms = period_ms;
-      best = candidate;
-    }
-    if (candidate >= 0 && (best_beside_ms == 0.0f || period_ms < best_beside_ms)) {
-      best_beside_ms = period_ms;
-      best_beside = candidate;
-    }
-    if (phase == kSearch) {
-      const int next = (candidate < 0) ? 0 : candidate + kCoarse;
-      if (next <= last) {
-        candidate = next;
-      } else {
-        phase = kRefine;
-      }
-    }
-    if (phase == kRefine) {
-      // best_beside - 1, then best_beside + 1 (those inside the range; the centre may move once)
-      int next = -1;
-      while (refined < 2 && next < 0) {
-        const int probe = best_beside + (refined == 0 ? -1 : 1);
-        ++refined;
-        if (probe >= 0 && probe <= last && last > 0) next = probe;
-      }
-      if (next >= 0) {
-        candidate = next;
-      } else if (first == kBackToBack && last >= 0) {
-        // the two modes once more, now that the pipeline has run for a while (the very first
-        // windows after start-up have read up to 20 % fast): back to back, then the best reserve
-        phase = kVerify;
-        candidate = kBackToBack;
-        best_ms = 0.0f;
-        interrupt();
-        return;
-      } else {
-        phase = kHold;
-        candidate = best;
-      }
-    } else if (phase == kVerify) {
-      if (candidate == kBackToBack) {
-        candidate = best_beside;
-      } else {
-        phase = kHold;
-        candidate = best;  // of the two re-timed windows (best_ms was reset before them)
-      }
-    }
-    interrupt();
-  }
-};
 
 struct avr_renderer {
   int device = 0, rank = 0, n_ranks = 1;
@@ -774,31 +628,29 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     abi_ok(avr_march_plan(r->march, r->scene, plan, volume, send, samples_out));
     // the tuner's window: the period of a few frames between two events after the march
     if (tuner.tuning()) {
-      if (tuner.closing && hipEventQuery(r->window_end) == hipSuccess) {
-        float elapsed_ms = 0.0f;
-        hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end),
-               "hipEventElapsedTime");
-        tuner.report(elapsed_ms / static_cast<float>(tuner.window_length));
-      } else if (tuner.closing) {
-        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+      if (tuner.closing) {
+        if (hipEventQuery(r->window_end) == hipSuccess) {
+          float elapsed_ms = 0.0f;
+          hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end),
+                 "hipEventElapsedTime");
+          tuner.report(elapsed_ms / static_cast<float>(tuner.window_length));
+        } else {
+          (void)hipGetLastError();  // hipErrorNotReady is not an error here
+        }
       } else {
-        ++tuner.frames_at_candidate;
-        const int start = (tuner.phase == CoRunTuner::kHold)
-                              ? CoRunTuner::kHoldFrames
-                              : std::min(CoRunTuner::kSettleFrames, tuner.frames_per_window());
-        if (!tuner.open && tuner.frames_at_candidate >= start) {
-          if (r->window_begin == nullptr) {
-            r->window_begin = make_event(true);
-            r->window_end = make_event(true);
-          }
-          hip_ok(hipEventRecord(r->window_begin, stream_m), "hipEventRecord");
-          tuner.open = true;
-          tuner.window_length = tuner.frames_per_window();
-        } else if (tuner.open &&
-                   tuner.frames_at_candidate >= start + tuner.window_length) {
-          hip_ok(hipEventRecord(r->window_end, stream_m), "hipEventRecord");
-          tuner.open = false;
-          tuner.closing = true;
+        switch (tuner.frame()) {
+          case CoRunTuner::kOpenWindow:
+            if (r->window_begin == nullptr) {
+              r->window_begin = make_event(true);
+              r->window_end = make_event(true);
+            }
+            hip_ok(hipEventRecord(r->window_begin, stream_m), "hipEventRecord");
+            break;
+          case CoRunTuner::kCloseWindow:
+            hip_ok(hipEventRecord(r->window_end, stream_m), "hipEventRecord");
+            break;
+          case CoRunTuner::kNothing:
+            break;
         }
       }
     }

@@ -1,0 +1,159 @@
+// CPU check of the frame driver's co-run search (amrvolumerenderer_amd/csrc/avr_corun.h): the
+// decision logic is driven with synthetic frame periods -- a model GPU that answers every timed
+// window with the period of the candidate in use -- and must settle where that period is least.
+//   corun_test            runs all cases, prints "ok", exit code 0
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../amrvolumerenderer_amd/csrc/avr_corun.h"
+
+namespace {
+
+int failures = 0;
+void expect(bool ok, const std::string& what) {
+  if (!ok) {
+    std::fprintf(stderr, "FAILED: %s\n", what.c_str());
+    ++failures;
+  }
+}
+
+// period(candidate) in ms; candidate -1 = back to back, k >= 0 = side by side with k * 2 KiB
+using Model = std::function<float(int)>;
+
+struct Run {
+  int frames = 0;          // frames until the search settled (or the limit)
+  int candidate = 0;       // what it holds
+  long windows = 0;
+  std::vector<int> tried;  // candidates in the order their windows were reported
+};
+
+// Plays `limit` frames.  `lag` = frames between a window's end event being recorded and it
+// reading as complete (the host runs ahead of the GPU); drain_every > 0 synchronises that often.
+Run play(CoRunTuner& tuner, const Model& model, int limit, int lag = 2, int drain_every = 0,
+         bool stop_when_settled = true) {
+  Run run;
+  int ready_in = -1;
+  for (int frame = 1; frame <= limit; ++frame) {
+    if (drain_every > 0 && frame % drain_every == 0) {
+      tuner.drained();
+      if (tuner.closing) ready_in = 0;  // a drain completes the pending end event
+    }
+    if (tuner.tuning()) {
+      if (tuner.closing) {
+        if (ready_in <= 0) {
+          run.tried.push_back(tuner.candidate);
+          tuner.report(model(tuner.candidate));
+        } else {
+          --ready_in;
+        }
+      } else {
+        const CoRunTuner::Action action = tuner.frame();
+        if (action == CoRunTuner::kCloseWindow) ready_in = lag;
+      }
+    }
+    run.frames = frame;
+    if (stop_when_settled && tuner.settled()) break;
+  }
+  run.candidate = tuner.candidate;
+  run.windows = tuner.windows;
+  return run;
+}
+
+// the one-rank config-4 curve (ms): flat, a dip at 24-26 KiB, a cliff behind it; back to back 1.29
+float one_rank(int c) {
+  if (c < 0) return 1.29f;
+  const float kib = 2.0f * static_cast<float>(c);
+  if (kib <= 16.0f) return 1.055f;
+  if (kib <= 20.0f) return 1.03f;
+  if (kib <= 23.0f) return 1.014f;
+  if (kib <= 26.0f) return 1.000f;
+  return 1.05f + 0.01f * (kib - 28.0f);
+}
+
+// a rank of eight: back to back beats the whole first stretch of reserves, the dip lies far out
+float eighth(int c) {
+  if (c < 0) return 0.223f;
+  const float kib = 2.0f * static_cast<float>(c);
+  if (kib <= 12.0f) return 0.27f - 0.002f * kib;
+  if (kib <= 44.0f) return 0.246f - (kib - 12.0f) * 0.0023f;
+  return 0.172f + (kib - 44.0f) * 0.004f;
+}
+
+}  // namespace
+
+int main() {
+  {  // one rank: starts side by side, never tries back to back before the end, finds the dip
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, /*beside_first=*/true);
+    expect(t.candidate == 0, "one rank starts side by side without a reserve");
+    const Run run = play(t, one_rank, 2000);
+    expect(t.settled(), "one rank settles");
+    expect(run.candidate == 12 || run.candidate == 13, "one rank holds 24-26 KiB, got " +
+                                                            std::to_string(run.candidate));
+    expect(run.frames < 320, "one rank settles within 320 frames, took " + std::to_string(run.frames));
+    expect(run.tried.front() == 0 && run.tried[run.tried.size() - 2] == CoRunTuner::kBackToBack,
+           "back to back is timed once, second to last");
+  }
+  {  // a rank of eight: starts back to back, still finds the far dip
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, false);
+    expect(t.candidate == CoRunTuner::kBackToBack, "a rank of several starts back to back");
+    const Run run = play(t, eighth, 2000);
+    expect(run.candidate >= 21 && run.candidate <= 23, "the far dip is found, got " +
+                                                           std::to_string(run.candidate));
+  }
+  {  // back to back wins when side by side is never better (streams sharing a hardware queue)
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, false);
+    const Run run = play(t, [](int c) { return c < 0 ? 0.23f : 0.25f + 0.001f * c; }, 2000);
+    expect(run.candidate == CoRunTuner::kBackToBack, "back to back is kept when it is fastest");
+  }
+  {  // the caller fixed the mode: nothing to tune
+    CoRunTuner t;
+    t.restrict_to(0, 0, true);
+    expect(!t.tuning() && t.settled() && t.candidate == 0, "a fixed choice is not searched");
+    const Run run = play(t, one_rank, 50, 2, 0, false);
+    expect(run.windows == 0, "no windows without a choice");
+  }
+  {  // the caller fixed the reserve: back to back against that one reserve
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, 0, true);
+    const Run run = play(t, one_rank, 500);
+    expect(t.settled() && run.candidate == 0 && run.windows == 3,
+           "fixed reserve: three windows (beside, back to back, beside), got " +
+               std::to_string(run.windows));
+  }
+  {  // bursts too short for a window (a drain every 5 frames): the start candidate is kept
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    const Run run = play(t, one_rank, 600, 2, 5, false);
+    expect(run.windows == 0 && run.candidate == 0 && !t.settled(),
+           "short bursts never complete a window");
+  }
+  {  // drains now and then (every 64 frames) do not stop the search
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    const Run run = play(t, one_rank, 3000, 2, 64);
+    expect(t.settled() && (run.candidate == 12 || run.candidate == 13),
+           "search completes across occasional drains");
+  }
+  {  // long frames get short windows; the held candidate is re-timed and a drift restarts
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    Run run = play(t, [](int c) { return 35.0f * one_rank(c); }, 5000);
+    expect(t.settled() && run.frames < 160, "35 ms frames settle within 160 frames, took " +
+                                                std::to_string(run.frames));
+    const int held = run.candidate;
+    run = play(t, [](int c) { return 35.0f * one_rank(c); }, 2 * CoRunTuner::kHoldFrames + 40, 2, 0,
+               false);
+    expect(t.phase == CoRunTuner::kHold && t.candidate == held, "a steady period is held");
+    run = play(t, [](int c) { return 50.0f * one_rank(c); }, CoRunTuner::kHoldFrames + 40, 2, 0, false);
+    expect(t.phase != CoRunTuner::kHold || t.windows > run.windows,
+           "a period that drifted by more than 10 % starts a new search");
+  }
+  if (failures == 0) std::printf("ok\n");
+  return failures == 0 ? 0 : 1;
+}
