@@ -38,8 +38,9 @@ struct CoRunTuner {
   enum Phase { kSearch, kRefine, kVerify, kHold } phase = kSearch;
   int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
   int candidate = kBackToBack;
-  int best = kBackToBack, best_beside = 0;
-  float best_ms = 0.0f, best_beside_ms = 0.0f;
+  int best = kBackToBack, best_beside = 0, second_beside = -1;
+  float best_ms = 0.0f, best_beside_ms = 0.0f, second_beside_ms = 0.0f;
+  int verify[3] = {0, 0, 0}, n_verify = 0, verify_at = 0;  // kVerify: candidates re-timed in turn
   int refined = 0;
   long windows = 0;
   // the window in progress
@@ -73,7 +74,9 @@ struct CoRunTuner {
     phase = kSearch;
     candidate = best = (start_beside && last >= 0) ? 0 : first;
     best_beside = 0;
-    best_ms = best_beside_ms = 0.0f;
+    second_beside = -1;
+    best_ms = best_beside_ms = second_beside_ms = 0.0f;
+    n_verify = verify_at = 0;
     refined = 0;
     interrupt();
   }
@@ -128,9 +131,18 @@ struct CoRunTuner {
       best_ms = period_ms;
       best = candidate;
     }
-    if (candidate >= 0 && (best_beside_ms == 0.0f || period_ms < best_beside_ms)) {
-      best_beside_ms = period_ms;
-      best_beside = candidate;
+    if (phase != kVerify && candidate >= 0) {  // the two best reserves of the search
+      if (best_beside_ms == 0.0f || period_ms < best_beside_ms) {
+        if (best_beside_ms != 0.0f) {
+          second_beside = best_beside;
+          second_beside_ms = best_beside_ms;
+        }
+        best_beside_ms = period_ms;
+        best_beside = candidate;
+      } else if (second_beside < 0 || period_ms < second_beside_ms) {
+        second_beside = candidate;
+        second_beside_ms = period_ms;
+      }
     }
     if (phase == kSearch) {
       const int next = (candidate < 0) ? 0 : candidate + kCoarse;
@@ -150,24 +162,30 @@ struct CoRunTuner {
       }
       if (next >= 0) {
         candidate = next;
-      } else if (first == kBackToBack && last >= 0) {
-        // the two modes once more, now that the pipeline has run for a while (the very first
-        // windows after start-up have read up to 20 % fast): back to back, then the best reserve
-        phase = kVerify;
-        candidate = kBackToBack;
-        best_ms = 0.0f;
-        interrupt();
-        return;
       } else {
-        phase = kHold;
-        candidate = best;
+        // The finalists once more, now that the pipeline has run for a while (the very first
+        // windows after start-up have read up to 20 % fast) and so that one lucky window does
+        // not decide (the reserve just past the dip sits on a cliff): back to back if allowed,
+        // the best reserve and the runner-up; the best of THESE windows is held.
+        n_verify = verify_at = 0;
+        if (first == kBackToBack) verify[n_verify++] = kBackToBack;
+        if (last >= 0) verify[n_verify++] = best_beside;
+        if (last > 0 && second_beside >= 0) verify[n_verify++] = second_beside;
+        if (n_verify >= 2) {
+          phase = kVerify;
+          candidate = verify[0];
+          best_ms = 0.0f;
+        } else {
+          phase = kHold;
+          candidate = best;
+        }
       }
     } else if (phase == kVerify) {
-      if (candidate == kBackToBack) {
-        candidate = best_beside;
+      if (++verify_at < n_verify) {
+        candidate = verify[verify_at];
       } else {
         phase = kHold;
-        candidate = best;  // of the two re-timed windows (best_ms was reset before them)
+        candidate = best;  // of the re-timed windows (best_ms was reset before them)
       }
     }
     interrupt();
