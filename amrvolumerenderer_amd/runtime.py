@@ -603,7 +603,7 @@ class Comm:
 
 
 class NativeRenderer:
-    """avr_renderer: the C++ frame driver of one rank (three HIP streams, double-buffered
+    """avr_renderer: the C++ frame driver of one rank (three HIP streams, rotating
     classified volumes and send layouts, RCCL exchange and gather).  Python only hands over the
     scene once and, per frame, the camera, the parameters and the output tensors."""
 

@@ -120,11 +120,11 @@ int avr_context_set_stream(avr_context *ctx, void *hip_stream);
 int avr_context_synchronize(avr_context *ctx);
 
 /* Resident march workgroups per CU for the launches of this context: 0 (default) = as many as
- * fit (8), 1..7 = capped (the launch reserves 160 KiB / n of LDS per workgroup).  A pipelined
- * renderer that classifies the next frame on another stream while this context marches sets 5:
- * the march is VALU-bound and the classify pass HBM-bound, and only when the march leaves wave
- * slots and LDS free do the two kernels really share a CU ("Three streams").  Never
- * changes results. */
+ * fit (7 by the kernel's registers), 1..7 = capped (the launch reserves 160 KiB / n of LDS per
+ * workgroup).  Round 1's frame driver capped its 8-per-CU march at 5 to leave room for the
+ * classify pass of the next frame; the present driver leaves the march uncapped and holds the
+ * classify pass back instead (avr_context_set_classify_lds_reserve; DESIGN.md section 3, "What
+ * the two kernels compete for").  Never changes results. */
 int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
 
 /* LDS (bytes, 0 = none) each classify workgroup of this context's launches claims beyond the
