@@ -147,6 +147,7 @@ SIGNATURES = {
     "avr_frame_plan_splits": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "avr_frame_plan_layers": (C.c_int, [_vp, _ip]),
     "avr_frame_plan_runs": (C.c_int, [_vp, C.POINTER(RunInfo)]),
+    "avr_frame_plan_tighten": (C.c_int, [_vp, C.POINTER(Box), C.c_int]),
     "avr_frame_plan_send_block": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_i64), _ip, _ip]),
     "avr_frame_plan_recv_block": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), _ip, _ip]),
     "avr_render_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -202,6 +203,7 @@ SIGNATURES = {
     "avr_renderer_set_scalar_range": (C.c_int, [_vp, _fp]),
     "avr_renderer_invalidate": (C.c_int, [_vp]),
     "avr_renderer_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_tighten": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_classify_share": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_corun_state": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.c_int), C.POINTER(C.c_long)]),

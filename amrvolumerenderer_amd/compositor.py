@@ -58,14 +58,28 @@ class FramePlan:
         self.recv_floats = info.recv_floats
         self.width = int(params.width)
         self.height = int(params.height)
+        self._read_splits()
+        order = list(group_order) if group_order is not None else list(range(self.n_ranks))
+        self.group_order = [int(g) for g in order]
+        self.piece_of_rank = [self.group_order.index(r) for r in range(self.n_ranks)]
+
+    def _read_splits(self) -> None:
         send = (C.c_int64 * self.n_ranks)()
         recv = (C.c_int64 * self.n_ranks)()
         _capi.check(_capi.lib().avr_frame_plan_splits(self._handle, send, recv))
         self.send_splits = [int(v) for v in send]
         self.recv_splits = [int(v) for v in recv]
-        order = list(group_order) if group_order is not None else list(range(self.n_ranks))
-        self.group_order = [int(g) for g in order]
-        self.piece_of_rank = [self.group_order.index(r) for r in range(self.n_ranks)]
+
+    def tighten(self) -> None:
+        """avr_frame_plan_tighten: per-row extents instead of the runs' rectangles (every rank of
+        the frame, or none); send_floats / recv_floats and the splits shrink."""
+        _capi.check(_capi.lib().avr_frame_plan_tighten(self._handle, self._boxes,
+                                                       len(self._boxes)))
+        info = _capi.FramePlanInfo()
+        _capi.check(_capi.lib().avr_frame_plan_get_info(self._handle, C.byref(info)))
+        self.send_floats = info.send_floats
+        self.recv_floats = info.recv_floats
+        self._read_splits()
 
     def close(self) -> None:
         if getattr(self, "_handle", None):

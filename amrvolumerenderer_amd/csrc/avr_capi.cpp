@@ -277,7 +277,8 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const avr_camera& camera, const int32_t* box_order, int n_order,
            const int32_t* run_end, int n_runs, int n_pieces,
            const std::vector<avr::RunRectDev>& run_rects,
-           const std::vector<avr::RunBlockDev>& run_blocks, avr_scene* scene, int slot,
+           const std::vector<avr::RunBlockDev>& run_blocks,
+           const std::vector<avr::RunSpanDev>* run_spans, avr_scene* scene, int slot,
            float* out_layers, uint64_t* samples_out, avr::FramePlan* cached) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
   require(slot >= 0 && slot < AVR_CLASSIFIED_SLOTS, "classified slot out of range");
@@ -352,10 +353,11 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     avr::build_march_items(plan, box_order, run_end, n_runs, run_rects, &items);
     bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
              items.size() * sizeof(avr::MarchItemDev) +
-             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev);
+             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev) +
+             (run_spans != nullptr ? run_spans->size() * sizeof(avr::RunSpanDev) : 0);
   }
   avr::StagingRing& staging = ctx->staging;
-  staging.begin(bytes, 8);
+  staging.begin(bytes, 9);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
   if (phases & kClassify) {
     launch.tile_begin_dev =
@@ -371,6 +373,9 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.n_pieces = n_pieces;
     launch.run_rects_dev = staging.add(run_rects.data(), run_rects.size());
     launch.run_blocks_dev = staging.add(run_blocks.data(), run_blocks.size());
+    launch.run_spans_dev = (run_spans != nullptr && !run_spans->empty())
+                               ? staging.add(run_spans->data(), run_spans->size())
+                               : nullptr;
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
     launch.counters = reinterpret_cast<unsigned long long*>(ctx->march_counters);
@@ -590,7 +595,8 @@ int avr_paint_box(avr_context* ctx, const avr_box* box, const avr_scalar_transfo
     require(params->width > 0 && params->height > 0, "image width and height must be positive");
     avr::dense_run_tables(params->width, params->height, 1, 1, &rects, &blocks);
     return render(ctx, kClassify | kMarch, box, 1, *transform, *params, *camera, order, 1, run_end,
-                  1, 1, rects, blocks, &ctx->scratch_scene, 0, out_rgbad, samples_out, nullptr);
+                  1, 1, rects, blocks, nullptr, &ctx->scratch_scene, 0, out_rgbad, samples_out,
+                  nullptr);
   });
 }
 
@@ -624,7 +630,7 @@ int avr_render_runs(avr_context* ctx, const avr_scene* scene, const avr_paint_pa
     avr::dense_run_tables(params->width, params->height, n_runs, n_pieces, &rects, &blocks);
     return render(ctx, kClassify | kMarch, scene->boxes.data(),
                   static_cast<int>(scene->boxes.size()), scene->transform, *params, *camera,
-                  box_order, n_order, run_end, n_runs, n_pieces, rects, blocks,
+                  box_order, n_order, run_end, n_runs, n_pieces, rects, blocks, nullptr,
                   const_cast<avr_scene*>(scene), 0, out_layers, samples_out, nullptr);
   });
 }
@@ -750,6 +756,15 @@ int avr_frame_plan_runs(const avr_frame_plan* plan, avr_run_info* runs) {
   });
 }
 
+int avr_frame_plan_tighten(avr_frame_plan* plan, const avr_box* all_boxes, int n_boxes) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && n_boxes >= 0 && (n_boxes == 0 || all_boxes != nullptr),
+            "invalid argument");
+    avr::tighten_frame_plan(all_boxes, n_boxes, plan);
+    return AVR_OK;
+  });
+}
+
 int avr_frame_plan_send_block(const avr_frame_plan* plan, int peer, int local_run, int64_t* offset,
                               int32_t* first_row, int32_t* n_rows) {
   return guarded([&]() -> int {
@@ -758,6 +773,7 @@ int avr_frame_plan_send_block(const avr_frame_plan* plan, int peer, int local_ru
     require(peer >= 0 && peer < plan->info.n_ranks && local_run >= 0 &&
                 local_run < plan->info.n_local_runs,
             "block index out of range");
+    require(!plan->tightened, "a tightened plan has no rectangular blocks");
     const size_t at = static_cast<size_t>(local_run) * plan->info.n_ranks +
                       static_cast<size_t>(plan->piece_of_rank[static_cast<size_t>(peer)]);
     *n_rows = plan->send_block_rows[at];
@@ -773,6 +789,7 @@ int avr_frame_plan_recv_block(const avr_frame_plan* plan, int global_run, int64_
     require(plan != nullptr && offset != nullptr && first_row != nullptr && n_rows != nullptr,
             "null argument");
     require(global_run >= 0 && global_run < plan->info.n_runs_total, "run index out of range");
+    require(!plan->tightened, "a tightened plan has no rectangular blocks");
     const size_t at = static_cast<size_t>(global_run);
     *n_rows = plan->recv_block_rows[at];
     *first_row = plan->recv_blocks[at].first_row;
@@ -794,7 +811,8 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                   scene->transform, plan->params, plan->camera, plan->local_order.data(),
                   static_cast<int>(plan->local_order.size()), plan->local_run_end.data(),
                   plan->info.n_local_runs, plan->info.n_ranks, plan->local_rects, plan->send_blocks,
-                  const_cast<avr_scene*>(scene), slot, send_buffer, samples_out,
+                  plan->tightened ? &plan->send_spans : nullptr, const_cast<avr_scene*>(scene), slot,
+                  send_buffer, samples_out,
                   &const_cast<avr_frame_plan*>(plan)->prologue);
   });
 }
@@ -840,10 +858,14 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
     avr::FoldLaunch launch;
     ctx->staging.begin(plan->global_rects.size() * sizeof(avr::RunRectDev) +
-                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev),
-                       2);
+                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev) +
+                           plan->recv_spans.size() * sizeof(avr::RunSpanDev),
+                       3);
     launch.run_rects_dev = ctx->staging.add(plan->global_rects.data(), plan->global_rects.size());
     launch.run_blocks_dev = ctx->staging.add(plan->recv_blocks.data(), plan->recv_blocks.size());
+    launch.run_spans_dev = (plan->tightened && !plan->recv_spans.empty())
+                               ? ctx->staging.add(plan->recv_spans.data(), plan->recv_spans.size())
+                               : nullptr;
     ctx->staging.commit(ctx->stream);
     launch.width = plan->params.width;
     launch.piece_begin = plan->info.piece_begin;

@@ -376,6 +376,78 @@ void screen_rect(const avr_box& box, const avr_camera& camera, const CameraBasis
 
 }  // namespace
 
+// Conservative per-row extent of a box on screen: rows rect[1]..rect[3] of its conservative
+// rectangle (box_screen_rect), for each the pixel columns its projection can touch.  The
+// projection of a box in front of the eye lies inside the convex hull of its projected corners;
+// per row the hull's x-extent over the band of that row (+- the same 2-pixel margin as the
+// rectangle) is taken from the 28 corner-to-corner segments, which contain the hull's edges.
+// A box that reaches behind the eye keeps its whole rectangle on every row.
+void box_row_spans(const avr_box& box, const avr_camera& camera, int width, int height,
+                   const int32_t rect[4], std::vector<int32_t>* row_x0,
+                   std::vector<int32_t>* row_x1) {
+  row_x0->clear();
+  row_x1->clear();
+  if (rect[2] < rect[0] || rect[3] < rect[1]) return;
+  const int rows = rect[3] - rect[1] + 1;
+  row_x0->assign(static_cast<size_t>(rows), rect[0]);
+  row_x1->assign(static_cast<size_t>(rows), rect[2]);
+  const CameraBasis basis = camera_basis(camera);
+  const Vec3d eye = from(camera.eye);
+  // (the float tangent and aspect the kernel's ray set-up and screen_rect use)
+  const double tan_y = static_cast<double>(std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f));
+  const double aspect = static_cast<double>(static_cast<float>(width) /
+                                            static_cast<float>(std::max(height, 1)));
+  const double tan_x = tan_y * aspect;
+  double px[8], py[8];
+  for (int corner = 0; corner < 8; ++corner) {
+    const Vec3d p{
+        static_cast<double>(static_cast<float>((corner & 1) ? box.max_corner[0] : box.min_corner[0])),
+        static_cast<double>(static_cast<float>((corner & 2) ? box.max_corner[1] : box.min_corner[1])),
+        static_cast<double>(static_cast<float>((corner & 4) ? box.max_corner[2] : box.min_corner[2]))};
+    const Vec3d v = sub(p, eye);
+    const double depth = dot(v, basis.forward);
+    if (!(depth > 1e-6) || !std::isfinite(depth)) return;  // whole rectangle
+    px[corner] = (dot(v, basis.right) / (depth * tan_x) + 1.0) * 0.5 * width - 0.5;
+    py[corner] = (dot(v, basis.up) / (depth * tan_y) + 1.0) * 0.5 * height - 0.5;
+    if (!std::isfinite(px[corner]) || !std::isfinite(py[corner])) return;
+  }
+  constexpr double margin = 2.0;  // as screen_rect
+  for (int r = 0; r < rows; ++r) {
+    const double band_lo = static_cast<double>(rect[1] + r) - 0.5 - margin;
+    const double band_hi = static_cast<double>(rect[1] + r) + 0.5 + margin;
+    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+    for (int a = 0; a < 8; ++a) {
+      for (int b = a; b < 8; ++b) {
+        // the part of segment a-b inside the band (a == b: the corner itself)
+        double ya = py[a], yb = py[b], xa = px[a], xb = px[b];
+        if (ya > yb) {
+          std::swap(ya, yb);
+          std::swap(xa, xb);
+        }
+        if (yb < band_lo || ya > band_hi) continue;
+        double x_first = xa, x_last = xb;
+        if (yb > ya) {
+          const double slope = (xb - xa) / (yb - ya);
+          if (ya < band_lo) x_first = xa + (band_lo - ya) * slope;
+          if (yb > band_hi) x_last = xa + (band_hi - ya) * slope;
+        }
+        lo = std::min(lo, std::min(x_first, x_last));
+        hi = std::max(hi, std::max(x_first, x_last));
+      }
+    }
+    if (!(hi >= lo)) {  // the hull misses the band: nothing of this box on the row
+      (*row_x0)[static_cast<size_t>(r)] = 0;
+      (*row_x1)[static_cast<size_t>(r)] = -1;
+      continue;
+    }
+    const double x0 = std::floor(lo - margin), x1 = std::ceil(hi + margin);
+    const int32_t c0 = static_cast<int32_t>(std::max(x0, static_cast<double>(rect[0])));
+    const int32_t c1 = static_cast<int32_t>(std::min(x1, static_cast<double>(rect[2])));
+    (*row_x0)[static_cast<size_t>(r)] = c0;
+    (*row_x1)[static_cast<size_t>(r)] = c1;  // c1 < c0: nothing on the row
+  }
+}
+
 void box_screen_rect(const avr_box& box, const avr_camera& camera, int width, int height,
                      int32_t rect[4]) {
   FrameConsts fc;

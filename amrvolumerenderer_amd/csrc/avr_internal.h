@@ -75,7 +75,15 @@ struct RunRectDev {
 struct RunBlockDev {
   int64_t offset;     // float offset of the block in the send / recv buffer (unused if empty)
   int32_t first_row;  // image row stored in the block's first row
-  int32_t pad_;
+  int32_t span_base;  // < 0: every row holds the run rectangle's x0..x1; else the block's rows are
+                      // entries span_base + (row - first_row) of the span table
+};
+// One row of a block of a tightened frame plan (avr_frame_plan_tighten): only the pixels
+// x0..x1 of the row are stored, starting at float `offset` of the send / recv buffer; the others
+// are known to be empty (conservative per-row extent of the run's boxes on screen).
+struct RunSpanDev {
+  int32_t x0, x1;  // inclusive; x1 < x0 = nothing stored for this row
+  int64_t offset;
 };
 
 // Host results for one frame over a list of boxes.
@@ -124,6 +132,10 @@ int layer_order(const float* hints, const int32_t* owner, const int32_t* local_i
 // Conservative screen rectangle of a box (x0,y0,x1,y1 inclusive; x1 < x0 = off-screen).
 void box_screen_rect(const avr_box& box, const avr_camera& camera, int width, int height,
                      int32_t rect[4]);
+// Per-row extent inside that rectangle (rows rect[1]..rect[3]; x1 < x0 = nothing on the row).
+void box_row_spans(const avr_box& box, const avr_camera& camera, int width, int height,
+                   const int32_t rect[4], std::vector<int32_t>* row_x0,
+                   std::vector<int32_t>* row_x1);
 // Fills plan for the given boxes; throws std::invalid_argument / std::runtime_error.
 void plan_frame(const avr_box* boxes, int n_boxes, const avr_scalar_transform& transform,
                 const avr_paint_params& params, const avr_camera& camera, FramePlan* plan);
@@ -139,6 +151,7 @@ struct RenderLaunch {
   int n_order, n_runs, n_pieces;
   const RunRectDev* run_rects_dev;    // n_runs
   const RunBlockDev* run_blocks_dev;  // n_runs x n_pieces
+  const RunSpanDev* run_spans_dev;    // rows of the blocks with span_base >= 0 (may be null)
   float* out_layers;
   unsigned long long* samples_out;  // may be null
   unsigned long long* counters;     // diagnostics (4 x uint64), only read when samples_out is set
@@ -171,6 +184,7 @@ struct FoldLaunch {
   int n_runs;                          // global runs, in order
   const RunRectDev* run_rects_dev;     // n_runs
   const RunBlockDev* run_blocks_dev;   // n_runs: block of this rank's piece in the recv buffer
+  const RunSpanDev* run_spans_dev;     // rows of the blocks with span_base >= 0 (may be null)
   const float* recv;
   float* out_piece;
   uint8_t* out_rgb8;                   // may be null

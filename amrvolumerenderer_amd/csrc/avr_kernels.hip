@@ -479,7 +479,8 @@ render_runs_kernel(
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
     const int n_runs, const int n_pieces, const RunRectDev* __restrict__ run_rects,
-    const RunBlockDev* __restrict__ run_blocks, const int tiles_x, const int tiles_y,
+    const RunBlockDev* __restrict__ run_blocks, const RunSpanDev* __restrict__ run_spans,
+    const int tiles_x, const int tiles_y,
     const MarchItemDev* __restrict__ items, float* __restrict__ out,
     unsigned long long* samples_out, unsigned long long* counters) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
@@ -603,14 +604,29 @@ render_runs_kernel(
       int64_t piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
       if (piece > n_pieces - 1) piece = n_pieces - 1;
       const RunBlockDev block = run_blocks[static_cast<int64_t>(run) * n_pieces + piece];
-      float* dst = out + block.offset +
-                   (static_cast<int64_t>(py - block.first_row) * (rect.x1 - rect.x0 + 1) +
-                    (px - rect.x0)) * 5;
-      dst[0] = acc.r;
-      dst[1] = acc.g;
-      dst[2] = acc.b;
-      dst[3] = acc.a;
-      dst[4] = acc.d;
+      float* dst;
+      if (block.span_base >= 0) {
+        // tightened plan: the row stores only the run's conservative extent on screen; a pixel
+        // outside it is empty by construction (counted, should the construction ever be wrong)
+        const RunSpanDev span = run_spans[block.span_base + (py - block.first_row)];
+        if (px < span.x0 || px > span.x1) {
+          if (STATS && counters != nullptr && acc.a != 0.0f) atomicAdd(counters + 4, 1ull);
+          dst = nullptr;
+        } else {
+          dst = out + span.offset + static_cast<int64_t>(px - span.x0) * 5;
+        }
+      } else {
+        dst = out + block.offset +
+              (static_cast<int64_t>(py - block.first_row) * (rect.x1 - rect.x0 + 1) +
+               (px - rect.x0)) * 5;
+      }
+      if (dst != nullptr) {
+        dst[0] = acc.r;
+        dst[1] = acc.g;
+        dst[2] = acc.b;
+        dst[3] = acc.a;
+        dst[4] = acc.d;
+      }
     }
   }
 
@@ -1002,7 +1018,8 @@ struct FoldEntry {
 __global__ __launch_bounds__(256) void fold_plan_kernel(
     const int width, const int64_t piece_begin, const int64_t piece_end, const int n_runs,
     const RunRectDev* __restrict__ rects, const RunBlockDev* __restrict__ blocks,
-    const float* __restrict__ recv, float* __restrict__ out_piece,
+    const RunSpanDev* __restrict__ spans, const float* __restrict__ recv,
+    float* __restrict__ out_piece,
     uint8_t* __restrict__ out_rgb8, const int first_row, const int chunks_per_row) {
   __shared__ FoldEntry list[256];
   __shared__ int wave_count[4];
@@ -1026,10 +1043,18 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
       touches = rect.x0 <= seg_x1 && rect.x1 >= seg_x0 && rect.y0 <= row && rect.y1 >= row;
       if (touches) {
         const RunBlockDev block = blocks[g];
-        entry.x0 = rect.x0;
-        entry.x1 = rect.x1;
-        entry.base = block.offset + (static_cast<int64_t>(row - block.first_row) *
-                                         (rect.x1 - rect.x0 + 1) - rect.x0) * 5;
+        if (block.span_base >= 0) {  // tightened plan: this row's stored extent
+          const RunSpanDev span = spans[block.span_base + (row - block.first_row)];
+          touches = span.x0 <= seg_x1 && span.x1 >= seg_x0;
+          entry.x0 = span.x0;
+          entry.x1 = span.x1;
+          entry.base = span.offset - static_cast<int64_t>(span.x0) * 5;
+        } else {
+          entry.x0 = rect.x0;
+          entry.x1 = rect.x1;
+          entry.base = block.offset + (static_cast<int64_t>(row - block.first_row) *
+                                           (rect.x1 - rect.x0 + 1) - rect.x0) * 5;
+        }
       }
     }
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(touches);
@@ -1197,7 +1222,8 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
   hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \
                      lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,      \
                      L.n_tables, L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces,              \
-                     L.run_rects_dev, L.run_blocks_dev, tiles_x, tiles_y, L.items_dev,           \
+                     L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, tiles_x, tiles_y,       \
+                     L.items_dev,                                                                \
                      L.out_layers, L.samples_out, L.counters)
   if (L.only_mode == kPow2Multiply) {
     if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
@@ -1280,7 +1306,8 @@ int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
   }
   hipLaunchKernelGGL(fold_plan_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                      static_cast<hipStream_t>(stream_v), L.width, L.piece_begin, L.piece_end,
-                     L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.recv, L.out_piece, L.out_rgb8,
+                     L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, L.recv,
+                     L.out_piece, L.out_rgb8,
                      first_row, chunks_per_row);
   return check_launch("fold_plan_kernel");
 }

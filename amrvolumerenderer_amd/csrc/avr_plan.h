@@ -27,6 +27,10 @@ struct avr_frame_plan {
   std::vector<avr::RunRectDev> global_rects;
   std::vector<avr::RunBlockDev> recv_blocks;
   std::vector<int32_t> recv_block_rows;
+  // tightened layout (avr_frame_plan_tighten): the rows of the blocks above, sender and receiver
+  std::vector<avr::RunSpanDev> send_spans, recv_spans;
+  bool tightened = false;
+  bool from_boxes = false;  // built by build_frame_plan (layers = boxes): may be tightened
   // host prologue of this frame's local boxes, filled by the first device call that needs it
   // (avr_classify_plan) and re-used by the next (avr_march_plan)
   avr::FramePlan prologue;
@@ -44,6 +48,10 @@ void dense_run_tables(int width, int height, int n_runs, int n_pieces,
 void build_layer_plan(int n_layers, const float* hints, const int32_t* owner,
                       const int32_t (*rects)[4], int n_ranks, int rank, const int32_t* group_order,
                       int width, int height, avr_frame_plan* plan);
+
+// Replaces the rectangular blocks of a frame plan by per-row spans (conservative extent of each
+// run's boxes on screen) and recomputes the exchange layout; every rank must do the same.
+void tighten_frame_plan(const avr_box* all_boxes, int n_boxes, avr_frame_plan* plan);
 
 void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
                       int rank, const int32_t* group_order, const avr_paint_params& params,

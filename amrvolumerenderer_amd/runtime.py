@@ -216,12 +216,12 @@ class Context:
                                                                 int(workgroups_per_cu)))
 
     def set_march_counters(self, counters: Optional[torch.Tensor]) -> None:
-        """avr_context_set_march_counters: diagnostics for the parity tests (4 x int64 on the
+        """avr_context_set_march_counters: diagnostics for the parity tests (5 x int64 on the
         device, or None to switch them off)."""
         if counters is not None:
             self._check_tensor(counters, torch.int64, "counters")
-            if counters.numel() < 4:
-                raise ValueError("counters needs 4 entries")
+            if counters.numel() < 5:
+                raise ValueError("counters needs 5 entries")
         self._march_counters = counters  # keep alive while set
         _capi.check(_capi.lib().avr_context_set_march_counters(
             self._handle, C.c_void_p(counters.data_ptr()) if counters is not None else None))
@@ -660,6 +660,10 @@ class NativeRenderer:
     def set_overlap(self, overlap_classify: int) -> None:
         """avr_renderer_set_overlap (-1 default, 0 back to back, 1 classify beside the march)."""
         _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
+
+    def set_tighten(self, enabled: bool = True) -> None:
+        """avr_renderer_set_tighten: per-row exchange layout from a camera's second frame on."""
+        _capi.check(_capi.lib().avr_renderer_set_tighten(self._handle, int(bool(enabled))))
 
     def set_classify_share(self, lds_reserve_bytes: int = -1) -> None:
         """avr_renderer_set_classify_share: -1 = measured by the driver (default), >= 0 = fixed

@@ -414,6 +414,7 @@ def main():
     renderer.synchronize()
     my_samples = int(samples_dev.item())
     n_pixels = params.width * params.height
+    send_floats = renderer.last_plan.send_floats   # (N > 1: the tightened layout by now)
     algo_bytes = 8.0 * my_samples + 4.0 * send_floats
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_source = profiled_traffic(args, world)

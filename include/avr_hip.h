@@ -136,13 +136,15 @@ int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
 #define AVR_CLASSIFY_LDS_RESERVE_MAX 61440
 int avr_context_set_classify_lds_reserve(avr_context *ctx, int bytes);
 
-/* Diagnostics for the parity tests: while set (device pointer to 4 x uint64; NULL = off), every
+/* Diagnostics for the parity tests: while set (device pointer to 5 x uint64; NULL = off), every
  * march launched with a samples_out counter also ADDS
  *   counters[0]  samples whose cell index took the exact IEEE divide of
  *                Common/VolumePainter.cpp:846-852 because the reciprocal product lay within the
  *                proven error bound of an integer ("Exact index without the divide"),
  *   counters[1..3]  samples of boxes indexed by the exact divide throughout (degenerate spacing) /
- *                by the reciprocal product / by the power-of-two product.
+ *                by the reciprocal product / by the power-of-two product,
+ *   counters[4]  non-empty pixels outside the row span of a tightened plan
+ *                (avr_frame_plan_tighten): always 0.
  * Never changes results. */
 int avr_context_set_march_counters(avr_context *ctx, uint64_t *counters_dev);
 
@@ -292,6 +294,18 @@ int avr_frame_plan_splits(const avr_frame_plan *plan, int64_t *send_splits, int6
 int avr_frame_plan_layers(const avr_frame_plan *plan, int32_t *layer_box);
 /* runs[n_runs_total] in global order. */
 int avr_frame_plan_runs(const avr_frame_plan *plan, avr_run_info *runs);
+/* Tightens the exchange layout of a plan made by avr_frame_plan_create: instead of its whole
+ * screen rectangle, every row of a run stores only the conservative extent of the run's boxes on
+ * that row (the convex hull of each box's projected corners, +2 pixels); what lies outside is the
+ * cleared layer pixel -- the exact identity of the depth-sort blend (DirectSendBase.cpp:400-446
+ * blends it like any other) -- on the sender and the receiver alike, so results do not change
+ * while send_floats / recv_floats and the splits shrink (config-4: the rectangles are 48-72 %
+ * filled).  Sizes still follow from the replicated metadata: EVERY rank must tighten the plan of
+ * a frame or none.  all_boxes as given to avr_frame_plan_create.  The march counts, in the 5th
+ * diagnostic counter (avr_context_set_march_counters), non-empty pixels it found outside a span:
+ * always 0.  avr_frame_plan_send_block / recv_block do not apply to a tightened plan. */
+int avr_frame_plan_tighten(avr_frame_plan *plan, const avr_box *all_boxes, int n_boxes);
+
 /* Offset (floats) of block(piece of `peer`, local run r) in the send buffer and of
  * block(my piece, global run g) in the recv buffer; -1 when the block is empty.
  * first_row receives the image row of the block's first row. */
@@ -466,6 +480,10 @@ int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
 int avr_renderer_set_classify_share(avr_renderer *renderer, int bytes);
 int avr_renderer_corun_state(const avr_renderer *renderer, int *overlap_out,
                              int *reserve_bytes_out, int *settled_out, long *windows_out);
+/* Whether the driver tightens the exchange layout (avr_frame_plan_tighten) of a plan from the
+ * second consecutive frame with the same camera and parameters on (default 1).  The same on
+ * every rank.  Never changes results. */
+int avr_renderer_set_tighten(avr_renderer *renderer, int enabled);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream

@@ -8,7 +8,7 @@ import torch
 from amrvolumerenderer_amd import runtime, scenes
 from amrvolumerenderer_amd.compositor import FramePlan
 from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
-from amrvolumerenderer_amd.types import make_params
+from amrvolumerenderer_amd.types import CameraParameters, make_params
 
 import plan_helpers as PH
 from helpers import assert_bit_equal, device_box
@@ -297,3 +297,80 @@ def test_corun_tuning_never_changes_results(O, ctx):
     state = renderer.native.corun_state()
     assert state == {"classify": "beside the march", "lds_reserve_bytes": 0, "settled": False,
                      "timed_windows": 0}
+
+
+def _simulated_frame(O, ctx, spec, cam, W, H, transparency, n_ranks, tighten, cells=None):
+    """The N-rank frame with the ranks played one after the other on this GPU: per rank its frame
+    plan (tightened or not), classify + march into the send buffer, the all-to-all by hand, the
+    fold.  Returns (image [W*H, 5], floats sent by all ranks, non-empty pixels the march found
+    outside a tightened row span)."""
+    from test_frame_plan import painted_scene
+    import plan_helpers as PH
+    if cells is None:
+        cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+    oboxes = [O.make_box(c, m.min_corner, m.max_corner) for c, m in zip(cells, spec.boxes)]
+    ref = O.reference_sample_distance(oboxes, spec.bounds.min_corner, spec.bounds.max_corner)
+    params = make_params(W, H, spec.scalar_range, transparency, ref, spec.bounds)
+    counters = torch.zeros(5, dtype=torch.int64, device=ctx.device)
+    samples = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+    ctx.set_march_counters(counters)
+    plans, sends = [], []
+    try:
+        for r in range(n_ranks):
+            plan = FramePlan(meta, params, cam, r, n_ranks)
+            if tighten:
+                plan.tighten()
+            local = [device_box(ctx, cells[i], spec.boxes[i].min_corner, spec.boxes[i].max_corner,
+                                spec.boxes[i].level) for i in scenes.local_box_indices(spec, r)]
+            scene = ctx.create_scene(local, spec.transform)
+            send = scene.render_plan(plan, samples=samples)
+            ctx.synchronize()
+            plans.append(plan)
+            sends.append(send[:plan.send_floats].cpu().numpy())
+    finally:
+        ctx.set_march_counters(None)
+    image = np.zeros((W * H, 5), np.float32)
+    for plan, recv in zip(plans, PH.route(plans, sends)):
+        dev = torch.from_numpy(np.ascontiguousarray(recv)).to(ctx.device)
+        if dev.numel() == 0:
+            dev = torch.zeros(1, device=ctx.device)
+        piece, _ = ctx.fold_plan(plan, dev, want_rgb8=True)
+        ctx.synchronize()
+        image[plan.piece_begin:plan.piece_end] = piece.cpu().numpy()
+    return image, sum(p.send_floats for p in plans), int(counters[4].item())
+
+
+@pytest.mark.parametrize("n_ranks,policy", [(2, "morton"), (3, "round_robin"), (5, "morton"),
+                                            (8, "round_robin")])
+def test_tightened_exchange_layout_is_exact(O, ctx, n_ranks, policy):
+    """avr_frame_plan_tighten: per-row extents instead of the runs' rectangles.  For views from
+    outside, from inside the domain (boxes reach behind the eye: those keep their rectangle) and
+    grazing along a face, the frame of N simulated ranks is the oracle's N-rank compose bit for
+    bit, the march finds no non-empty pixel outside a span, and fewer floats travel."""
+    from test_frame_plan import local_indices, painted_scene
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    scenes.assign_owners(spec, n_ranks, policy)
+    owners = [b.owner for b in spec.boxes]
+    W, H, transparency = 131, 97, 0.85
+    cams = [scenes.default_camera(), scenes.orbit_camera(5),
+            CameraParameters((0.45, 0.55, 0.5), (0.9, 0.4, 0.1), (0.0, 1.0, 0.0), 70.0, 0.05, 20.0),
+            CameraParameters((0.5, 1.0, 2.6), (0.5, 1.0, 0.0), (0.0, 1.0, 0.0), 35.0, 0.1, 20.0)]
+    saved = []
+    try:
+        for cam in cams:
+            cells, layers, hints, _ = painted_scene(O, spec, cam, W, H, transparency)
+            want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks),
+                                           n_ranks)
+            loose, loose_floats, _ = _simulated_frame(O, ctx, spec, cam, W, H, transparency,
+                                                      n_ranks, False, cells)
+            tight, tight_floats, dropped = _simulated_frame(O, ctx, spec, cam, W, H, transparency,
+                                                            n_ranks, True, cells)
+            assert_bit_equal(loose, want, "rectangular layout")
+            assert_bit_equal(tight, want, "tightened layout")
+            assert dropped == 0
+            assert tight_floats <= loose_floats
+            saved.append(1.0 - tight_floats / loose_floats)
+        assert saved[0] > 0.1 and saved[1] > 0.1   # the oblique views from outside
+    finally:
+        scenes.assign_owners(spec, 1, "morton")

@@ -64,7 +64,10 @@ def test_config4_single_rank_frame_is_the_oracles(O, ctx, config4):
         assert torch.equal(again, rgb8)
 
 
-def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config4):
+@pytest.mark.parametrize("tighten", [False, True])
+def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config4, tighten):
+    """(tighten: the per-row exchange layout of avr_frame_plan_tighten instead of the runs'
+    rectangles -- same frame, fewer floats on the wire.)"""
     spec, cam, device_cells, layers, hints, ref, _ = config4
     n_ranks = 8
     scenes.assign_owners(spec, n_ranks, "morton")
@@ -75,6 +78,10 @@ def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config
     plans, sends = [], []
     for r in range(n_ranks):
         plan = FramePlan(meta, params, cam, r, n_ranks)
+        if tighten:
+            loose_floats = plan.send_floats
+            plan.tighten()
+            assert plan.send_floats <= loose_floats
         local = [AmrBox(spec.boxes[i].min_corner, spec.boxes[i].max_corner, device_cells[i],
                         spec.boxes[i].level, owner=r) for i in scenes.local_box_indices(spec, r)]
         scene = ctx.create_scene(local, spec.transform)

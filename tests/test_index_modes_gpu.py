@@ -98,7 +98,7 @@ def run_case(O, ctx, cells, lo, hi, cam, size, transparency, counters, bounds, r
 def test_reciprocal_index_path_random_boxes(O, ctx, kind, seed):
     rng = np.random.default_rng(1000 + seed)
     bounds = VolumeBounds((-1.0,) * 3, (2.0,) * 3)
-    counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    counters = torch.zeros(5, dtype=torch.int64, device=ctx.device)
     total = 0
     for _ in range(60):
         total += run_case(O, ctx, *random_case(rng, kind), counters, bounds)
@@ -125,7 +125,7 @@ def test_near_integer_fallback_is_decisive(O, ctx):
         for nudge in (0, 1, -1):    # RN(k dx) and its float neighbours
             eye_x = np.float32(np.float32(k) * dx)
             eye_x = np.nextafter(eye_x, np.float32(np.inf * nudge)) if nudge else eye_x
-            counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+            counters = torch.zeros(5, dtype=torch.int64, device=ctx.device)
             cam = CameraParameters((float(eye_x), 0.45, 4.0), (float(eye_x), 0.45, 0.0),
                                    (0.0, 1.0, 0.0), 10.0, 0.05, 90.0)
             n = run_case(O, ctx, cells, lo, hi, cam, (1, 48), 0.9, counters, bounds)
@@ -143,7 +143,7 @@ def test_exact_divide_mode_degenerate_spacing(O, ctx):
     slab's closed bounds."""
     rng = np.random.default_rng(5)
     bounds = VolumeBounds((-0.05,) * 3, (1.05,) * 3)
-    counters = torch.zeros(4, dtype=torch.int64, device=ctx.device)
+    counters = torch.zeros(5, dtype=torch.int64, device=ctx.device)
     cells = rng.random((16, 16, 4))   # nz, ny, nx
     lo, hi = (-1e-39, 0.0, 0.0), (1e-39, 1.0, 1.0)
     cam = CameraParameters((0.0, 0.5, 3.0), (0.0, 0.5, 0.5), (0.0, 1.0, 0.0), 30.0, 0.05, 20.0)

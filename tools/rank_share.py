@@ -80,7 +80,6 @@ def measure_share(n_ranks, rank):
     r.render(args.size, args.size, args.transparency, 1, cam, samples=counter, **kw)
     r.synchronize()
     samples = int(counter.item())
-    info = r.plan_info()
     # clocks and allocator pools settle, and the driver finishes measuring how the rank's two
     # kernels share the GPU (bounded at 3 s)
     begin = time.perf_counter()
@@ -105,6 +104,7 @@ def measure_share(n_ranks, rank):
     torch.cuda.synchronize()
     share = (time.perf_counter() - t0) / args.frames
     sections, _ = r.host_profile()
+    info = r.plan_info()   # (after the first frame the driver tightens the exchange layout)
     classify_ms, march_ms, busy_ms, _ = r.timings()
     r.set_timing(False)
     return dict(rank=rank, boxes=len(local), share_ms=1e3 * share, host_ms=1e3 * host,
