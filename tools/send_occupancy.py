@@ -2,7 +2,8 @@
 """How much of the sparse exchange volume is empty pixels?  For every rank of an N-rank config-4
 frame: the floats of its send buffer (run rectangles cut into pieces, avr_frame_plan) against
 the pixels in it that carry anything (alpha != 0) -- the bound of any exact compression of the
-exchange (empty pixels are the identity of the depth-sort blend)."""
+exchange (empty pixels are the identity of the depth-sort blend) -- and against the tightened
+layout of avr_frame_plan_tighten (per-row extents of the runs' boxes)."""
 import argparse
 import os
 import sys
@@ -22,7 +23,7 @@ cam = scenes.default_camera()
 for n in args.ranks:
     spec = scenes.config4("smooth")
     scenes.assign_owners(spec, n, "morton")
-    total_px = total_full = 0
+    total_px = total_full = total_tight = 0
     worst = 0.0
     for rank in range(n):
         ctx = runtime.Context(0)
@@ -43,8 +44,14 @@ for n in args.ranks:
         total_px += px
         total_full += full
         worst = max(worst, px * 20 / 1e6)
-        print(f"  N={n} rank {rank}: {px * 20 / 1e6:7.2f} MB sent, {100.0 * full / max(px, 1):5.1f} % "
-              f"of its pixels non-empty ({full * 20 / 1e6:7.2f} MB)")
+        plan.tighten()
+        tight_px = plan.send_floats // 5
+        total_tight += tight_px
+        print(f"  N={n} rank {rank}: {px * 20 / 1e6:7.2f} MB in rectangles, {100.0 * full / max(px, 1):5.1f} % "
+              f"of the pixels non-empty ({full * 20 / 1e6:7.2f} MB); tightened layout "
+              f"{tight_px * 20 / 1e6:7.2f} MB")
         del r, send, layers, local, all_boxes
         torch.cuda.empty_cache()
-    print(f"N={n}: {total_px * 20 / 1e6:.1f} MB in all, {100.0 * total_full / total_px:.1f} % non-empty")
+    print(f"N={n}: {total_px * 20 / 1e6:.1f} MB in all, {100.0 * total_full / total_px:.1f} % non-empty; "
+          f"tightened (avr_frame_plan_tighten) {total_tight * 20 / 1e6:.1f} MB = "
+          f"{100.0 * total_tight / total_px:.1f} %")
