@@ -412,39 +412,47 @@ void box_row_spans(const avr_box& box, const avr_camera& camera, int width, int 
     if (!std::isfinite(px[corner]) || !std::isfinite(py[corner])) return;
   }
   constexpr double margin = 2.0;  // as screen_rect
-  for (int r = 0; r < rows; ++r) {
-    const double band_lo = static_cast<double>(rect[1] + r) - 0.5 - margin;
-    const double band_hi = static_cast<double>(rect[1] + r) + 0.5 + margin;
-    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-    for (int a = 0; a < 8; ++a) {
-      for (int b = a; b < 8; ++b) {
-        // the part of segment a-b inside the band (a == b: the corner itself)
-        double ya = py[a], yb = py[b], xa = px[a], xb = px[b];
-        if (ya > yb) {
-          std::swap(ya, yb);
-          std::swap(xa, xb);
-        }
+  // per row the extent of the segments' parts inside the row's band [y - 0.5 - m, y + 0.5 + m];
+  // every segment only visits the rows whose band it reaches
+  std::vector<double> lo(static_cast<size_t>(rows), std::numeric_limits<double>::infinity());
+  std::vector<double> hi(static_cast<size_t>(rows), -std::numeric_limits<double>::infinity());
+  for (int a = 0; a < 8; ++a) {
+    for (int b = a + 1; b < 8; ++b) {
+      double ya = py[a], yb = py[b], xa = px[a], xb = px[b];
+      if (ya > yb) {
+        std::swap(ya, yb);
+        std::swap(xa, xb);
+      }
+      const double first = std::ceil(ya - 0.5 - margin), last = std::floor(yb + 0.5 + margin);
+      const int r_lo = static_cast<int>(std::max(first - rect[1], 0.0));
+      const int r_hi = static_cast<int>(std::min(last - rect[1], static_cast<double>(rows - 1)));
+      const double slope = (yb > ya) ? (xb - xa) / (yb - ya) : 0.0;
+      for (int r = r_lo; r <= r_hi; ++r) {
+        const double band_lo = static_cast<double>(rect[1] + r) - 0.5 - margin;
+        const double band_hi = static_cast<double>(rect[1] + r) + 0.5 + margin;
         if (yb < band_lo || ya > band_hi) continue;
         double x_first = xa, x_last = xb;
         if (yb > ya) {
-          const double slope = (xb - xa) / (yb - ya);
           if (ya < band_lo) x_first = xa + (band_lo - ya) * slope;
           if (yb > band_hi) x_last = xa + (band_hi - ya) * slope;
         }
-        lo = std::min(lo, std::min(x_first, x_last));
-        hi = std::max(hi, std::max(x_first, x_last));
+        lo[static_cast<size_t>(r)] = std::min(lo[static_cast<size_t>(r)], std::min(x_first, x_last));
+        hi[static_cast<size_t>(r)] = std::max(hi[static_cast<size_t>(r)], std::max(x_first, x_last));
       }
     }
-    if (!(hi >= lo)) {  // the hull misses the band: nothing of this box on the row
-      (*row_x0)[static_cast<size_t>(r)] = 0;
+  }
+  for (int r = 0; r < rows; ++r) {
+    if (!(hi[static_cast<size_t>(r)] >= lo[static_cast<size_t>(r)])) {
+      (*row_x0)[static_cast<size_t>(r)] = 0;  // the hull misses the band: nothing on the row
       (*row_x1)[static_cast<size_t>(r)] = -1;
       continue;
     }
-    const double x0 = std::floor(lo - margin), x1 = std::ceil(hi + margin);
-    const int32_t c0 = static_cast<int32_t>(std::max(x0, static_cast<double>(rect[0])));
-    const int32_t c1 = static_cast<int32_t>(std::min(x1, static_cast<double>(rect[2])));
-    (*row_x0)[static_cast<size_t>(r)] = c0;
-    (*row_x1)[static_cast<size_t>(r)] = c1;  // c1 < c0: nothing on the row
+    const double x0 = std::floor(lo[static_cast<size_t>(r)] - margin);
+    const double x1 = std::ceil(hi[static_cast<size_t>(r)] + margin);
+    (*row_x0)[static_cast<size_t>(r)] =
+        static_cast<int32_t>(std::max(x0, static_cast<double>(rect[0])));
+    (*row_x1)[static_cast<size_t>(r)] =
+        static_cast<int32_t>(std::min(x1, static_cast<double>(rect[2])));  // < x0: nothing
   }
 }
 
