@@ -128,3 +128,42 @@ def test_plan_edge_cases(avr_lib):
         b.owner = 5
     with pytest.raises(ValueError):
         FramePlan(boxes, params, cam, 0, 2)
+
+
+@pytest.mark.parametrize("n_ranks,policy", [(2, "morton"), (3, "round_robin"), (5, "block"),
+                                            (8, "morton")])
+def test_tightened_plans_agree_between_ranks(avr_lib, n_ranks, policy):
+    """avr_frame_plan_tighten on the host: every rank derives the per-row layout from replicated
+    metadata alone, so what rank a will send to rank b is what b expects from a; the layout never
+    grows, is idempotent, and the rectangular block accessors refuse a tightened plan."""
+    from amrvolumerenderer_amd.types import CameraParameters
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    scenes.assign_owners(spec, n_ranks, policy)
+    meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+    cams = [scenes.default_camera(), scenes.orbit_camera(3), scenes.orbit_camera(11),
+            CameraParameters((0.45, 0.55, 0.5), (0.9, 0.4, 0.1), (0.0, 1.0, 0.0), 70.0, 0.05, 20.0)]
+    try:
+        for cam in cams:
+            for W, H in ((75, 43), (256, 192)):
+                params = make_params(W, H, spec.scalar_range, 0.8, 0.02, spec.bounds)
+                plans = [FramePlan(meta, params, cam, r, n_ranks) for r in range(n_ranks)]
+                loose = [(p.send_floats, p.recv_floats, list(p.send_splits)) for p in plans]
+                for p in plans:
+                    p.tighten()
+                for p, (send, recv, splits) in zip(plans, loose):
+                    assert p.send_floats <= send and p.recv_floats <= recv
+                    assert sum(p.send_splits) == p.send_floats
+                    assert sum(p.recv_splits) == p.recv_floats
+                    assert all(a <= b for a, b in zip(p.send_splits, splits))
+                    assert all(v % 5 == 0 for v in p.send_splits)
+                for a in range(n_ranks):
+                    for b in range(n_ranks):
+                        assert plans[a].send_splits[b] == plans[b].recv_splits[a], (a, b)
+                before = (plans[0].send_floats, list(plans[0].send_splits))
+                plans[0].tighten()
+                assert before == (plans[0].send_floats, list(plans[0].send_splits))
+                if plans[0].n_local_runs:
+                    with pytest.raises(Exception):
+                        plans[0].send_block(0, 0)
+    finally:
+        scenes.assign_owners(spec, 1, "morton")
