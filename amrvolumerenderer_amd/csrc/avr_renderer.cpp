@@ -115,9 +115,25 @@ struct avr_renderer {
   bool tighten_exchange = true;  // avr_renderer_set_tighten
   int overlap_classify = -1;  // -1: default (1 for one rank, 0 otherwise); see avr_renderer_set_overlap
 
-  avr_frame_plan* plan = nullptr;
-  PlanKey key;
+  // Frame plans by (render parameters, camera, group order), most recently used kept: a camera
+  // that comes back (an orbit) finds its plan -- and, for N > 1, its tightened exchange layout.
+  struct CachedPlan {
+    PlanKey key;
+    avr_frame_plan* plan = nullptr;
+    uint64_t last_used = 0;
+  };
+  static constexpr size_t kCachedPlans = 32;
+  std::vector<CachedPlan> plans;
+  uint64_t plan_clock = 0;
+  avr_frame_plan* plan = nullptr;  // of the last frame (owned by `plans`)
   bool have_plan = false;
+
+  void forget_plans() {
+    for (CachedPlan& entry : plans) avr_frame_plan_destroy(entry.plan);
+    plans.clear();
+    plan = nullptr;
+    have_plan = false;
+  }
 
   DeviceBuffer send[2], recv, piece, piece_rgb8, full_rgb8, full_image, small_image;
   // classified volume f % 3, send buffer f % 2
@@ -165,7 +181,7 @@ struct avr_renderer {
     }
     if (input_event != nullptr) (void)hipEventDestroy(input_event);
     if (epoch != nullptr) (void)hipEventDestroy(epoch);
-    if (plan != nullptr) avr_frame_plan_destroy(plan);
+    forget_plans();
     if (visibility != nullptr) avr_visibility_graph_destroy(visibility);
     if (scene != nullptr) avr_scene_destroy(scene);
     for (avr_context* ctx : {classify, march, compose}) avr_context_destroy(ctx);
@@ -323,7 +339,7 @@ int avr_renderer_set_scalar_range(avr_renderer* r, const float scalar_range[2]) 
     require(r != nullptr && scalar_range != nullptr, "null argument");
     r->scalar_range[0] = scalar_range[0];
     r->scalar_range[1] = scalar_range[1];
-    r->have_plan = false;  // the plan carries the paint parameters
+    r->forget_plans();  // the plans carry the paint parameters
     return AVR_OK;
   });
 }
@@ -362,7 +378,7 @@ int avr_renderer_set_tighten(avr_renderer* r, int enabled) {
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
     r->tighten_exchange = enabled != 0;
-    r->have_plan = false;  // the next frame plans afresh
+    r->forget_plans();  // the next frame plans afresh
     return AVR_OK;
   });
 }
@@ -508,7 +524,13 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     key.render = *render;
     key.camera = *camera;
     if (group_order != nullptr) key.group.assign(group_order, group_order + r->n_ranks);
-    if (!r->have_plan || !(key == r->key) || render->write_visibility_graph) {
+    avr_renderer::CachedPlan* cached = nullptr;
+    if (!render->write_visibility_graph) {
+      for (avr_renderer::CachedPlan& entry : r->plans) {
+        if (entry.key == key) cached = &entry;
+      }
+    }
+    if (cached == nullptr) {
       std::vector<int32_t> order;
       const int32_t* group = group_order;
       if (group == nullptr && r->visibility != nullptr) {
@@ -537,18 +559,27 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       abi_ok(avr_frame_plan_create(r->all_boxes.data(), r->owner.data(),
                                    static_cast<int>(r->all_boxes.size()), r->n_ranks, r->rank, group,
                                    &params, camera, &fresh));
-      if (r->plan != nullptr) avr_frame_plan_destroy(r->plan);
-      r->plan = fresh;
-      r->key = key;
-      r->have_plan = true;
+      if (r->plans.size() >= avr_renderer::kCachedPlans) {  // the least recently used one goes
+        size_t oldest = 0;
+        for (size_t i = 1; i < r->plans.size(); ++i) {
+          if (r->plans[i].last_used < r->plans[oldest].last_used) oldest = i;
+        }
+        avr_frame_plan_destroy(r->plans[oldest].plan);
+        r->plans.erase(r->plans.begin() + static_cast<std::ptrdiff_t>(oldest));
+      }
+      r->plans.push_back(avr_renderer::CachedPlan{key, fresh, 0});
+      cached = &r->plans.back();
     } else if (r->n_ranks > 1 && r->tighten_exchange) {
-      // The camera repeats: from its second frame on the plan's exchange layout is tightened to
-      // the runs' per-row extents (30-50 % fewer bytes on the links; ~ms of host geometry, which
-      // a camera that moves every frame never pays).  Every rank sees the same sequence of
-      // cameras, so every rank tightens the same frames.
-      abi_ok(avr_frame_plan_tighten(r->plan, r->all_boxes.data(),
+      // The camera has been seen before: from its second frame on the plan's exchange layout is
+      // tightened to the runs' per-row extents (25-50 % fewer bytes on the links; ~2 ms of host
+      // geometry, which a camera that never comes back never pays).  Every rank sees the same
+      // sequence of cameras, so every rank tightens the same frames.
+      abi_ok(avr_frame_plan_tighten(cached->plan, r->all_boxes.data(),
                                     static_cast<int>(r->all_boxes.size())));
     }
+    cached->last_used = ++r->plan_clock;
+    r->plan = cached->plan;
+    r->have_plan = true;
     const avr_frame_plan* plan = r->plan;
     const avr_frame_plan_info& info = plan->info;
     const int64_t piece_pixels = info.piece_end - info.piece_begin;

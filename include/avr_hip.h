@@ -480,8 +480,9 @@ int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
 int avr_renderer_set_classify_share(avr_renderer *renderer, int bytes);
 int avr_renderer_corun_state(const avr_renderer *renderer, int *overlap_out,
                              int *reserve_bytes_out, int *settled_out, long *windows_out);
-/* Whether the driver tightens the exchange layout (avr_frame_plan_tighten) of a plan from the
- * second consecutive frame with the same camera and parameters on (default 1).  The same on
+/* Whether the driver tightens the exchange layout (avr_frame_plan_tighten) of a plan when its
+ * camera and parameters are seen a second time (default 1; the 32 most recently used plans are
+ * kept).  The same on
  * every rank.  Never changes results. */
 int avr_renderer_set_tighten(avr_renderer *renderer, int enabled);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);

@@ -309,8 +309,15 @@ int main(int argc, char** argv) {
             avr::hip_ok(hipSetDevice(0), "hipSetDevice");
             avr::FrameDriver driver(0, r, n_ranks, n_ranks > 1 ? comms[static_cast<size_t>(r)].get() : nullptr,
                                     boxes, owner, transform, bmin, bmax);
-            for (int frame = 0; frame < frames; ++frame) {  // pipelined: no synchronisation between
-              driver.render(render, camera, r == 0 ? bytes.data() : nullptr, true,
+            // pipelined: no synchronisation between the frames.  Every third frame before the
+            // last looks from elsewhere: the camera then comes back to a cached plan (whose
+            // exchange layout the driver tightens on that second use).
+            avr_camera elsewhere = camera;
+            elsewhere.eye[0] = camera.eye[0] - 0.9f;
+            elsewhere.eye[1] = camera.eye[1] + 0.4f;
+            for (int frame = 0; frame < frames; ++frame) {
+              const bool away = (frame % 3 == 1) && frame + 1 < frames;
+              driver.render(render, away ? elsewhere : camera, r == 0 ? bytes.data() : nullptr, true,
                             r == 0 ? image.data() : nullptr);
             }
             driver.synchronize();
