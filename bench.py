@@ -460,6 +460,9 @@ def main():
                                   f"C++ driver's communicator failed: {renderer.native_error}"),
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
             "corun": renderer.native.corun_state() if native else None,
+            "exchange": ({"rank0_send_mb": round(renderer.last_plan.send_floats * 4 / 1e6, 2),
+                          "layout": "per-row extents of the runs (avr_frame_plan_tighten)"
+                          if native else "run rectangles"} if world > 1 else None),
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
             "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,
