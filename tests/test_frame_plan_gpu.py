@@ -374,3 +374,50 @@ def test_tightened_exchange_layout_is_exact(O, ctx, n_ranks, policy):
         assert saved[0] > 0.1 and saved[1] > 0.1   # the oblique views from outside
     finally:
         scenes.assign_owners(spec, 1, "morton")
+
+
+def test_tightened_layout_random_views(O, ctx):
+    """Random cameras -- far, close with strong perspective, eyes inside boxes, views nearly along
+    an axis -- for a 3-rank frame: the tightened layout gives the rectangular layout's image bit
+    for bit and the march never finds a non-empty pixel outside a row span."""
+    rng = np.random.default_rng(2026)
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    scenes.assign_owners(spec, 3, "round_robin")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    W, H = 113, 79
+    saved = 0.0
+    try:
+        for case in range(24):
+            kind = case % 4
+            centre = np.array([0.5, 0.5, 0.5])
+            if kind == 0:      # from outside, anywhere on a sphere
+                d = rng.normal(size=3)
+                eye = centre + d / np.linalg.norm(d) * rng.uniform(1.2, 4.0)
+                look, fov = centre + rng.uniform(-0.2, 0.2, size=3), rng.uniform(20.0, 60.0)
+            elif kind == 1:    # close to a face: strong perspective, wide angle
+                d = rng.normal(size=3)
+                eye = centre + d / np.linalg.norm(d) * rng.uniform(0.75, 1.0)
+                look, fov = centre, rng.uniform(70.0, 110.0)
+            elif kind == 2:    # inside the domain: boxes reach behind the eye
+                eye = rng.uniform(0.1, 0.9, size=3)
+                look, fov = eye + rng.normal(size=3), rng.uniform(40.0, 100.0)
+            else:              # nearly along an axis
+                axis = int(rng.integers(0, 3))
+                eye = centre.copy()
+                eye[axis] += rng.choice([-1.0, 1.0]) * rng.uniform(1.5, 3.0)
+                eye += rng.uniform(-1e-3, 1e-3, size=3)
+                look, fov = centre, rng.uniform(25.0, 50.0)
+            forward = look - eye
+            up = (0.0, 1.0, 0.0) if abs(forward[1]) < 0.9 * np.linalg.norm(forward) else (1.0, 0.0, 0.0)
+            cam = CameraParameters(tuple(float(v) for v in eye), tuple(float(v) for v in look), up,
+                                   float(fov), 0.05, 30.0)
+            loose, loose_floats, _ = _simulated_frame(O, ctx, spec, cam, W, H, 0.9, 3, False, cells)
+            tight, tight_floats, dropped = _simulated_frame(O, ctx, spec, cam, W, H, 0.9, 3, True,
+                                                            cells)
+            assert_bit_equal(tight, loose, f"view {case}")
+            assert dropped == 0, (case, dropped)
+            assert tight_floats <= loose_floats
+            saved += 1.0 - tight_floats / max(loose_floats, 1)
+        assert saved / 24 > 0.05
+    finally:
+        scenes.assign_owners(spec, 1, "morton")
