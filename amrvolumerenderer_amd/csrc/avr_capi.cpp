@@ -278,7 +278,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const int32_t* run_end, int n_runs, int n_pieces,
            const std::vector<avr::RunRectDev>& run_rects,
            const std::vector<avr::RunBlockDev>& run_blocks,
-           const std::vector<avr::RunSpanDev>* run_spans, avr_scene* scene, int slot,
+           const avr::RunSpanDev* run_spans_dev, avr_scene* scene, int slot,
            float* out_layers, uint64_t* samples_out, avr::FramePlan* cached) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
   require(slot >= 0 && slot < AVR_CLASSIFIED_SLOTS, "classified slot out of range");
@@ -353,11 +353,10 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     avr::build_march_items(plan, box_order, run_end, n_runs, run_rects, &items);
     bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
              items.size() * sizeof(avr::MarchItemDev) +
-             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev) +
-             (run_spans != nullptr ? run_spans->size() * sizeof(avr::RunSpanDev) : 0);
+             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev);
   }
   avr::StagingRing& staging = ctx->staging;
-  staging.begin(bytes, 9);
+  staging.begin(bytes, 8);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
   if (phases & kClassify) {
     launch.tile_begin_dev =
@@ -373,9 +372,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.n_pieces = n_pieces;
     launch.run_rects_dev = staging.add(run_rects.data(), run_rects.size());
     launch.run_blocks_dev = staging.add(run_blocks.data(), run_blocks.size());
-    launch.run_spans_dev = (run_spans != nullptr && !run_spans->empty())
-                               ? staging.add(run_spans->data(), run_spans->size())
-                               : nullptr;
+    launch.run_spans_dev = run_spans_dev;
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
     launch.counters = reinterpret_cast<unsigned long long*>(ctx->march_counters);
@@ -721,7 +718,14 @@ int avr_pack_layers(avr_context* ctx, const avr_frame_plan* plan, const float* c
   });
 }
 
-void avr_frame_plan_destroy(avr_frame_plan* plan) { delete plan; }
+void avr_frame_plan_destroy(avr_frame_plan* plan) {
+  if (plan == nullptr) return;
+  // (the caller has made sure that no launch still reads the plan's device tables: the frame
+  // driver drains its streams before it lets go of a tightened plan)
+  if (plan->send_spans_dev != nullptr) (void)hipFree(plan->send_spans_dev);
+  if (plan->recv_spans_dev != nullptr) (void)hipFree(plan->recv_spans_dev);
+  delete plan;
+}
 
 int avr_frame_plan_get_info(const avr_frame_plan* plan, avr_frame_plan_info* out) {
   return guarded([&]() -> int {
@@ -798,6 +802,24 @@ int avr_frame_plan_recv_block(const avr_frame_plan* plan, int global_run, int64_
   });
 }
 
+// The span tables of a tightened plan live on the device for the plan's lifetime: one blocking
+// copy when first needed (streams created non-blocking are not synchronised by it).
+static const avr::RunSpanDev* resident_spans(const avr_context* ctx,
+                                             const std::vector<avr::RunSpanDev>& host,
+                                             void** device_copy, const avr_frame_plan* plan) {
+  if (host.empty()) return nullptr;
+  if (*device_copy == nullptr) {
+    require(plan->spans_device < 0 || plan->spans_device == ctx->device,
+            "a tightened plan is bound to the device that used it first");
+    plan->spans_device = ctx->device;
+    const size_t bytes = host.size() * sizeof(avr::RunSpanDev);
+    avr::hip_check(hipMalloc(device_copy, bytes), "hipMalloc(span table)");
+    avr::hip_check(hipMemcpy(*device_copy, host.data(), bytes, hipMemcpyHostToDevice),
+                   "hipMemcpy(span table)");
+  }
+  return static_cast<const avr::RunSpanDev*>(*device_copy);
+}
+
 static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                       const avr_frame_plan* plan, int slot, float* send_buffer,
                       uint64_t* samples_out) {
@@ -811,8 +833,10 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                   scene->transform, plan->params, plan->camera, plan->local_order.data(),
                   static_cast<int>(plan->local_order.size()), plan->local_run_end.data(),
                   plan->info.n_local_runs, plan->info.n_ranks, plan->local_rects, plan->send_blocks,
-                  plan->tightened ? &plan->send_spans : nullptr, const_cast<avr_scene*>(scene), slot,
-                  send_buffer, samples_out,
+                  ((phases & kMarch) && plan->tightened)
+                      ? resident_spans(ctx, plan->send_spans, &plan->send_spans_dev, plan)
+                      : nullptr,
+                  const_cast<avr_scene*>(scene), slot, send_buffer, samples_out,
                   &const_cast<avr_frame_plan*>(plan)->prologue);
   });
 }
@@ -858,14 +882,13 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
     avr::FoldLaunch launch;
     ctx->staging.begin(plan->global_rects.size() * sizeof(avr::RunRectDev) +
-                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev) +
-                           plan->recv_spans.size() * sizeof(avr::RunSpanDev),
-                       3);
+                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev),
+                       2);
     launch.run_rects_dev = ctx->staging.add(plan->global_rects.data(), plan->global_rects.size());
     launch.run_blocks_dev = ctx->staging.add(plan->recv_blocks.data(), plan->recv_blocks.size());
-    launch.run_spans_dev = (plan->tightened && !plan->recv_spans.empty())
-                               ? ctx->staging.add(plan->recv_spans.data(), plan->recv_spans.size())
-                               : nullptr;
+    launch.run_spans_dev =
+        plan->tightened ? resident_spans(ctx, plan->recv_spans, &plan->recv_spans_dev, plan)
+                        : nullptr;
     ctx->staging.commit(ctx->stream);
     launch.width = plan->params.width;
     launch.piece_begin = plan->info.piece_begin;

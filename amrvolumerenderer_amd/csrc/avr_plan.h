@@ -30,6 +30,11 @@ struct avr_frame_plan {
   // tightened layout (avr_frame_plan_tighten): the rows of the blocks above, sender and receiver
   std::vector<avr::RunSpanDev> send_spans, recv_spans;
   bool tightened = false;
+  // device copies of the two span tables (hundreds of KB: uploaded once, by the first call that
+  // needs them -- avr_capi.cpp -- not with every frame's descriptors; freed with the plan)
+  mutable void* send_spans_dev = nullptr;
+  mutable void* recv_spans_dev = nullptr;
+  mutable int spans_device = -1;
   bool from_boxes = false;  // built by build_frame_plan (layers = boxes): may be tightened
   // host prologue of this frame's local boxes, filled by the first device call that needs it
   // (avr_classify_plan) and re-used by the next (avr_march_plan)

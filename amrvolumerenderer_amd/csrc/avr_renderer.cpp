@@ -129,6 +129,7 @@ struct avr_renderer {
   bool have_plan = false;
 
   void forget_plans() {
+    if (!plans.empty()) drain_all();  // tightened plans own device tables that launches read
     for (CachedPlan& entry : plans) avr_frame_plan_destroy(entry.plan);
     plans.clear();
     plan = nullptr;
@@ -563,6 +564,11 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         size_t oldest = 0;
         for (size_t i = 1; i < r->plans.size(); ++i) {
           if (r->plans[i].last_used < r->plans[oldest].last_used) oldest = i;
+        }
+        // (a tightened plan owns device tables that launches may still read)
+        if (r->plans[oldest].plan->send_spans_dev != nullptr ||
+            r->plans[oldest].plan->recv_spans_dev != nullptr) {
+          r->drain_all();
         }
         avr_frame_plan_destroy(r->plans[oldest].plan);
         r->plans.erase(r->plans.begin() + static_cast<std::ptrdiff_t>(oldest));
