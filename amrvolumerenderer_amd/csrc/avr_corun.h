@@ -25,8 +25,10 @@ struct CoRunTuner {
   static constexpr int kLastCandidate = 28;    // 56 KiB: two classify workgroups per CU
   static constexpr int kCoarse = 2;            // the first pass takes every second reserve
   static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate (at most)
-  static constexpr int kWindowFrames = 8;      // frames timed per candidate (at most)
-  static constexpr float kWindowMs = 10.0f;    // ... but no longer than this, two frames at least
+  static constexpr int kWindowFrames = 40;     // frames timed per candidate (at most)
+  static constexpr float kWindowMs = 8.0f;     // ... as many as fill this time, two at least: the
+                                               // 0.2 ms frames of an N = 8 share need ~40 for a
+                                               // period good to a per cent, 1 ms frames 8
   static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
   static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
 
@@ -53,7 +55,7 @@ struct CoRunTuner {
   int frames_per_window() const {
     if (last_period_ms <= 0.0f) return 4;
     const int frames = static_cast<int>(std::ceil(kWindowMs / last_period_ms));
-    return std::min(std::max(frames, 2), kWindowFrames);
+    return std::min(std::max(frames, 2), kWindowFrames);  // 1 ms -> 8, 35 ms -> 2, 0.2 ms -> 40
   }
 
   // Where the search starts is what a caller keeps who never renders enough frames back to back

@@ -327,8 +327,9 @@ def main():
         return renderer.native is None or renderer.native.corun_state()["settled"]
 
     # (N ranks: every frame is a collective, so every rank must run the same number of them --
-    # a fixed count, well past the ~260 frames the search takes, instead of a clock)
-    fixed_burst = 640 if world > 1 else None
+    # a fixed count, well past the <= 1000 frames the search takes at short frames, instead of a
+    # clock)
+    fixed_burst = 1600 if world > 1 else None
     while True:
         for _ in range(16):
             step(burst)

@@ -266,7 +266,7 @@ def test_corun_tuning_never_changes_results(O, ctx):
         return renderer, out
 
     _, want = run(0, 0, 3)
-    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 700), (4096, -1, 150)):
+    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 1500), (4096, -1, 400)):
         renderer, got = run(share, overlap, frames)
         state = renderer.native.corun_state()
         if overlap == 1:
