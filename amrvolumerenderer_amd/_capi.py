@@ -123,6 +123,8 @@ SIGNATURES = {
                                          C.c_int, _fp]),
     "avr_box_sampling": (C.c_int, [C.POINTER(Box), C.POINTER(PaintParams), _fp, _fp, _fp]),
     "avr_box_depth_hint": (C.c_int, [C.POINTER(Box), C.POINTER(Camera), _fp]),
+    "avr_box_footprint": (C.c_int, [C.POINTER(Box), C.POINTER(Camera), C.c_int, C.c_int, _ip, _ip,
+                                    _ip]),
     "avr_reference_sample_distance": (C.c_int, [C.POINTER(Box), C.c_int, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double), _fp]),
     "avr_layer_order": (C.c_int, [_fp, _ip, _ip, C.c_int, _ip, _ip, C.POINTER(C.c_int)]),

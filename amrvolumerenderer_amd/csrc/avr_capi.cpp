@@ -760,6 +760,28 @@ int avr_frame_plan_runs(const avr_frame_plan* plan, avr_run_info* runs) {
   });
 }
 
+int avr_box_footprint(const avr_box* box, const avr_camera* camera, int width, int height,
+                      int32_t rect[4], int32_t* row_x0, int32_t* row_x1) {
+  return guarded([&]() -> int {
+    require(box != nullptr && camera != nullptr && rect != nullptr, "null argument");
+    require(width > 0 && height > 0, "image width and height must be positive");
+    require((row_x0 == nullptr) == (row_x1 == nullptr), "row_x0 and row_x1 go together");
+    avr::box_screen_rect(*box, *camera, width, height, rect);
+    if (row_x0 == nullptr) return AVR_OK;
+    for (int y = 0; y < height; ++y) {
+      row_x0[y] = 0;
+      row_x1[y] = -1;
+    }
+    std::vector<int32_t> x0, x1;
+    avr::box_row_spans(*box, *camera, width, height, rect, &x0, &x1);
+    for (size_t r = 0; r < x0.size(); ++r) {
+      row_x0[rect[1] + static_cast<int>(r)] = x0[r];
+      row_x1[rect[1] + static_cast<int>(r)] = x1[r];
+    }
+    return AVR_OK;
+  });
+}
+
 int avr_frame_plan_tighten(avr_frame_plan* plan, const avr_box* all_boxes, int n_boxes) {
   return guarded([&]() -> int {
     require(plan != nullptr && n_boxes >= 0 && (n_boxes == 0 || all_boxes != nullptr),

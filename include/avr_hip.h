@@ -162,6 +162,16 @@ int avr_box_sampling(const avr_box *box, const avr_paint_params *params, float *
 /* computeBoxDepthHint (VolumeRenderer/VolumeRenderer.cpp:541-553). */
 int avr_box_depth_hint(const avr_box *box, const avr_camera *camera, float *out_hint);
 
+/* The conservative footprint of a box on a width x height image that the frame plans are built
+ * from (host only): its screen rectangle rect[4] = {x0, y0, x1, y1} inclusive (x1 < x0: off
+ * screen) -- the march only traces the rays of those pixels -- and, for every image row y, the
+ * columns row_x0[y] .. row_x1[y] of the tightened layout (avr_frame_plan_tighten; row_x1 < row_x0:
+ * nothing on that row; rows outside the rectangle are empty).  row_x0 / row_x1: height entries
+ * each, or NULL.  For the parity tests: every pixel the reference's K1 leaves non-empty for the
+ * box (VolumePainter.cpp:802-837: slab hit in front of the eye) must lie inside both. */
+int avr_box_footprint(const avr_box *box, const avr_camera *camera, int width, int height,
+                      int32_t rect[4], int32_t *row_x0, int32_t *row_x1);
+
 /* referenceSampleDistance of renderSingleTrial (VolumeRenderer/VolumeRenderer.cpp:1138-1190)
  * over the boxes given (the caller reduces with MAX over ranks when boxes are distributed:
  * pass the already-reduced coarsest spacing through avr_paint_params instead). */

@@ -142,3 +142,65 @@ def test_piece_range(O, avr_lib):
 def test_invalid_arguments_raise(avr_lib):
     with pytest.raises(ValueError):
         runtime.build_color_table(1.0, 1.0, (0, 1), [(0.0, 1.0, 1.0)])  # malformed entry
+
+
+def test_box_footprint_contains_what_the_oracle_paints(O, avr_lib):
+    """avr_box_footprint (host): the conservative screen rectangle the march restricts a box to and
+    the per-row extents the tightened exchange layout keeps.  Every pixel the oracle's
+    VolumePainter::paint leaves non-empty for the box -- random boxes seen from afar, from close
+    up, from inside, along a face -- lies inside both; and the extents are not vacuous."""
+    from helpers import oracle_camera, oracle_params, oracle_transform
+    from amrvolumerenderer_amd.types import ScalarTransform
+    rng = np.random.default_rng(31)
+    L = _capi.lib()
+    W, H = 96, 72
+    bounds = VolumeBounds((-1.0,) * 3, (2.0,) * 3)
+    cells = np.full((6, 6, 6), 0.5)
+    covered = kept = 0
+    for case in range(60):
+        lo = rng.uniform(-0.3, 0.6, size=3)
+        hi = lo + rng.uniform(0.15, 0.8, size=3)
+        centre = 0.5 * (lo + hi)
+        kind = case % 4
+        if kind == 0:
+            d = rng.normal(size=3)
+            eye = centre + d / np.linalg.norm(d) * rng.uniform(1.5, 4.0)
+            look, fov = centre + rng.uniform(-0.3, 0.3, size=3), rng.uniform(20.0, 70.0)
+        elif kind == 1:
+            d = rng.normal(size=3)
+            eye = centre + d / np.linalg.norm(d) * rng.uniform(0.55, 0.9) * np.linalg.norm(hi - lo)
+            look, fov = centre, rng.uniform(60.0, 110.0)
+        elif kind == 2:
+            eye = lo + rng.uniform(0.1, 0.9, size=3) * (hi - lo)
+            look, fov = eye + rng.normal(size=3), rng.uniform(40.0, 100.0)
+        else:
+            axis = int(rng.integers(0, 3))
+            eye = centre.copy()
+            eye[axis] = hi[axis] + rng.uniform(0.5, 2.0)
+            other = (axis + 1) % 3
+            eye[other] = (lo, hi)[int(rng.integers(0, 2))][other] + rng.choice([0.0, 1e-6, -1e-4])
+            look, fov = eye.copy(), rng.uniform(20.0, 60.0)
+            look[axis] = lo[axis]
+        forward = look - eye
+        up = (0.0, 1.0, 0.0) if abs(forward[1]) < 0.9 * np.linalg.norm(forward) else (1.0, 0.0, 0.0)
+        cam = CameraParameters(tuple(float(v) for v in eye), tuple(float(v) for v in look), up,
+                               float(fov), 0.05, 50.0)
+        box = AmrBox(tuple(float(v) for v in lo), tuple(float(v) for v in hi), None, dims=(6, 6, 6))
+        rect = (C.c_int32 * 4)()
+        x0 = (C.c_int32 * H)()
+        x1 = (C.c_int32 * H)()
+        cbox, ccam = box.to_c(), cam.to_c()
+        _capi.check(L.avr_box_footprint(C.byref(cbox), C.byref(ccam), W, H, rect, x0, x1))
+        ob = O.make_box(cells, box.min_corner, box.max_corner)
+        op = oracle_params(O, W, H, (0.0, 1.0), 0.5, 0.05, bounds)
+        layer, n = O.paint_box(ob, oracle_transform(O, ScalarTransform(normalize_to_unit_range=True)),
+                               op, oracle_camera(O, cam))
+        painted = layer.reshape(H, W, 5)[..., 3] != 0.0
+        ys, xs = np.nonzero(painted)
+        assert (n > 0) == (len(ys) > 0)
+        for y, x in zip(ys, xs):
+            assert rect[0] <= x <= rect[2] and rect[1] <= y <= rect[3], (case, x, y, list(rect))
+            assert x0[y] <= x <= x1[y], (case, x, y, x0[y], x1[y])
+        covered += len(ys)
+        kept += sum(max(x1[y] - x0[y] + 1, 0) for y in range(H))
+    assert covered > 20000 and kept < 2.2 * covered   # conservative, but not the whole image
