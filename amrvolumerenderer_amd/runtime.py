@@ -736,12 +736,16 @@ class NativeRenderer:
                     image = torch.empty((height, width, 5), dtype=torch.float32, device=self.device)
         if samples is not None and (samples.dtype != torch.int64 or samples.device != self.device):
             raise ValueError("samples must be an int64 tensor on the renderer's device")
-        # cell data / the samples counter may have been written on the caller's stream
-        wait = None if caller.query() else C.c_void_p(caller.cuda_stream)
-        if samples is not None and wait is not None:
+        # Cell data / the samples counter may have been written on the caller's stream.  The wait
+        # is placed here and not through avr_renderer_render's input_stream: torch's default
+        # stream has handle 0, which that argument reads as "nothing to wait for", and the
+        # driver's streams are non-blocking, so they never order themselves after the null stream.
+        # The classify pass runs on stream C or (back to back) on stream M: both wait.
+        if not caller.query():
+            self.streams[0].wait_stream(caller)
             self.streams[1].wait_stream(caller)
         _capi.check(_capi.lib().avr_renderer_render(
-            self._handle, C.byref(rp), C.byref(ccam), group, wait,
+            self._handle, C.byref(rp), C.byref(ccam), group, None,
             C.c_void_p(samples.data_ptr()) if samples is not None else None, int(bool(want_image)),
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
             C.c_void_p(image.data_ptr()) if image is not None else None))

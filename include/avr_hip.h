@@ -497,8 +497,12 @@ int avr_renderer_corun_state(const avr_renderer *renderer, int *overlap_out,
 int avr_renderer_set_tighten(avr_renderer *renderer, int enabled);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
- * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream (may be NULL): a HIP stream
- * whose queued work produces the cell data; the classify pass is ordered after it.
+ * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream: a HIP stream whose queued work
+ * produces the cell data (or zeroes samples_out); the classify pass, and with it the march, is
+ * ordered after it.  NULL means "nothing to wait for", NOT the legacy default stream (handle 0):
+ * the driver's streams are non-blocking and never order themselves after that one implicitly, so
+ * a caller that fills cells on the default stream passes hipStreamLegacy ((hipStream_t)1) or
+ * orders avr_renderer_stream(r, 0) and (r, 1) after its work itself.
  * samples_out (device, may be NULL) as avr_paint_box.  want_image (the SAME on every rank: it
  * adds a gather of the float pieces): also deliver the gathered -- with antialiasing downsampled
  * and overlaid -- depth-sort image.  On rank 0: rgb8_out (device, width*height*3 bytes, rows

@@ -131,6 +131,58 @@ def test_pipelined_frames_reuse_buffers_safely(O, ctx):
         assert np.array_equal(rgb, one_rgb.cpu().numpy())
 
 
+def test_cells_written_on_the_default_stream_are_seen_without_a_host_sync(ctx):
+    """The caller fills the cells (and zeroes the sample counter) on torch's default stream --
+    handle 0, which the C ABI's input_stream cannot name -- and renders at once: the frame must
+    be ordered after that work on the driver's non-blocking streams."""
+    from amrvolumerenderer_amd import runtime as rt
+    n = 96
+    lo, hi = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    from amrvolumerenderer_amd.types import AmrBox, ScalarTransform, VolumeBounds
+    bounds = VolumeBounds(lo, hi)
+    cells = torch.zeros((n, n, n), dtype=torch.float64, device=ctx.device)
+    box = AmrBox(lo, hi, cells)
+    tr = ScalarTransform(normalize_to_unit_range=True)
+    r = rt.NativeRenderer(0, [box], tr, bounds)
+    cam = scenes.default_camera()
+    torch.cuda.synchronize()
+    counter = torch.ones(1, dtype=torch.int64, device=ctx.device)
+    results = []
+    for value in (0.25, 0.75, 0.5):
+        # a long queue on the default stream, the cell fill at its very end
+        scratch = torch.zeros(1 << 26, device=ctx.device)
+        for _ in range(20):
+            scratch.add_(1.0)
+        cells.fill_(value)
+        counter.zero_()
+        img, rgb = r.render(128, 128, 0.5, 1, cam, draw_bounds=False, samples=counter,
+                            want_image=True)
+        # the caller's side of the contract: its next writes (and its read of the counter) are
+        # ordered after the frame's classify pass and march
+        default = torch.cuda.current_stream(ctx.device)
+        default.wait_stream(r.streams[0])
+        default.wait_stream(r.streams[1])
+        results.append((img, rgb, counter.clone()))
+    r.synchronize()
+    torch.cuda.synchronize()
+    fresh = []
+    for value in (0.25, 0.75, 0.5):
+        cells.fill_(value)
+        counter.zero_()
+        torch.cuda.synchronize()
+        img, rgb = r.render(128, 128, 0.5, 1, cam, draw_bounds=False, samples=counter,
+                            want_image=True)
+        r.synchronize()
+        torch.cuda.synchronize()
+        fresh.append((img, rgb, counter.clone()))
+    assert not torch.equal(fresh[0][0], fresh[1][0])
+    for (img, rgb, count), (want_img, want_rgb, want_count) in zip(results, fresh):
+        assert torch.equal(img.view(torch.int32), want_img.view(torch.int32))
+        assert torch.equal(rgb, want_rgb)
+        assert int(want_count.item()) > 0 and int(count.item()) == int(want_count.item())
+    r.close()
+
+
 def test_two_phase_plan_calls_equal_the_fused_call(ctx):
     """avr_classify_plan + avr_march_plan (either classified slot, classify on another
     context's stream) produce the same send buffer as avr_render_plan."""
