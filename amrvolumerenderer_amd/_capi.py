@@ -87,7 +87,11 @@ class FramePlanInfo(C.Structure):
         ("n_local_runs", C.c_int32), ("n_local_boxes", C.c_int32),
         ("n_pixels", C.c_int64), ("piece_begin", C.c_int64), ("piece_end", C.c_int64),
         ("send_floats", C.c_int64), ("recv_floats", C.c_int64),
+        ("piece_layout", C.c_int32), ("band_rows", C.c_int32),
     ]
+
+
+PIECES_CONTIGUOUS, PIECES_ROW_BANDS = 0, 1
 
 
 class RunInfo(C.Structure):
@@ -141,6 +145,9 @@ SIGNATURES = {
     "avr_frame_plan_create": (C.c_int, [C.POINTER(Box), _ip, C.c_int, C.c_int, C.c_int, _ip,
                                          C.POINTER(PaintParams), C.POINTER(Camera),
                                          C.POINTER(_vp)]),
+    "avr_frame_plan_create_pieces": (C.c_int, [C.POINTER(Box), _ip, C.c_int, C.c_int, C.c_int, _ip,
+                                                C.POINTER(PaintParams), C.POINTER(Camera),
+                                                C.c_int, C.c_int, C.POINTER(_vp)]),
     "avr_layered_plan_create": (C.c_int, [_fp, _ip, C.c_int, C.c_int, C.c_int, _ip, C.c_int,
                                            C.c_int, C.POINTER(_vp)]),
     "avr_pack_layers": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.c_int, _vp]),
@@ -168,6 +175,9 @@ SIGNATURES = {
     "avr_bbox_overlay": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(Camera), C.c_int, C.c_int, C.c_int, _i64, _i64, _vp,
                                     _vp]),
+    "avr_bbox_overlay_piece": (C.c_int, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(Camera), _vp, _vp]),
+    "avr_assemble_rows": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "avr_scene_scalar_stats": (C.c_int, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "avr_scene_transform_from_stats": (C.c_int, [C.POINTER(C.c_double), _i64, C.c_int, C.c_int,
                                                   C.POINTER(ScalarTransform),
@@ -206,6 +216,7 @@ SIGNATURES = {
     "avr_renderer_invalidate": (C.c_int, [_vp]),
     "avr_renderer_set_overlap": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_tighten": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_piece_layout": (C.c_int, [_vp, C.c_int, C.c_int]),
     "avr_renderer_set_classify_share": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_corun_state": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.c_int), C.POINTER(C.c_long)]),

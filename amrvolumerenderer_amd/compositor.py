@@ -29,7 +29,8 @@ class FramePlan:
 
     def __init__(self, all_boxes: Sequence[AmrBox], params: _capi.PaintParams,
                  camera: CameraParameters, rank: int = 0, n_ranks: int = 1,
-                 group_order: Optional[Sequence[int]] = None, _box_array=None, _owner_array=None):
+                 group_order: Optional[Sequence[int]] = None, _box_array=None, _owner_array=None,
+                 piece_layout: int = _capi.PIECES_CONTIGUOUS, band_rows: int = 1):
         n = len(all_boxes)
         # the C arrays can be prepared once per scene and re-used for every frame
         self._boxes = _box_array if _box_array is not None else make_box_array(all_boxes)
@@ -39,9 +40,9 @@ class FramePlan:
             group = (C.c_int32 * n_ranks)(*[int(g) for g in group_order])
         ccam = camera.to_c()
         handle = C.c_void_p()
-        _capi.check(_capi.lib().avr_frame_plan_create(
+        _capi.check(_capi.lib().avr_frame_plan_create_pieces(
             self._boxes, self._owner, n, int(n_ranks), int(rank), group, C.byref(params),
-            C.byref(ccam), C.byref(handle)))
+            C.byref(ccam), int(piece_layout), int(band_rows), C.byref(handle)))
         self._handle = handle
         self._params = params  # keeps the colour map alive
         info = _capi.FramePlanInfo()
@@ -56,6 +57,8 @@ class FramePlan:
         self.piece_end = info.piece_end
         self.send_floats = info.send_floats
         self.recv_floats = info.recv_floats
+        self.piece_layout = info.piece_layout
+        self.band_rows = info.band_rows
         self.width = int(params.width)
         self.height = int(params.height)
         self._read_splits()

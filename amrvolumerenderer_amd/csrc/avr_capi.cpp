@@ -278,7 +278,8 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const int32_t* run_end, int n_runs, int n_pieces,
            const std::vector<avr::RunRectDev>& run_rects,
            const std::vector<avr::RunBlockDev>& run_blocks,
-           const avr::RunSpanDev* run_spans_dev, avr_scene* scene, int slot,
+           const std::vector<avr::RunSpanDev>* run_spans, const avr::PieceMapDev& pieces,
+           avr_scene* scene, int slot,
            float* out_layers, uint64_t* samples_out, avr::FramePlan* cached) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
   require(slot >= 0 && slot < AVR_CLASSIFIED_SLOTS, "classified slot out of range");
@@ -353,10 +354,11 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     avr::build_march_items(plan, box_order, run_end, n_runs, run_rects, &items);
     bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
              items.size() * sizeof(avr::MarchItemDev) +
-             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev);
+             run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev) +
+             (run_spans != nullptr ? run_spans->size() * sizeof(avr::RunSpanDev) : 0);
   }
   avr::StagingRing& staging = ctx->staging;
-  staging.begin(bytes, 8);
+  staging.begin(bytes, 9);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
   if (phases & kClassify) {
     launch.tile_begin_dev =
@@ -372,7 +374,10 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.n_pieces = n_pieces;
     launch.run_rects_dev = staging.add(run_rects.data(), run_rects.size());
     launch.run_blocks_dev = staging.add(run_blocks.data(), run_blocks.size());
-    launch.run_spans_dev = run_spans_dev;
+    launch.run_spans_dev = (run_spans != nullptr && !run_spans->empty())
+                               ? staging.add(run_spans->data(), run_spans->size())
+                               : nullptr;
+    launch.pieces = pieces;
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
     launch.counters = reinterpret_cast<unsigned long long*>(ctx->march_counters);
@@ -592,8 +597,9 @@ int avr_paint_box(avr_context* ctx, const avr_box* box, const avr_scalar_transfo
     require(params->width > 0 && params->height > 0, "image width and height must be positive");
     avr::dense_run_tables(params->width, params->height, 1, 1, &rects, &blocks);
     return render(ctx, kClassify | kMarch, box, 1, *transform, *params, *camera, order, 1, run_end,
-                  1, 1, rects, blocks, nullptr, &ctx->scratch_scene, 0, out_rgbad, samples_out,
-                  nullptr);
+                  1, 1, rects, blocks, nullptr,
+                  avr::make_piece_map(AVR_PIECES_CONTIGUOUS, 1, 1, params->width, params->height),
+                  &ctx->scratch_scene, 0, out_rgbad, samples_out, nullptr);
   });
 }
 
@@ -628,13 +634,16 @@ int avr_render_runs(avr_context* ctx, const avr_scene* scene, const avr_paint_pa
     return render(ctx, kClassify | kMarch, scene->boxes.data(),
                   static_cast<int>(scene->boxes.size()), scene->transform, *params, *camera,
                   box_order, n_order, run_end, n_runs, n_pieces, rects, blocks, nullptr,
+                  avr::make_piece_map(AVR_PIECES_CONTIGUOUS, 1, n_pieces, params->width,
+                                      params->height),
                   const_cast<avr_scene*>(scene), 0, out_layers, samples_out, nullptr);
   });
 }
 
-int avr_frame_plan_create(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
-                          int rank, const int32_t* group_order, const avr_paint_params* params,
-                          const avr_camera* camera, avr_frame_plan** out_plan) {
+int avr_frame_plan_create_pieces(const avr_box* all_boxes, const int32_t* owner, int n_boxes,
+                                 int n_ranks, int rank, const int32_t* group_order,
+                                 const avr_paint_params* params, const avr_camera* camera,
+                                 int piece_layout, int band_rows, avr_frame_plan** out_plan) {
   return guarded([&]() -> int {
     require(out_plan != nullptr && params != nullptr && camera != nullptr, "null argument");
     *out_plan = nullptr;
@@ -643,7 +652,7 @@ int avr_frame_plan_create(const avr_box* all_boxes, const int32_t* owner, int n_
     auto* plan = new avr_frame_plan();
     try {
       avr::build_frame_plan(all_boxes, owner, n_boxes, n_ranks, rank, group_order, *params, *camera,
-                            plan);
+                            piece_layout, band_rows, plan);
     } catch (...) {
       delete plan;
       throw;
@@ -651,6 +660,13 @@ int avr_frame_plan_create(const avr_box* all_boxes, const int32_t* owner, int n_
     *out_plan = plan;
     return AVR_OK;
   });
+}
+
+int avr_frame_plan_create(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
+                          int rank, const int32_t* group_order, const avr_paint_params* params,
+                          const avr_camera* camera, avr_frame_plan** out_plan) {
+  return avr_frame_plan_create_pieces(all_boxes, owner, n_boxes, n_ranks, rank, group_order, params,
+                                      camera, AVR_PIECES_CONTIGUOUS, 1, out_plan);
 }
 
 int avr_layered_plan_create(const float* hints, const int32_t* owner, int n_layers, int n_ranks,
@@ -664,7 +680,7 @@ int avr_layered_plan_create(const float* hints, const int32_t* owner, int n_laye
       plan->params.width = width;
       plan->params.height = height;
       avr::build_layer_plan(n_layers, hints, owner, nullptr, n_ranks, rank, group_order, width,
-                            height, plan);
+                            height, AVR_PIECES_CONTIGUOUS, 1, plan);
     } catch (...) {
       delete plan;
       throw;
@@ -682,6 +698,8 @@ int avr_pack_layers(avr_context* ctx, const avr_frame_plan* plan, const float* c
     require(n_local_layers == plan->info.n_local_boxes, "layer count does not match the plan");
     require(n_local_layers == 0 || local_layers != nullptr, "null layer list");
     require(plan->info.send_floats == 0 || send_buffer != nullptr, "null send buffer");
+    require(plan->pieces.layout == avr::kPiecesContiguous,
+            "avr_pack_layers needs the reference's contiguous pieces");
     const int n_ranks = plan->info.n_ranks;
     const int64_t width = plan->params.width;
     int start = 0;
@@ -718,14 +736,7 @@ int avr_pack_layers(avr_context* ctx, const avr_frame_plan* plan, const float* c
   });
 }
 
-void avr_frame_plan_destroy(avr_frame_plan* plan) {
-  if (plan == nullptr) return;
-  // (the caller has made sure that no launch still reads the plan's device tables: the frame
-  // driver drains its streams before it lets go of a tightened plan)
-  if (plan->send_spans_dev != nullptr) (void)hipFree(plan->send_spans_dev);
-  if (plan->recv_spans_dev != nullptr) (void)hipFree(plan->recv_spans_dev);
-  delete plan;
-}
+void avr_frame_plan_destroy(avr_frame_plan* plan) { delete plan; }
 
 int avr_frame_plan_get_info(const avr_frame_plan* plan, avr_frame_plan_info* out) {
   return guarded([&]() -> int {
@@ -824,24 +835,6 @@ int avr_frame_plan_recv_block(const avr_frame_plan* plan, int global_run, int64_
   });
 }
 
-// The span tables of a tightened plan live on the device for the plan's lifetime: one blocking
-// copy when first needed (streams created non-blocking are not synchronised by it).
-static const avr::RunSpanDev* resident_spans(const avr_context* ctx,
-                                             const std::vector<avr::RunSpanDev>& host,
-                                             void** device_copy, const avr_frame_plan* plan) {
-  if (host.empty()) return nullptr;
-  if (*device_copy == nullptr) {
-    require(plan->spans_device < 0 || plan->spans_device == ctx->device,
-            "a tightened plan is bound to the device that used it first");
-    plan->spans_device = ctx->device;
-    const size_t bytes = host.size() * sizeof(avr::RunSpanDev);
-    avr::hip_check(hipMalloc(device_copy, bytes), "hipMalloc(span table)");
-    avr::hip_check(hipMemcpy(*device_copy, host.data(), bytes, hipMemcpyHostToDevice),
-                   "hipMemcpy(span table)");
-  }
-  return static_cast<const avr::RunSpanDev*>(*device_copy);
-}
-
 static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                       const avr_frame_plan* plan, int slot, float* send_buffer,
                       uint64_t* samples_out) {
@@ -855,9 +848,8 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                   scene->transform, plan->params, plan->camera, plan->local_order.data(),
                   static_cast<int>(plan->local_order.size()), plan->local_run_end.data(),
                   plan->info.n_local_runs, plan->info.n_ranks, plan->local_rects, plan->send_blocks,
-                  ((phases & kMarch) && plan->tightened)
-                      ? resident_spans(ctx, plan->send_spans, &plan->send_spans_dev, plan)
-                      : nullptr,
+                  ((phases & kMarch) && plan->tightened) ? &plan->send_spans : nullptr,
+                  plan->pieces,
                   const_cast<avr_scene*>(scene), slot, send_buffer, samples_out,
                   &const_cast<avr_frame_plan*>(plan)->prologue);
   });
@@ -903,15 +895,18 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
     require(plan->info.recv_floats == 0 || recv_buffer != nullptr, "null receive buffer");
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
     avr::FoldLaunch launch;
+    const bool spans = plan->tightened && !plan->recv_spans.empty();
     ctx->staging.begin(plan->global_rects.size() * sizeof(avr::RunRectDev) +
-                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev),
-                       2);
+                           plan->recv_blocks.size() * sizeof(avr::RunBlockDev) +
+                           (spans ? plan->recv_spans.size() * sizeof(avr::RunSpanDev) : 0),
+                       3);
     launch.run_rects_dev = ctx->staging.add(plan->global_rects.data(), plan->global_rects.size());
     launch.run_blocks_dev = ctx->staging.add(plan->recv_blocks.data(), plan->recv_blocks.size());
     launch.run_spans_dev =
-        plan->tightened ? resident_spans(ctx, plan->recv_spans, &plan->recv_spans_dev, plan)
-                        : nullptr;
+        spans ? ctx->staging.add(plan->recv_spans.data(), plan->recv_spans.size()) : nullptr;
     ctx->staging.commit(ctx->stream);
+    launch.pieces = plan->pieces;
+    launch.piece = plan->piece_of_rank[static_cast<size_t>(plan->info.rank)];
     launch.width = plan->params.width;
     launch.piece_begin = plan->info.piece_begin;
     launch.piece_end = plan->info.piece_end;
@@ -986,7 +981,40 @@ int avr_bbox_overlay(avr_context* ctx, const double bounds_min[3], const double 
     require(image != nullptr, "null image");
     avr::OverlayPlan plan;
     avr::plan_overlay(bounds_min, bounds_max, *camera, sqrt_antialiasing, width, height, &plan);
-    return avr::launch_overlay(plan, width, pixel_begin, pixel_end, image, rgb8, ctx->stream);
+    return avr::launch_overlay(plan, width, pixel_begin, pixel_end, nullptr, 0, image, rgb8,
+                               ctx->stream);
+  });
+}
+
+int avr_bbox_overlay_piece(avr_context* ctx, const avr_frame_plan* plan, const double bounds_min[3],
+                           const double bounds_max[3], const avr_camera* camera, float* piece,
+                           uint8_t* rgb8) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(plan != nullptr && bounds_min != nullptr && bounds_max != nullptr && camera != nullptr,
+            "null argument");
+    const int64_t begin = plan->info.piece_begin, end = plan->info.piece_end;
+    if (end <= begin) return AVR_OK;
+    require(piece != nullptr, "null image");
+    avr::OverlayPlan overlay;
+    avr::plan_overlay(bounds_min, bounds_max, *camera, 1, plan->params.width, plan->params.height,
+                      &overlay);
+    return avr::launch_overlay(overlay, plan->params.width, begin, end, &plan->pieces,
+                               plan->piece_of_rank[static_cast<size_t>(plan->info.rank)], piece,
+                               rgb8, ctx->stream);
+  });
+}
+
+int avr_assemble_rows(avr_context* ctx, const avr_frame_plan* plan, const void* gathered,
+                      int bytes_per_pixel, int flip, void* image) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(plan != nullptr && bytes_per_pixel > 0, "invalid argument");
+    if (plan->info.n_pixels == 0) return AVR_OK;
+    require(gathered != nullptr && image != nullptr && gathered != image, "invalid image pointers");
+    return avr::launch_assemble_rows(plan->pieces, static_cast<const uint8_t*>(gathered),
+                                     static_cast<int64_t>(plan->params.width) * bytes_per_pixel,
+                                     flip, static_cast<uint8_t*>(image), ctx->stream);
   });
 }
 

@@ -334,11 +334,11 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
     const int n = comm->n_ranks, me = comm->rank;
     require(bytes_per_pixel > 0 && root >= 0 && root < n, "invalid argument");
     const int64_t n_pixels = plan->info.n_pixels;
-    const int64_t piece_size = n_pixels / n;  // getPieceRange (DirectSendBase.cpp:59-74)
+    // where a rank's piece sits in the gathered buffer: its pixel range of the image
+    // (getPieceRange, DirectSendBase.cpp:59-74) or, with row bands, piece after piece
+    // (avr_assemble_rows restores the image order)
     auto piece_range = [&](int rank, int64_t* begin, int64_t* end) {
-      const int k = plan->piece_of_rank[static_cast<size_t>(rank)];
-      *begin = piece_size * k;
-      *end = (k < n - 1) ? *begin + piece_size : n_pixels;
+      avr::piece_pixel_range(plan->pieces, plan->piece_of_rank[static_cast<size_t>(rank)], begin, end);
     };
     int64_t my_begin = 0, my_end = 0;
     piece_range(me, &my_begin, &my_end);

@@ -318,50 +318,78 @@ bool fold_is_exact(const BoxDev& dev) {
 // lies inside.  Pixels outside produce the empty layer pixel (0,0,0,0,+inf) in the reference
 // (slab miss, or an intersection interval entirely behind the eye: VolumePainter.cpp:802-837),
 // which is an exact identity of the depth-sort blend, so skipping them does not change bits.
-void screen_rect(const avr_box& box, const avr_camera& camera, const CameraBasis& basis,
-                 const FrameConsts& fc, int32_t rect[4]) {
-  const Vec3d eye = from(camera.eye);
+// The projected corners are kept with it: the per-row extents are the convex hull of the same
+// eight points.
+struct Projector {
+  CameraBasis basis;
+  Vec3d eye;
+  double tan_x = 0.0, tan_y = 0.0;
+  int width = 0, height = 0;
+};
+
+Projector make_projector(const avr_camera& camera, float tan_half_fov, float aspect, int width,
+                         int height) {
+  Projector pr;
+  pr.basis = camera_basis(camera);
+  pr.eye = from(camera.eye);
+  pr.tan_y = static_cast<double>(tan_half_fov);
+  pr.tan_x = pr.tan_y * static_cast<double>(aspect);
+  pr.width = width;
+  pr.height = height;
+  return pr;
+}
+
+// (the float tangent and aspect the kernel's ray set-up uses)
+Projector make_projector(const avr_camera& camera, int width, int height) {
+  return make_projector(camera, std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f),
+                        static_cast<float>(width) / static_cast<float>(std::max(height, 1)), width,
+                        height);
+}
+
+void project_box(const avr_box& box, const Projector& pr, BoxFootprint* out) {
   double lo_x = std::numeric_limits<double>::infinity(), hi_x = -lo_x;
   double lo_y = lo_x, hi_y = -lo_x;
   bool full = false;
-  const double tan_y = static_cast<double>(fc.tan_half_fov);
-  const double tan_x = tan_y * static_cast<double>(fc.aspect);
   // Corners are tested after the float cast the kernel applies (VolumePainter.cpp:658-665).
   for (int corner = 0; corner < 8 && !full; ++corner) {
     const Vec3d p{
         static_cast<double>(static_cast<float>((corner & 1) ? box.max_corner[0] : box.min_corner[0])),
         static_cast<double>(static_cast<float>((corner & 2) ? box.max_corner[1] : box.min_corner[1])),
         static_cast<double>(static_cast<float>((corner & 4) ? box.max_corner[2] : box.min_corner[2]))};
-    const Vec3d v = sub(p, eye);
-    const double depth = dot(v, basis.forward);
+    const Vec3d v = sub(p, pr.eye);
+    const double depth = dot(v, pr.basis.forward);
     if (!(depth > 1e-6) || !std::isfinite(depth)) {
       full = true;
       break;
     }
-    const double ndc_x = dot(v, basis.right) / (depth * tan_x);
-    const double ndc_y = dot(v, basis.up) / (depth * tan_y);
-    const double px = (ndc_x + 1.0) * 0.5 * fc.width - 0.5;
-    const double py = (ndc_y + 1.0) * 0.5 * fc.height - 0.5;
+    const double ndc_x = dot(v, pr.basis.right) / (depth * pr.tan_x);
+    const double ndc_y = dot(v, pr.basis.up) / (depth * pr.tan_y);
+    const double px = (ndc_x + 1.0) * 0.5 * pr.width - 0.5;
+    const double py = (ndc_y + 1.0) * 0.5 * pr.height - 0.5;
     if (!std::isfinite(px) || !std::isfinite(py)) {
       full = true;
       break;
     }
+    out->px[corner] = px;
+    out->py[corner] = py;
     lo_x = std::min(lo_x, px);
     hi_x = std::max(hi_x, px);
     lo_y = std::min(lo_y, py);
     hi_y = std::max(hi_y, py);
   }
-  if (full) {
+  int32_t* rect = out->rect;
+  out->whole = full;
+  if (full) {  // the box reaches behind the eye: the whole image, on every row
     rect[0] = 0;
     rect[1] = 0;
-    rect[2] = fc.width - 1;
-    rect[3] = fc.height - 1;
+    rect[2] = pr.width - 1;
+    rect[3] = pr.height - 1;
     return;
   }
   constexpr double margin = 2.0;  // pixels; float rounding of the ray setup is << 1 pixel
   const double x0 = std::floor(lo_x - margin), x1 = std::ceil(hi_x + margin);
   const double y0 = std::floor(lo_y - margin), y1 = std::ceil(hi_y + margin);
-  if (x1 < 0.0 || y1 < 0.0 || x0 > fc.width - 1.0 || y0 > fc.height - 1.0) {
+  if (x1 < 0.0 || y1 < 0.0 || x0 > pr.width - 1.0 || y0 > pr.height - 1.0) {
     rect[0] = 0;
     rect[1] = 0;
     rect[2] = -1;
@@ -370,18 +398,181 @@ void screen_rect(const avr_box& box, const avr_camera& camera, const CameraBasis
   }
   rect[0] = static_cast<int32_t>(std::max(x0, 0.0));
   rect[1] = static_cast<int32_t>(std::max(y0, 0.0));
-  rect[2] = static_cast<int32_t>(std::min(x1, fc.width - 1.0));
-  rect[3] = static_cast<int32_t>(std::min(y1, fc.height - 1.0));
+  rect[2] = static_cast<int32_t>(std::min(x1, pr.width - 1.0));
+  rect[3] = static_cast<int32_t>(std::min(y1, pr.height - 1.0));
+}
+
+void screen_rect(const avr_box& box, const avr_camera& camera, const CameraBasis& basis,
+                 const FrameConsts& fc, int32_t rect[4]) {
+  Projector pr;
+  pr.basis = basis;
+  pr.eye = from(camera.eye);
+  pr.tan_y = static_cast<double>(fc.tan_half_fov);
+  pr.tan_x = pr.tan_y * static_cast<double>(fc.aspect);
+  pr.width = fc.width;
+  pr.height = fc.height;
+  BoxFootprint fp;
+  project_box(box, pr, &fp);
+  std::copy(fp.rect, fp.rect + 4, rect);
 }
 
 }  // namespace
 
-// Conservative per-row extent of a box on screen: rows rect[1]..rect[3] of its conservative
-// rectangle (box_screen_rect), for each the pixel columns its projection can touch.  The
-// projection of a box in front of the eye lies inside the convex hull of its projected corners;
-// per row the hull's x-extent over the band of that row (+- the same 2-pixel margin as the
-// rectangle) is taken from the 28 corner-to-corner segments, which contain the hull's edges.
+// Conservative per-row extent of a box on screen: for rows of its conservative rectangle
+// (box_screen_rect) the pixel columns its projection can touch.  The projection of a box in front
+// of the eye is the convex hull of its projected corners; per row the hull's x-extent over the
+// band of that row (+- the same 2-pixel margin as the rectangle) is taken from the hull's edges.
 // A box that reaches behind the eye keeps its whole rectangle on every row.
+//
+// Cost matters: for N > 1 this runs for every box of every frame whose camera is new (the
+// exchange layout of a frame plan is tightened when the plan is made).  Every hull edge visits
+// only the rows whose band it reaches (two chains: ~2 edge visits per row instead of the 28
+// corner-to-corner segments' ~14), rows the caller does not need are skipped (RowSet), and the
+// interior rows of an edge -- both band boundaries cut it -- are two multiply-adds each.
+namespace {
+
+// Andrew's monotone chain over (y, x); collinear points are dropped.  Returns the hull's size
+// (counter-clockwise, 1 or 2 for degenerate inputs).
+int convex_hull8(const double* px, const double* py, int hull[16]) {
+  int idx[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+  std::sort(idx, idx + 8, [&](int a, int b) {
+    return py[a] < py[b] || (py[a] == py[b] && px[a] < px[b]);
+  });
+  auto cross = [&](int o, int a, int b) {
+    return (px[a] - px[o]) * (py[b] - py[o]) - (py[a] - py[o]) * (px[b] - px[o]);
+  };
+  int n = 0;
+  for (int i = 0; i < 8; ++i) {
+    while (n >= 2 && cross(hull[n - 2], hull[n - 1], idx[i]) <= 0.0) --n;
+    hull[n++] = idx[i];
+  }
+  const int lower = n + 1;
+  for (int i = 6; i >= 0; --i) {
+    while (n >= lower && cross(hull[n - 2], hull[n - 1], idx[i]) <= 0.0) --n;
+    hull[n++] = idx[i];
+  }
+  return std::max(n - 1, 1);  // the last point repeats the first
+}
+
+constexpr double kRowMargin = 2.0;  // pixels, as screen_rect
+
+}  // namespace
+
+void merge_footprint_rows(const BoxFootprint& fp, const RowSet& rows, int y_base, int32_t* out_x0,
+                          int32_t* out_x1) {
+  const int32_t* rect = fp.rect;
+  if (rect[2] < rect[0] || rect[3] < rect[1]) return;
+  const int y_lo = std::max(rect[1], rows.lo), y_hi = std::min(rect[3], rows.hi);
+  if (y_hi < y_lo) return;
+  auto merge = [&](int y, int32_t x0, int32_t x1) {
+    if (x1 < x0) return;
+    int32_t& m0 = out_x0[y - y_base];
+    int32_t& m1 = out_x1[y - y_base];
+    if (m1 < m0) {
+      m0 = x0;
+      m1 = x1;
+    } else {
+      m0 = std::min(m0, x0);
+      m1 = std::max(m1, x1);
+    }
+  };
+  if (fp.whole) {  // the whole rectangle on every needed row
+    for_rows(rows, y_lo, y_hi, [&](int a, int b) {
+      for (int y = a; y <= b; ++y) merge(y, rect[0], rect[2]);
+    });
+    return;
+  }
+  const double* px = fp.px;
+  const double* py = fp.py;
+  // per needed row the extent of the hull's part inside the row's band [y - 0.5 - m, y + 0.5 + m]
+  const int n_rows = y_hi - y_lo + 1;
+  thread_local std::vector<double> lo_scratch, hi_scratch;
+  if (lo_scratch.size() < static_cast<size_t>(n_rows)) {
+    lo_scratch.resize(static_cast<size_t>(n_rows));
+    hi_scratch.resize(static_cast<size_t>(n_rows));
+  }
+  double* lo = lo_scratch.data();
+  double* hi = hi_scratch.data();
+  for_rows(rows, y_lo, y_hi, [&](int a, int b) {
+    for (int y = a; y <= b; ++y) {
+      lo[y - y_lo] = std::numeric_limits<double>::infinity();
+      hi[y - y_lo] = -std::numeric_limits<double>::infinity();
+    }
+  });
+  int hull[16];
+  const int n_hull = convex_hull8(px, py, hull);
+  const double half = 0.5 + kRowMargin;
+  for (int e = 0; e < n_hull; ++e) {
+    double ya = py[hull[e]], yb = py[hull[(e + 1) % n_hull]];
+    double xa = px[hull[e]], xb = px[hull[(e + 1) % n_hull]];
+    if (ya > yb) {
+      std::swap(ya, yb);
+      std::swap(xa, xb);
+    }
+    // rows whose band the edge reaches, clamped in double before the cast (a box just in front
+    // of the eye can project far outside any integer range)
+    const double first = std::max(std::ceil(ya - half), static_cast<double>(y_lo));
+    const double last = std::min(std::floor(yb + half), static_cast<double>(y_hi));
+    if (!(first <= last)) continue;
+    const int r_first = static_cast<int>(first), r_last = static_cast<int>(last);
+    const double slope = (yb > ya) ? (xb - xa) / (yb - ya) : 0.0;
+    // interior rows: the band's lower boundary lies above ya and its upper boundary below yb, so
+    // both ends are interpolated:  ya < y - half  and  y + half < yb.  (Clamped in double before
+    // the cast: the corners of a box far off screen are unbounded.)
+    const int in_first = static_cast<int>(
+        std::clamp(std::floor(ya + half) + 1.0, static_cast<double>(r_first), r_last + 1.0));
+    const int in_last = static_cast<int>(
+        std::clamp(std::ceil(yb - half) - 1.0, r_first - 1.0, static_cast<double>(r_last)));
+    auto generic = [&](int y) {
+      const double band_lo = static_cast<double>(y) - half, band_hi = static_cast<double>(y) + half;
+      if (yb < band_lo || ya > band_hi) return;
+      double x_first = xa, x_last = xb;
+      if (yb > ya) {
+        if (ya < band_lo) x_first = xa + (band_lo - ya) * slope;
+        if (yb > band_hi) x_last = xa + (band_hi - ya) * slope;
+      }
+      lo[y - y_lo] = std::min(lo[y - y_lo], std::min(x_first, x_last));
+      hi[y - y_lo] = std::max(hi[y - y_lo], std::max(x_first, x_last));
+    };
+    for_rows(rows, r_first, r_last, [&](int a, int b) {
+      int y = a;
+      for (const int end = std::min(b, in_first - 1); y <= end; ++y) generic(y);
+      for (const int end = std::min(b, in_last); y <= end; ++y) {
+        // the expressions of `generic` with both ends interpolated
+        const double x_first = xa + ((static_cast<double>(y) - half) - ya) * slope;
+        const double x_last = xa + ((static_cast<double>(y) + half) - ya) * slope;
+        lo[y - y_lo] = std::min(lo[y - y_lo], std::min(x_first, x_last));
+        hi[y - y_lo] = std::max(hi[y - y_lo], std::max(x_first, x_last));
+      }
+      for (; y <= b; ++y) generic(y);
+    });
+  }
+  for_rows(rows, y_lo, y_hi, [&](int a, int b) {
+    for (int y = a; y <= b; ++y) {
+      const double l = lo[y - y_lo], h = hi[y - y_lo];
+      if (!(h >= l)) continue;  // the hull misses the band: nothing on the row
+      const double x0 = std::max(std::floor(l - kRowMargin), static_cast<double>(rect[0]));
+      const double x1 = std::min(std::ceil(h + kRowMargin), static_cast<double>(rect[2]));
+      if (x1 < x0) continue;
+      merge(y, static_cast<int32_t>(x0), static_cast<int32_t>(x1));
+    }
+  });
+}
+
+void box_footprints(const avr_box* boxes, int n_boxes, const avr_camera& camera, int width,
+                    int height, BoxFootprint* out) {
+  const Projector pr = make_projector(camera, width, height);
+  for (int b = 0; b < n_boxes; ++b) {
+    if (boxes[b].dims[0] <= 0 || boxes[b].dims[1] <= 0 || boxes[b].dims[2] <= 0) {
+      out[b].whole = false;
+      out[b].rect[0] = out[b].rect[1] = 0;
+      out[b].rect[2] = out[b].rect[3] = -1;
+      continue;
+    }
+    project_box(boxes[b], pr, &out[b]);
+  }
+}
+
 void box_row_spans(const avr_box& box, const avr_camera& camera, int width, int height,
                    const int32_t rect[4], std::vector<int32_t>* row_x0,
                    std::vector<int32_t>* row_x1) {
@@ -389,87 +580,18 @@ void box_row_spans(const avr_box& box, const avr_camera& camera, int width, int 
   row_x1->clear();
   if (rect[2] < rect[0] || rect[3] < rect[1]) return;
   const int rows = rect[3] - rect[1] + 1;
-  row_x0->assign(static_cast<size_t>(rows), rect[0]);
-  row_x1->assign(static_cast<size_t>(rows), rect[2]);
-  const CameraBasis basis = camera_basis(camera);
-  const Vec3d eye = from(camera.eye);
-  // (the float tangent and aspect the kernel's ray set-up and screen_rect use)
-  const double tan_y = static_cast<double>(std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f));
-  const double aspect = static_cast<double>(static_cast<float>(width) /
-                                            static_cast<float>(std::max(height, 1)));
-  const double tan_x = tan_y * aspect;
-  double px[8], py[8];
-  for (int corner = 0; corner < 8; ++corner) {
-    const Vec3d p{
-        static_cast<double>(static_cast<float>((corner & 1) ? box.max_corner[0] : box.min_corner[0])),
-        static_cast<double>(static_cast<float>((corner & 2) ? box.max_corner[1] : box.min_corner[1])),
-        static_cast<double>(static_cast<float>((corner & 4) ? box.max_corner[2] : box.min_corner[2]))};
-    const Vec3d v = sub(p, eye);
-    const double depth = dot(v, basis.forward);
-    if (!(depth > 1e-6) || !std::isfinite(depth)) return;  // whole rectangle
-    px[corner] = (dot(v, basis.right) / (depth * tan_x) + 1.0) * 0.5 * width - 0.5;
-    py[corner] = (dot(v, basis.up) / (depth * tan_y) + 1.0) * 0.5 * height - 0.5;
-    if (!std::isfinite(px[corner]) || !std::isfinite(py[corner])) return;
-  }
-  constexpr double margin = 2.0;  // as screen_rect
-  // per row the extent of the segments' parts inside the row's band [y - 0.5 - m, y + 0.5 + m];
-  // every segment only visits the rows whose band it reaches
-  std::vector<double> lo(static_cast<size_t>(rows), std::numeric_limits<double>::infinity());
-  std::vector<double> hi(static_cast<size_t>(rows), -std::numeric_limits<double>::infinity());
-  for (int a = 0; a < 8; ++a) {
-    for (int b = a + 1; b < 8; ++b) {
-      double ya = py[a], yb = py[b], xa = px[a], xb = px[b];
-      if (ya > yb) {
-        std::swap(ya, yb);
-        std::swap(xa, xb);
-      }
-      const double first = std::ceil(ya - 0.5 - margin), last = std::floor(yb + 0.5 + margin);
-      const int r_lo = static_cast<int>(std::max(first - rect[1], 0.0));
-      const int r_hi = static_cast<int>(std::min(last - rect[1], static_cast<double>(rows - 1)));
-      const double slope = (yb > ya) ? (xb - xa) / (yb - ya) : 0.0;
-      for (int r = r_lo; r <= r_hi; ++r) {
-        const double band_lo = static_cast<double>(rect[1] + r) - 0.5 - margin;
-        const double band_hi = static_cast<double>(rect[1] + r) + 0.5 + margin;
-        if (yb < band_lo || ya > band_hi) continue;
-        double x_first = xa, x_last = xb;
-        if (yb > ya) {
-          if (ya < band_lo) x_first = xa + (band_lo - ya) * slope;
-          if (yb > band_hi) x_last = xa + (band_hi - ya) * slope;
-        }
-        lo[static_cast<size_t>(r)] = std::min(lo[static_cast<size_t>(r)], std::min(x_first, x_last));
-        hi[static_cast<size_t>(r)] = std::max(hi[static_cast<size_t>(r)], std::max(x_first, x_last));
-      }
-    }
-  }
-  for (int r = 0; r < rows; ++r) {
-    if (!(hi[static_cast<size_t>(r)] >= lo[static_cast<size_t>(r)])) {
-      (*row_x0)[static_cast<size_t>(r)] = 0;  // the hull misses the band: nothing on the row
-      (*row_x1)[static_cast<size_t>(r)] = -1;
-      continue;
-    }
-    const double x0 = std::floor(lo[static_cast<size_t>(r)] - margin);
-    const double x1 = std::ceil(hi[static_cast<size_t>(r)] + margin);
-    (*row_x0)[static_cast<size_t>(r)] =
-        static_cast<int32_t>(std::max(x0, static_cast<double>(rect[0])));
-    (*row_x1)[static_cast<size_t>(r)] =
-        static_cast<int32_t>(std::min(x1, static_cast<double>(rect[2])));  // < x0: nothing
-  }
+  row_x0->assign(static_cast<size_t>(rows), 0);
+  row_x1->assign(static_cast<size_t>(rows), -1);
+  BoxFootprint fp;
+  box_footprints(&box, 1, camera, width, height, &fp);
+  merge_footprint_rows(fp, RowSet{}, rect[1], row_x0->data(), row_x1->data());
 }
 
 void box_screen_rect(const avr_box& box, const avr_camera& camera, int width, int height,
                      int32_t rect[4]) {
-  FrameConsts fc;
-  std::memset(&fc, 0, sizeof(fc));
-  fc.width = width;
-  fc.height = height;
-  fc.aspect = static_cast<float>(width) / static_cast<float>(std::max(height, 1));
-  fc.tan_half_fov = std::tan(camera.fov_y_degrees * 0.5f * kPi / 180.0f);
-  if (box.dims[0] <= 0 || box.dims[1] <= 0 || box.dims[2] <= 0) {
-    rect[0] = rect[1] = 0;
-    rect[2] = rect[3] = -1;
-    return;
-  }
-  screen_rect(box, camera, camera_basis(camera), fc, rect);
+  BoxFootprint fp;
+  box_footprints(&box, 1, camera, width, height, &fp);
+  std::copy(fp.rect, fp.rect + 4, rect);
 }
 
 void build_color_table(float alpha_scale, float normalization_factor, const float scalar_range[2],

@@ -67,6 +67,52 @@ struct FrameConsts {
 constexpr int kBrickX = 8, kBrickY = 4, kBrickZ = 4, kBrickBytes = 128;
 constexpr int kClassifyChunk = 128;  // cells of one x-row handled by one classify workgroup
 
+#if defined(__HIP__)
+#define AVR_HD __host__ __device__
+#else
+#define AVR_HD
+#endif
+
+// How the image's pixels are dealt to the N pieces of the direct-send exchange (one piece per
+// rank of the compositing group).
+//   kPiecesContiguous  the reference's partition: piece k = pixels [k * floor(P/N), ...), the
+//                      last piece takes the remainder (getPieceRange, DirectSendBase.cpp:59-74).
+//                      What Compositor::compose promises its caller, so the plugin keeps it.
+//   kPiecesRowBands    bands of `band_rows` image rows dealt round-robin: band b belongs to piece
+//                      b % N.  The scene covers a compact part of the screen, so contiguous
+//                      pieces leave some ranks with nothing to receive and fold and others with
+//                      everything (config-4, N = 8: 36.5 MB against 0); dealt bands give every
+//                      rank the same share of every region.  Per-pixel results do not depend on
+//                      which rank folds a pixel, so the gathered image is the same bit for bit;
+//                      only the frame driver (whose caller sees the gathered image, never the
+//                      pieces) uses it.
+// A piece's rows are numbered 0, 1, ... in image order ("piece rows"); with contiguous pieces a
+// piece row IS the image row (blocks count rows from the image's row 0 there).
+enum PieceLayout : int32_t { kPiecesContiguous = 0, kPiecesRowBands = 1 };
+struct PieceMapDev {
+  int32_t layout = kPiecesContiguous;
+  int32_t band_rows = 1;
+  int32_t n_pieces = 1;
+  int32_t width = 0, height = 0;
+  int32_t pad_ = 0;
+  int64_t piece_size = 0;  // kPiecesContiguous: floor(P / N)
+};
+AVR_HD inline int piece_of_row(const PieceMapDev& m, int y) { return (y / m.band_rows) % m.n_pieces; }
+// position of image row y among the rows of its piece (kPiecesRowBands)
+AVR_HD inline int piece_row_of(const PieceMapDev& m, int y) {
+  return (y / (m.band_rows * m.n_pieces)) * m.band_rows + y % m.band_rows;
+}
+// image row of piece row j of piece k (kPiecesRowBands)
+AVR_HD inline int image_row_of(const PieceMapDev& m, int k, int j) {
+  return ((j / m.band_rows) * m.n_pieces + k) * m.band_rows + j % m.band_rows;
+}
+// number of rows of piece k (kPiecesRowBands)
+AVR_HD inline int piece_row_count(const PieceMapDev& m, int k) {
+  const int cycle = m.band_rows * m.n_pieces;
+  const int rest = m.height % cycle - k * m.band_rows;  // rows of the last, partial cycle left for k
+  return (m.height / cycle) * m.band_rows + (rest <= 0 ? 0 : (rest < m.band_rows ? rest : m.band_rows));
+}
+
 // Sparse run layers: a run's layer is stored only inside the run's screen rectangle, cut into
 // one block per DirectSend piece (include/avr_hip.h, "frame plan").
 struct RunRectDev {
@@ -74,17 +120,20 @@ struct RunRectDev {
 };
 struct RunBlockDev {
   int64_t offset;     // float offset of the block in the send / recv buffer (unused if empty)
-  int32_t first_row;  // image row stored in the block's first row
+  int32_t first_row;  // piece row (contiguous pieces: image row) stored in the block's first row
   int32_t span_base;  // < 0: every row holds the run rectangle's x0..x1; else the block's rows are
                       // entries span_base + (row - first_row) of the span table
 };
 // One row of a block of a tightened frame plan (avr_frame_plan_tighten): only the pixels
-// x0..x1 of the row are stored, starting at float `offset` of the send / recv buffer; the others
-// are known to be empty (conservative per-row extent of the run's boxes on screen).
+// x0..x1 of the row are stored, starting `rel` floats after the block's offset; the others are
+// known to be empty (conservative per-row extent of the run's boxes on screen).  8 bytes per row:
+// the two span tables of a frame travel with its descriptors (hundreds of KB at 16).
 struct RunSpanDev {
-  int32_t x0, x1;  // inclusive; x1 < x0 = nothing stored for this row
-  int64_t offset;
+  uint16_t x0, x1;  // inclusive; x1 < x0 = nothing stored for this row
+  uint32_t rel;
 };
+constexpr int kMaxTightenedWidth = 65535;            // x0 / x1 are 16 bit
+constexpr int64_t kMaxTightenedBlockFloats = 0xffffffffLL;  // rel is 32 bit
 
 // Host results for one frame over a list of boxes.
 struct FramePlan {
@@ -132,6 +181,42 @@ int layer_order(const float* hints, const int32_t* owner, const int32_t* local_i
 // Conservative screen rectangle of a box (x0,y0,x1,y1 inclusive; x1 < x0 = off-screen).
 void box_screen_rect(const avr_box& box, const avr_camera& camera, int width, int height,
                      int32_t rect[4]);
+// The image rows a caller wants extents for: lo <= y <= hi and, with period > 1, only the rows of
+// the bands dealt to one piece ((y / band_rows) % period == phase).
+struct RowSet {
+  int32_t band_rows = 1, period = 1, phase = 0;
+  int32_t lo = 0, hi = 0x7fffffff;
+};
+// Calls f(a, b) for every maximal interval [a, b] of rows of the set inside [lo, hi].
+template <typename F>
+inline void for_rows(const RowSet& set, int lo, int hi, F&& f) {
+  lo = lo > set.lo ? lo : set.lo;
+  hi = hi < set.hi ? hi : set.hi;
+  if (hi < lo) return;
+  if (set.period <= 1) {
+    f(lo, hi);
+    return;
+  }
+  int band = lo / set.band_rows;
+  band += ((set.phase - band) % set.period + set.period) % set.period;  // first band of the phase
+  for (; band * set.band_rows <= hi; band += set.period) {
+    const int a = band * set.band_rows, b = a + set.band_rows - 1;
+    f(a > lo ? a : lo, b < hi ? b : hi);
+  }
+}
+// A box on screen: its conservative rectangle and the projected corners whose convex hull bounds
+// its projection (`whole`: the box reaches behind the eye, every row keeps the whole rectangle).
+struct BoxFootprint {
+  int32_t rect[4];  // x0, y0, x1, y1 inclusive; x1 < x0 = off-screen
+  bool whole = false;
+  double px[8], py[8];
+};
+void box_footprints(const avr_box* boxes, int n_boxes, const avr_camera& camera, int width,
+                    int height, BoxFootprint* out);
+// Merges (min / max) the box's conservative extent on every row of `rows` inside its rectangle
+// into x0[y - y_base], x1[y - y_base]; an entry with x1 < x0 is empty.
+void merge_footprint_rows(const BoxFootprint& footprint, const RowSet& rows, int y_base,
+                          int32_t* x0, int32_t* x1);
 // Per-row extent inside that rectangle (rows rect[1]..rect[3]; x1 < x0 = nothing on the row).
 void box_row_spans(const avr_box& box, const avr_camera& camera, int width, int height,
                    const int32_t rect[4], std::vector<int32_t>* row_x0,
@@ -152,6 +237,7 @@ struct RenderLaunch {
   const RunRectDev* run_rects_dev;    // n_runs
   const RunBlockDev* run_blocks_dev;  // n_runs x n_pieces
   const RunSpanDev* run_spans_dev;    // rows of the blocks with span_base >= 0 (may be null)
+  PieceMapDev pieces;                 // which piece a pixel's row belongs to
   float* out_layers;
   unsigned long long* samples_out;  // may be null
   unsigned long long* counters;     // diagnostics (4 x uint64), only read when samples_out is set
@@ -180,7 +266,9 @@ int launch_encode_u8(const float* rgba, uint32_t* out, int64_t n, void* stream);
 int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream);
 struct FoldLaunch {
   int width;
-  int64_t piece_begin, piece_end;
+  PieceMapDev pieces;
+  int piece;                           // this rank's piece
+  int64_t piece_begin, piece_end;      // contiguous pieces: the image's pixel range; row bands: [0, n)
   int n_runs;                          // global runs, in order
   const RunRectDev* run_rects_dev;     // n_runs
   const RunBlockDev* run_blocks_dev;   // n_runs: block of this rank's piece in the recv buffer
@@ -195,6 +283,10 @@ int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, i
 int launch_downsample(const float* src, int tw, int th, int block, float* dst, void* stream);
 int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream);
 int launch_flip_rows(const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst, void* stream);
+// Gathered, piece-major rows (row bands: piece 0's rows, then piece 1's, ...) -> image order;
+// flip != 0 also turns the image upside down (bottom-up image -> top-down file rows).
+int launch_assemble_rows(const PieceMapDev& pieces, const uint8_t* src, int64_t row_bytes, int flip,
+                         uint8_t* dst, void* stream);
 
 constexpr uint32_t kScanWorkgroups = 2048;  // grid of the grid-stride cell scans
 // scene statistics (avr_scene_stats.hip).  partial_dev: kScanWorkgroups x 32 bytes of scratch;
@@ -233,8 +325,10 @@ void plan_overlay(const double bounds_min[3], const double bounds_max[3], const 
 // computeTightBounds (VolumeRenderer.cpp:791-848) over replicated box metadata.
 void tight_bounds(const avr_box* boxes, int n_boxes, const double fallback_min[3],
                   const double fallback_max[3], double out_min[3], double out_max[3]);
+// image / rgb8 hold the pixels [pixel_begin, pixel_end) of the image, or -- pieces != nullptr with
+// row bands -- the rows of piece `piece` in order (pixel_begin = 0, pixel_end = its pixel count).
 int launch_overlay(const OverlayPlan& plan, int width, int64_t pixel_begin, int64_t pixel_end,
-                   float* image, uint8_t* rgb8, void* stream);
+                   const PieceMapDev* pieces, int piece, float* image, uint8_t* rgb8, void* stream);
 
 // ---- visibility ordering (avr_visibility.cpp) -----------------------------------------------
 struct VisBox {

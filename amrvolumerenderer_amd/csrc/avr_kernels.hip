@@ -480,6 +480,7 @@ render_runs_kernel(
     const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
     const int n_runs, const int n_pieces, const RunRectDev* __restrict__ run_rects,
     const RunBlockDev* __restrict__ run_blocks, const RunSpanDev* __restrict__ run_spans,
+    const int band_shift,  // >= 0: pieces are bands of 2^band_shift rows dealt round-robin
     const int tiles_x, const int tiles_y,
     const MarchItemDev* __restrict__ items, float* __restrict__ out,
     unsigned long long* samples_out, unsigned long long* counters) {
@@ -600,24 +601,33 @@ render_runs_kernel(
     // The run's layer is stored only inside the run's screen rectangle, in the block of the
     // DirectSend piece the pixel belongs to.
     if (live && px >= rect.x0 && px <= rect.x1 && py >= rect.y0 && py <= rect.y1) {
-      const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
-      int64_t piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
-      if (piece > n_pieces - 1) piece = n_pieces - 1;
+      int64_t piece;
+      int row = py;  // the pixel's row in its piece's numbering (contiguous pieces: the image row)
+      if (band_shift >= 0) {  // kPiecesRowBands
+        const unsigned band = static_cast<unsigned>(py) >> band_shift;
+        const unsigned cycle = band / static_cast<unsigned>(n_pieces);
+        piece = band - cycle * static_cast<unsigned>(n_pieces);
+        row = static_cast<int>((cycle << band_shift) + (static_cast<unsigned>(py) & ((1u << band_shift) - 1u)));
+      } else {
+        const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
+        piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
+        if (piece > n_pieces - 1) piece = n_pieces - 1;
+      }
       const RunBlockDev block = run_blocks[static_cast<int64_t>(run) * n_pieces + piece];
       float* dst;
       if (block.span_base >= 0) {
         // tightened plan: the row stores only the run's conservative extent on screen; a pixel
         // outside it is empty by construction (counted, should the construction ever be wrong)
-        const RunSpanDev span = run_spans[block.span_base + (py - block.first_row)];
-        if (px < span.x0 || px > span.x1) {
+        const RunSpanDev span = run_spans[block.span_base + (row - block.first_row)];
+        if (px < static_cast<int>(span.x0) || px > static_cast<int>(span.x1)) {
           if (STATS && counters != nullptr && acc.a != 0.0f) atomicAdd(counters + 4, 1ull);
           dst = nullptr;
         } else {
-          dst = out + span.offset + static_cast<int64_t>(px - span.x0) * 5;
+          dst = out + block.offset + span.rel + static_cast<int64_t>(px - static_cast<int>(span.x0)) * 5;
         }
       } else {
         dst = out + block.offset +
-              (static_cast<int64_t>(py - block.first_row) * (rect.x1 - rect.x0 + 1) +
+              (static_cast<int64_t>(row - block.first_row) * (rect.x1 - rect.x0 + 1) +
                (px - rect.x0)) * 5;
       }
       if (dst != nullptr) {
@@ -1020,17 +1030,22 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
     const RunRectDev* __restrict__ rects, const RunBlockDev* __restrict__ blocks,
     const RunSpanDev* __restrict__ spans, const float* __restrict__ recv,
     float* __restrict__ out_piece,
-    uint8_t* __restrict__ out_rgb8, const int first_row, const int chunks_per_row) {
+    uint8_t* __restrict__ out_rgb8, const int first_row, const int chunks_per_row,
+    const PieceMapDev pieces, const int piece) {
   __shared__ FoldEntry list[256];
   __shared__ int wave_count[4];
   const int tid = static_cast<int>(threadIdx.x);
   const int wave = tid >> 6;
   const int lane = tid & 63;
-  const int row = first_row + static_cast<int>(blockIdx.x) / chunks_per_row;
+  // `block_row`: the row in the numbering the blocks use (piece rows); `row`: the image row
+  const int block_row = first_row + static_cast<int>(blockIdx.x) / chunks_per_row;
+  const bool bands = pieces.layout == kPiecesRowBands;
+  const int row = bands ? image_row_of(pieces, piece, block_row) : block_row;
   const int seg_x0 = (static_cast<int>(blockIdx.x) % chunks_per_row) * 256;
   const int seg_x1 = min(seg_x0 + 255, width - 1);
   const int px = seg_x0 + tid;
-  const int64_t p = static_cast<int64_t>(row) * width + px;
+  // position among the piece's pixels: its rows in order, or the image's pixel range
+  const int64_t p = static_cast<int64_t>(block_row) * width + px;
   const bool live = (px < width) && (p >= piece_begin) && (p < piece_end);
 
   Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};
@@ -1044,15 +1059,15 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
       if (touches) {
         const RunBlockDev block = blocks[g];
         if (block.span_base >= 0) {  // tightened plan: this row's stored extent
-          const RunSpanDev span = spans[block.span_base + (row - block.first_row)];
-          touches = span.x0 <= seg_x1 && span.x1 >= seg_x0;
-          entry.x0 = span.x0;
-          entry.x1 = span.x1;
-          entry.base = span.offset - static_cast<int64_t>(span.x0) * 5;
+          const RunSpanDev span = spans[block.span_base + (block_row - block.first_row)];
+          entry.x0 = static_cast<int32_t>(span.x0);
+          entry.x1 = static_cast<int32_t>(span.x1);
+          touches = entry.x0 <= seg_x1 && entry.x1 >= seg_x0;
+          entry.base = block.offset + span.rel - static_cast<int64_t>(entry.x0) * 5;
         } else {
           entry.x0 = rect.x0;
           entry.x1 = rect.x1;
-          entry.base = block.offset + (static_cast<int64_t>(row - block.first_row) *
+          entry.base = block.offset + (static_cast<int64_t>(block_row - block.first_row) *
                                            (rect.x1 - rect.x0 + 1) - rect.x0) * 5;
         }
       }
@@ -1158,6 +1173,29 @@ __global__ void flip_rows_kernel(const T* __restrict__ src, int64_t row_items, i
   }
 }
 
+// Gathered piece-major rows -> image rows (row bands), optionally upside down: destination row
+// y_out holds image row y = flip ? h - 1 - y_out : y_out, which is piece row j of piece k and
+// sits after the rows of the pieces before k in the gathered buffer.
+template <typename T>
+__global__ void assemble_rows_kernel(const T* __restrict__ src, int64_t row_items,
+                                     const PieceMapDev pieces, int flip, T* __restrict__ dst) {
+  const int h = pieces.height;
+  const int64_t n = row_items * h;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
+       q += stride) {
+    const int64_t out_row = q / row_items;
+    const int y = flip ? (h - 1 - static_cast<int>(out_row)) : static_cast<int>(out_row);
+    int64_t src_row = y;
+    if (pieces.layout == kPiecesRowBands) {
+      const int k = piece_of_row(pieces, y);
+      src_row = piece_row_of(pieces, y);
+      for (int before = 0; before < k; ++before) src_row += piece_row_count(pieces, before);
+    }
+    dst[q] = src[src_row * row_items + (q - out_row * row_items)];
+  }
+}
+
 int grid_for(int64_t n, int block) {
   int64_t blocks = (n + block - 1) / block;
   const int64_t cap = 256 * 8;  // 256 CUs x 8 blocks, grid-stride the rest
@@ -1218,11 +1256,21 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
     lds_bytes = std::max(lds_bytes, share);
   }
   const bool stats = L.samples_out != nullptr;
+  int band_shift = -1;
+  if (L.pieces.layout == kPiecesRowBands) {
+    band_shift = 0;
+    while ((1 << band_shift) < L.pieces.band_rows) ++band_shift;
+    if ((1 << band_shift) != L.pieces.band_rows) {
+      set_error("render_runs_kernel: band_rows must be a power of two");
+      return AVR_ERR_INVALID_ARGUMENT;
+    }
+  }
 #define AVR_LAUNCH(STATS, ONLY)                                                                 \
   hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \
                      lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,      \
                      L.n_tables, L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces,              \
-                     L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, tiles_x, tiles_y,       \
+                     L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, band_shift, tiles_x,    \
+                     tiles_y,                                                                    \
                      L.items_dev,                                                                \
                      L.out_layers, L.samples_out, L.counters)
   if (L.only_mode == kPow2Multiply) {
@@ -1296,6 +1344,7 @@ int launch_decode_u8(const uint32_t* in, float* rgba, int64_t n, void* stream_v)
 int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
   const int64_t n = L.piece_end - L.piece_begin;
   if (n <= 0) return AVR_OK;
+  // (row bands: piece_begin is 0 and the rows are the piece's own)
   const int first_row = static_cast<int>(L.piece_begin / L.width);
   const int last_row = static_cast<int>((L.piece_end - 1) / L.width);
   const int chunks_per_row = (L.width + 255) / 256;
@@ -1308,7 +1357,7 @@ int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
                      static_cast<hipStream_t>(stream_v), L.width, L.piece_begin, L.piece_end,
                      L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, L.recv,
                      L.out_piece, L.out_rgb8,
-                     first_row, chunks_per_row);
+                     first_row, chunks_per_row, L.pieces, L.piece);
   return check_launch("fold_plan_kernel");
 }
 
@@ -1342,6 +1391,31 @@ int launch_flip_rows(const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst,
                        stream, src, row_bytes, h, dst);
   }
   return check_launch("flip_rows_kernel");
+}
+
+int launch_assemble_rows(const PieceMapDev& pieces, const uint8_t* src, int64_t row_bytes, int flip,
+                         uint8_t* dst, void* stream_v) {
+  const int h = pieces.height;
+  if (row_bytes <= 0 || h <= 0) return AVR_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  const bool wide = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  if (wide) {
+    const int64_t items = row_bytes / 16;
+    hipLaunchKernelGGL(assemble_rows_kernel<uint4>, dim3(grid_for(items * h, 256)), dim3(256), 0,
+                       stream, reinterpret_cast<const uint4*>(src), items, pieces, flip,
+                       reinterpret_cast<uint4*>(dst));
+  } else if (row_bytes % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & 3u) == 0) &&
+             ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0)) {
+    const int64_t items = row_bytes / 4;
+    hipLaunchKernelGGL(assemble_rows_kernel<uint32_t>, dim3(grid_for(items * h, 256)), dim3(256), 0,
+                       stream, reinterpret_cast<const uint32_t*>(src), items, pieces, flip,
+                       reinterpret_cast<uint32_t*>(dst));
+  } else {
+    hipLaunchKernelGGL(assemble_rows_kernel<uint8_t>, dim3(grid_for(row_bytes * h, 256)), dim3(256),
+                       0, stream, src, row_bytes, pieces, flip, dst);
+  }
+  return check_launch("assemble_rows_kernel");
 }
 
 int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, void* stream_v) {

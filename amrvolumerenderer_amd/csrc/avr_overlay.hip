@@ -27,15 +27,17 @@ __device__ __forceinline__ uint32_t as_byte(float c) {  // Color::GetComponentAs
 
 // image: pixels [pixel_begin, pixel_end) of a width x height depth-sort image (5 floats each).
 __global__ void overlay_kernel(const OverlayPlan plan, const int width, const int64_t pixel_begin,
-                               const int64_t pixel_end, float* __restrict__ image,
-                               uint8_t* __restrict__ rgb8) {
+                               const int64_t pixel_end, const PieceMapDev pieces, const int piece,
+                               float* __restrict__ image, uint8_t* __restrict__ rgb8) {
   const int64_t n = pixel_end - pixel_begin;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; q < n;
        q += stride) {
     const int64_t p = pixel_begin + q;
     const int px = static_cast<int>(p % width);
-    const int py = static_cast<int>(p / width);
+    int py = static_cast<int>(p / width);
+    // a piece of row bands holds its rows in order: piece row -> image row
+    if (pieces.layout == kPiecesRowBands) py = image_row_of(pieces, piece, py);
     float* buffer = image + q * 5;
     float r = buffer[0], g = buffer[1], b = buffer[2], a = buffer[3], depth = buffer[4];
     bool touched = false;
@@ -89,14 +91,15 @@ __global__ void overlay_kernel(const OverlayPlan plan, const int width, const in
 }  // namespace
 
 int launch_overlay(const OverlayPlan& plan, int width, int64_t pixel_begin, int64_t pixel_end,
-                   float* image, uint8_t* rgb8, void* stream_v) {
+                   const PieceMapDev* pieces, int piece, float* image, uint8_t* rgb8,
+                   void* stream_v) {
   const int64_t n = pixel_end - pixel_begin;
   if (n <= 0) return AVR_OK;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(overlay_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream_v), plan, width, pixel_begin, pixel_end, image,
-                     rgb8);
+                     static_cast<hipStream_t>(stream_v), plan, width, pixel_begin, pixel_end,
+                     pieces != nullptr ? *pieces : PieceMapDev{}, piece, image, rgb8);
   const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_error(std::string("overlay_kernel: ") + hipGetErrorString(err));

@@ -27,15 +27,13 @@ struct avr_frame_plan {
   std::vector<avr::RunRectDev> global_rects;
   std::vector<avr::RunBlockDev> recv_blocks;
   std::vector<int32_t> recv_block_rows;
-  // tightened layout (avr_frame_plan_tighten): the rows of the blocks above, sender and receiver
+  // tightened layout (avr_frame_plan_tighten): the rows of the blocks above, sender and receiver;
+  // they travel to the device with the descriptors of every call that needs them
   std::vector<avr::RunSpanDev> send_spans, recv_spans;
   bool tightened = false;
-  // device copies of the two span tables (hundreds of KB: uploaded once, by the first call that
-  // needs them -- avr_capi.cpp -- not with every frame's descriptors; freed with the plan)
-  mutable void* send_spans_dev = nullptr;
-  mutable void* recv_spans_dev = nullptr;
-  mutable int spans_device = -1;
+  avr::PieceMapDev pieces;  // how the image's pixels are dealt to the ranks' pieces
   bool from_boxes = false;  // built by build_frame_plan (layers = boxes): may be tightened
+  std::vector<avr::BoxFootprint> footprints;  // of all boxes on screen (from_boxes)
   // host prologue of this frame's local boxes, filled by the first device call that needs it
   // (avr_classify_plan) and re-used by the next (avr_march_plan)
   avr::FramePlan prologue;
@@ -52,7 +50,7 @@ void dense_run_tables(int width, int height, int n_runs, int n_pieces,
 // Compositor::compose case; rects == nullptr: every layer covers the whole image.
 void build_layer_plan(int n_layers, const float* hints, const int32_t* owner,
                       const int32_t (*rects)[4], int n_ranks, int rank, const int32_t* group_order,
-                      int width, int height, avr_frame_plan* plan);
+                      int width, int height, int piece_layout, int band_rows, avr_frame_plan* plan);
 
 // Replaces the rectangular blocks of a frame plan by per-row spans (conservative extent of each
 // run's boxes on screen) and recomputes the exchange layout; every rank must do the same.
@@ -60,7 +58,14 @@ void tighten_frame_plan(const avr_box* all_boxes, int n_boxes, avr_frame_plan* p
 
 void build_frame_plan(const avr_box* all_boxes, const int32_t* owner, int n_boxes, int n_ranks,
                       int rank, const int32_t* group_order, const avr_paint_params& params,
-                      const avr_camera& camera, avr_frame_plan* plan);
+                      const avr_camera& camera, int piece_layout, int band_rows,
+                      avr_frame_plan* plan);
+
+PieceMapDev make_piece_map(int layout, int band_rows, int n_pieces, int width, int height);
+// Where piece k sits in the gathered, piece-major image: pixels [begin, end).  With contiguous
+// pieces this IS the image's pixel range (getPieceRange, DirectSendBase.cpp:59-74); with row
+// bands the pieces' rows follow each other piece by piece and avr_assemble_rows puts them back.
+void piece_pixel_range(const PieceMapDev& map, int k, int64_t* begin, int64_t* end);
 
 }  // namespace avr
 

@@ -81,9 +81,23 @@ struct PlanKey {
   avr_render_params render{};
   avr_camera camera{};
   std::vector<int32_t> group;  // explicit group order, if any
+  // Field by field (bit patterns): avr_camera carries tail padding whose bytes are whatever the
+  // caller's stack held, so comparing whole structs could hit on one rank and miss on another.
   bool operator==(const PlanKey& o) const {
-    return std::memcmp(&render, &o.render, sizeof(render)) == 0 &&
-           std::memcmp(&camera, &o.camera, sizeof(camera)) == 0 && group == o.group;
+    auto same = [](const auto& a, const auto& b) {
+      static_assert(sizeof(a) == sizeof(b), "field");
+      return std::memcmp(&a, &b, sizeof(a)) == 0;
+    };
+    return render.width == o.render.width && render.height == o.render.height &&
+           same(render.box_transparency, o.render.box_transparency) &&
+           render.antialiasing == o.render.antialiasing &&
+           render.use_visibility_graph == o.render.use_visibility_graph &&
+           render.draw_bounds == o.render.draw_bounds &&
+           render.write_visibility_graph == o.render.write_visibility_graph &&
+           same(camera.eye, o.camera.eye) && same(camera.look_at, o.camera.look_at) &&
+           same(camera.up, o.camera.up) && same(camera.fov_y_degrees, o.camera.fov_y_degrees) &&
+           same(camera.near_plane, o.camera.near_plane) &&
+           same(camera.far_plane, o.camera.far_plane) && group == o.group;
   }
 };
 
@@ -113,6 +127,11 @@ struct avr_renderer {
   int march_cap = -1;  // -1: default (uncapped)
   bool cache_classification = false;
   bool tighten_exchange = true;  // avr_renderer_set_tighten
+  // How the image is dealt to the ranks' pieces (avr_renderer_set_piece_layout): bands of 8 rows
+  // (the height of a march wave's tile) dealt round-robin, so that every rank receives and folds
+  // the same share of every screen region; one rank has one piece either way.
+  int piece_layout = AVR_PIECES_ROW_BANDS;
+  int band_rows = 8;
   int overlap_classify = -1;  // -1: default (1 for one rank, 0 otherwise); see avr_renderer_set_overlap
 
   // Frame plans by (render parameters, camera, group order), most recently used kept: a camera
@@ -129,14 +148,13 @@ struct avr_renderer {
   bool have_plan = false;
 
   void forget_plans() {
-    if (!plans.empty()) drain_all();  // tightened plans own device tables that launches read
     for (CachedPlan& entry : plans) avr_frame_plan_destroy(entry.plan);
     plans.clear();
     plan = nullptr;
     have_plan = false;
   }
 
-  DeviceBuffer send[2], recv, piece, piece_rgb8, full_rgb8, full_image, small_image;
+  DeviceBuffer send[2], recv, piece, piece_rgb8, full_rgb8, full_image, assembled_image, small_image;
   // classified volume f % 3, send buffer f % 2
   hipEvent_t classified_event[AVR_CLASSIFIED_SLOTS] = {};  // classify pass of the volume finished
   hipEvent_t marched_event[AVR_CLASSIFIED_SLOTS] = {};     // march finished reading the volume
@@ -384,6 +402,21 @@ int avr_renderer_set_tighten(avr_renderer* r, int enabled) {
   });
 }
 
+int avr_renderer_set_piece_layout(avr_renderer* r, int piece_layout, int band_rows) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    require(piece_layout == AVR_PIECES_CONTIGUOUS || piece_layout == AVR_PIECES_ROW_BANDS,
+            "unknown piece layout");
+    require(piece_layout == AVR_PIECES_CONTIGUOUS ||
+                (band_rows >= 1 && (band_rows & (band_rows - 1)) == 0),
+            "band_rows must be a power of two");
+    r->piece_layout = piece_layout;
+    r->band_rows = (piece_layout == AVR_PIECES_ROW_BANDS) ? band_rows : 1;
+    r->forget_plans();
+    return AVR_OK;
+  });
+}
+
 int avr_renderer_set_overlap(avr_renderer* r, int overlap_classify) {
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
@@ -557,31 +590,33 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       params.colormap = r->colormap.empty() ? nullptr : r->colormap.data();
       params.colormap_count = static_cast<int32_t>(r->colormap.size());
       avr_frame_plan* fresh = nullptr;
-      abi_ok(avr_frame_plan_create(r->all_boxes.data(), r->owner.data(),
-                                   static_cast<int>(r->all_boxes.size()), r->n_ranks, r->rank, group,
-                                   &params, camera, &fresh));
+      abi_ok(avr_frame_plan_create_pieces(r->all_boxes.data(), r->owner.data(),
+                                          static_cast<int>(r->all_boxes.size()), r->n_ranks, r->rank,
+                                          group, &params, camera, r->piece_layout, r->band_rows,
+                                          &fresh));
+      if (r->n_ranks > 1 && r->tighten_exchange) {
+        // The exchange layout is tightened to the runs' per-row extents when the plan is made
+        // (25-50 % fewer bytes on the links from a camera's FIRST frame on; tens of microseconds
+        // of host geometry, avr_plan.cpp).  The decision depends on nothing but the renderer's
+        // settings, so every rank of the frame takes it alike.
+        const int status = avr_frame_plan_tighten(fresh, r->all_boxes.data(),
+                                                  static_cast<int>(r->all_boxes.size()));
+        if (status != AVR_OK) {
+          avr_frame_plan_destroy(fresh);
+          abi_ok(status);
+        }
+      }
       if (r->plans.size() >= avr_renderer::kCachedPlans) {  // the least recently used one goes
         size_t oldest = 0;
         for (size_t i = 1; i < r->plans.size(); ++i) {
           if (r->plans[i].last_used < r->plans[oldest].last_used) oldest = i;
         }
-        // (a tightened plan owns device tables that launches may still read)
-        if (r->plans[oldest].plan->send_spans_dev != nullptr ||
-            r->plans[oldest].plan->recv_spans_dev != nullptr) {
-          r->drain_all();
-        }
+        // (a plan is host data only: every launch copied what it reads into its own descriptors)
         avr_frame_plan_destroy(r->plans[oldest].plan);
         r->plans.erase(r->plans.begin() + static_cast<std::ptrdiff_t>(oldest));
       }
       r->plans.push_back(avr_renderer::CachedPlan{key, fresh, 0});
       cached = &r->plans.back();
-    } else if (r->n_ranks > 1 && r->tighten_exchange) {
-      // The camera has been seen before: from its second frame on the plan's exchange layout is
-      // tightened to the runs' per-row extents (25-50 % fewer bytes on the links; ~2 ms of host
-      // geometry, which a camera that never comes back never pays).  Every rank sees the same
-      // sequence of cameras, so every rank tightens the same frames.
-      abi_ok(avr_frame_plan_tighten(cached->plan, r->all_boxes.data(),
-                                    static_cast<int>(r->all_boxes.size())));
     }
     cached->last_used = ++r->plan_clock;
     r->plan = cached->plan;
@@ -743,26 +778,34 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     abi_ok(avr_fold_plan(r->compose, plan, received, piece, overlay_piece ? nullptr : piece_rgb8));
     if (overlay_piece && piece_pixels > 0) {
-      abi_ok(avr_bbox_overlay(r->compose, r->tight_min, r->tight_max, camera, 1, width, height,
-                              info.piece_begin, info.piece_end, piece, piece_rgb8));
+      abi_ok(avr_bbox_overlay_piece(r->compose, plan, r->tight_min, r->tight_max, camera, piece,
+                                    piece_rgb8));
     }
     hip_ok(hipEventRecord(r->composed_event[slot], stream_x), "hipEventRecord");
     r->composed_pending[slot] = true;
 
     lap(4);
     const int64_t n_pixels = info.n_pixels;
+    // The gathered buffer is piece-major; with contiguous pieces that IS the image, with row
+    // bands avr_assemble_rows puts the rows back (for the bytes in the same pass that turns the
+    // bottom-up image into the file's top-down rows).
+    const bool banded = info.piece_layout == AVR_PIECES_ROW_BANDS;
     if (early_rgb8) {
-      // pieces are pixel ranges of the bottom-up image; the output file's rows run top-down
       uint8_t* full = piece_rgb8;
       if (r->n_ranks > 1) {
         full = is_root ? static_cast<uint8_t*>(r->full_rgb8.reserve(static_cast<size_t>(n_pixels) * 3, drain))
                        : nullptr;
         abi_ok(avr_gather(r->compose, plan, r->comm, piece_rgb8, 3, full, 0));
       }
-      if (is_root) abi_ok(avr_flip_rows(r->compose, full, width * 3, height, rgb8_out));
+      if (is_root) abi_ok(avr_assemble_rows(r->compose, plan, full, 3, 1, rgb8_out));
       if (gather_image) {
         if (r->n_ranks > 1) {
-          abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, is_root ? image_out : nullptr, 0));
+          float* gathered = is_root ? image_out : nullptr;
+          if (is_root && banded) {
+            gathered = static_cast<float*>(r->full_image.reserve(static_cast<size_t>(n_pixels) * 20, drain));
+          }
+          abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, gathered, 0));
+          if (is_root && banded) abi_ok(avr_assemble_rows(r->compose, plan, gathered, 20, 0, image_out));
         } else {
           hip_ok(hipMemcpyAsync(image_out, piece, static_cast<size_t>(n_pixels) * 20,
                                 hipMemcpyDeviceToDevice, stream_x), "hipMemcpyAsync(image)");
@@ -774,6 +817,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         full = is_root ? static_cast<float*>(r->full_image.reserve(static_cast<size_t>(n_pixels) * 20, drain))
                        : nullptr;
         abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, full, 0));
+        if (is_root && banded) {
+          float* assembled = static_cast<float*>(
+              r->assembled_image.reserve(static_cast<size_t>(n_pixels) * 20, drain));
+          abi_ok(avr_assemble_rows(r->compose, plan, full, 20, 0, assembled));
+          full = assembled;
+        }
       }
       if (is_root) {
         float* small = gather_image ? image_out

@@ -146,14 +146,17 @@ class FrameRenderer:
         self._frame = 0
         self.last_plan = None
         # ---- the native frame driver -------------------------------------------------------------
+        # The process group is the CONTROL plane only (any backend; bench.py uses gloo): it carries
+        # RCCL's 128-byte id from rank 0 to the others and the agreement below.  The data plane is
+        # the C++ driver's own RCCL communicator -- the only one in the process.
         if native is None:
             native = not stage_through_host and not force_collectives
             if native and n_ranks > 1 and comm is None:
                 import torch.distributed as dist
-                native = (process_group is not None or dist.is_initialized()) and \
-                    dist.get_backend(process_group) == "nccl"
+                native = process_group is not None or dist.is_initialized()
         self.native_error = None
         if native and n_ranks > 1 and comm is None:
+            import torch.distributed as dist
             try:
                 comm = runtime.Comm.from_process_group(ctx.device_index, process_group)
             except Exception as error:   # e.g. RCCL not loadable: say so, keep the frame on the GPU
@@ -161,14 +164,21 @@ class FrameRenderer:
                 # collectives (all_to_all_single / gather) instead of the C++ driver's; every rank
                 # must take the same path, so the decision is agreed on below
                 self.native_error = f"{type(error).__name__}: {error}"
-            import torch.distributed as dist
-            failed = torch.tensor([1 if self.native_error else 0], device=ctx.device)
+            on_host = dist.get_backend(process_group) != "nccl"
+            failed = torch.tensor([1 if self.native_error else 0],
+                                  device="cpu" if on_host else ctx.device)
             dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=process_group)
             if int(failed.item()):
                 import warnings
                 warnings.warn("native RCCL communicator unavailable on some rank "
                               f"({self.native_error}); using the torch.distributed frame loop")
                 native, comm = False, None
+                if on_host:
+                    # the fallback's collectives need an RCCL group of torch's own: created here,
+                    # by every rank alike, and only now (normally no second communicator exists)
+                    fallback_group = dist.new_group(backend="nccl")
+                    self.compositor = DirectSendCompositor(self.comm_ctx, fallback_group, False,
+                                                           force_collectives)
         if native:
             merged = []   # replicated metadata, this rank's boxes with their cells
             mine = iter(self.local_boxes)

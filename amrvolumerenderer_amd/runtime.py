@@ -553,12 +553,22 @@ class Comm:
 
     def __init__(self, device_index: int, rank: int, n_ranks: int, broadcast_bytes):
         self.rank, self.n_ranks = int(rank), int(n_ranks)
-        ident = None
+        ident, failure = None, None
         if self.rank == 0:
-            buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
-            _capi.check(_capi.lib().avr_comm_unique_id(buf))
-            ident = buf.raw
+            # Whatever happens here, the broadcast below still takes place: the other ranks are
+            # waiting in it, and a rank 0 that raised first would leave them there (an empty id
+            # tells them that rank 0 failed).
+            try:
+                buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+                _capi.check(_capi.lib().avr_comm_unique_id(buf))
+                ident = buf.raw
+            except Exception as error:
+                ident, failure = b"", error
         ident = broadcast_bytes(ident)
+        if failure is not None:
+            raise failure
+        if not ident:
+            raise RuntimeError("rank 0 could not create the communicator id (RCCL not loadable?)")
         if len(ident) != _capi.COMM_ID_BYTES:
             raise ValueError("the communicator id did not survive the broadcast")
         handle = C.c_void_p()
@@ -662,8 +672,14 @@ class NativeRenderer:
         _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
 
     def set_tighten(self, enabled: bool = True) -> None:
-        """avr_renderer_set_tighten: per-row exchange layout from a camera's second frame on."""
+        """avr_renderer_set_tighten: per-row exchange layout of every plan the driver makes."""
         _capi.check(_capi.lib().avr_renderer_set_tighten(self._handle, int(bool(enabled))))
+
+    def set_piece_layout(self, layout: int = _capi.PIECES_ROW_BANDS, band_rows: int = 8) -> None:
+        """avr_renderer_set_piece_layout: how the image is dealt to the ranks' pieces (bands of
+        rows dealt round-robin by default; _capi.PIECES_CONTIGUOUS = the reference's ranges)."""
+        _capi.check(_capi.lib().avr_renderer_set_piece_layout(self._handle, int(layout),
+                                                              int(band_rows)))
 
     def set_classify_share(self, lds_reserve_bytes: int = -1) -> None:
         """avr_renderer_set_classify_share: -1 = measured by the driver (default), >= 0 = fixed

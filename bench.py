@@ -39,12 +39,17 @@ def parse_args():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--field", default="smooth", choices=["smooth", "noise", "radial"])
     ap.add_argument("--transparency", type=float, default=0.97)
-    ap.add_argument("--ownership", default="morton", choices=["morton", "round_robin", "block"])
+    ap.add_argument("--ownership", default="morton", choices=["morton", "morton_cost", "morton_pairs", "level_pairs", "round_robin",
+                             "block"])
     ap.add_argument("--antialiasing", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the bounded cpu_baseline sample")
     ap.add_argument("--orbit", type=int, default=0, help="average over this many orbit views")
+    ap.add_argument("--fly-through", action="store_true",
+                    help="every frame of the timed region (and of the warm-up) has a camera the "
+                         "driver has never seen: plan cache useless, host planning (visibility "
+                         "order, frame plan, exchange layout, per-box prologue) paid per frame")
     ap.add_argument("--cache-classification", action="store_true",
                     help="NOT the headline configuration: keep the classified volumes across "
                          "frames (static data, moving camera) instead of re-reading the f64 "
@@ -128,7 +133,7 @@ def profiled_traffic(args, world):
     are not (MI355X_MICROARCH.md, HBM).  Only valid for the default single-GPU workload."""
     default = (world == 1 and args.config == "config4" and args.field == "smooth"
                and args.transparency == 0.97 and not args.width and not args.height
-               and args.antialiasing == 1 and args.orbit == 0)
+               and args.antialiasing == 1 and args.orbit == 0 and not args.fly_through)
     path = os.path.join(ROOT, "profiles", "r2_final", "pmc_summary.txt")
     if not default or not os.path.exists(path):
         return None, None
@@ -213,11 +218,11 @@ def main():
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+        # The process group is the CONTROL plane only -- RCCL's 128-byte id, the barriers, the
+        # sample-count and max-time reductions -- and runs over gloo, so that the one RCCL
+        # communicator in the process is the C++ driver's own (a second one, torch's, would
+        # share the GPU's queues with it for nothing).
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         group = dist.group.WORLD
 
     from amrvolumerenderer_amd import build as avr_build
@@ -258,6 +263,15 @@ def main():
                                draw_bounds=False)  # not part of the metric
     cameras = ([scenes.orbit_camera(v, args.orbit) for v in range(args.orbit)]
                if args.orbit > 0 else [scenes.default_camera()])
+    # --fly-through: a camera that never repeats (0.1 degree of orbit per frame).  The timed
+    # frames are views FLY_TIMED + i; everything untimed before them uses views counted up from 0
+    # (never reaching FLY_TIMED), so no timed frame finds a plan in the driver's cache.
+    FLY_VIEWS, FLY_TIMED = 3600, 1_000_000
+    if args.fly_through:
+        if args.orbit:
+            raise SystemExit("--fly-through and --orbit exclude each other")
+        cameras = [scenes.orbit_camera(FLY_TIMED + i, FLY_VIEWS) for i in range(args.steps)]
+    fly_view = [0]
 
     # ---- untimed: sample count of one frame per camera (device-side counter, stats build) ----
     samples_dev = torch.zeros(1, dtype=torch.int64, device=ctx.device)
@@ -269,8 +283,7 @@ def main():
         torch.cuda.synchronize()
         s = samples_dev.clone()
         if world > 1:
-            if args.rehearse_on_one_gpu:
-                s = s.cpu()
+            s = s.cpu()
             dist.all_reduce(s, group=group)
         frame_samples.append(int(s.item()))
     local_runs = renderer.last_plan.n_local_runs
@@ -281,7 +294,7 @@ def main():
     checks = {}
     default_scene = (args.config == "config4" and args.field == "smooth" and not args.width
                      and not args.height and args.transparency == 0.97 and args.antialiasing == 1
-                     and args.orbit == 0)
+                     and args.orbit == 0 and not args.fly_through)
     if default_scene and not args.no_self_check:
         # the ranks' shares of the frame add up to the one-rank frame's samples, whatever N
         # (the count tests/test_full_size_gpu.py checks against the oracle)
@@ -290,14 +303,16 @@ def main():
         # the same frame through the other implementation of the collectives: the C++ driver's
         # grouped ncclSend / ncclRecv (avr_exchange / avr_gather) against torch.distributed's
         # all_to_all_single / gather on the same RCCL transport -- rank 0's bytes must agree
+        twin_group = group if args.rehearse_on_one_gpu else dist.new_group(backend="nccl")
         twin = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
-                             spec.scalar_range, rank, world, group, native=False)
+                             spec.scalar_range, rank, world, twin_group, native=False,
+                             stage_through_host=args.rehearse_on_one_gpu)
         _, a = renderer.render(rparams, cameras[0])
         _, b = twin.render(rparams, cameras[0])
         renderer.synchronize()
         twin.synchronize()
         torch.cuda.synchronize()
-        same = torch.ones(1, device=ctx.device)
+        same = torch.ones(1)
         if rank == 0:
             same[0] = float(torch.equal(a, b) and bool(a.any()))
         dist.broadcast(same, 0, group=group)
@@ -308,7 +323,13 @@ def main():
             print(f"bench.py: self-check failed: {checks}", file=sys.stderr)
         raise SystemExit(3)
 
-    def step(i):
+    if args.fly_through and renderer.native is not None:
+        renderer.native.set_tighten(True)   # forgets the plans the sample counting left behind
+
+    def step(i, timed=False):
+        if args.fly_through and not timed:
+            fly_view[0] += 1
+            return renderer.render(rparams, scenes.orbit_camera(fly_view[0], FLY_VIEWS))
         return renderer.render(rparams, cameras[i % len(cameras)])
 
     # Untimed setup (optional): pick the march occupancy cap for this workload
@@ -363,17 +384,18 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if native:
+        renderer.native.host_profile(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, timed=True)
     renderer.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64,
-                     device="cpu" if args.rehearse_on_one_gpu else ctx.device)
+    t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     elapsed = float(t.item())
@@ -381,7 +403,11 @@ def main():
     # duration (what rocprofv3 --stats reports) includes the time it shared the GPU with the
     # other and their sum exceeds the frame time.  The paint stage's GPU time per frame is the
     # length of the union of the kernels' execution intervals over the timed region / frames.
+    host_us = None
     if native:
+        sections, profiled = renderer.native.host_profile()
+        if profiled == args.steps:
+            host_us = {k: round(v, 1) for k, v in sections.items()}
         classify_ms, march_ms, kernel_ms, n_events = renderer.native.timings()
         renderer.native.set_timing(False)
         assert n_events == args.steps
@@ -414,6 +440,8 @@ def main():
     renderer.render(rparams, cameras[0], samples=samples_dev)
     renderer.synchronize()
     my_samples = int(samples_dev.item())
+    if args.fly_through and world == 1:   # the timed frames' own average, not the first view's
+        my_samples = round(sum(frame_samples) / len(frame_samples))
     n_pixels = params.width * params.height
     send_floats = renderer.last_plan.send_floats   # (N > 1: the tightened layout by now)
     algo_bytes = 8.0 * my_samples + 4.0 * send_floats
@@ -436,6 +464,10 @@ def main():
         "samples_this_rank": my_samples,
         "compulsory_bytes": int(sum(b.values.numel() for b in local_boxes) * 8 + 4 * send_floats),
     }
+    # the third reading SURVEY.md 8(d) asks for: what the frame cannot avoid moving (every f64 cell
+    # once + the stored layer pixels) over the same kernel time
+    roofline["compulsory_frac"] = round(
+        roofline["compulsory_bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
 
     out = {
         "metric": f"Mray-samples/s ({width}x{height} render of {spec.n0}^3-base "
@@ -466,7 +498,19 @@ def main():
                           if native else "run rectangles"} if world > 1 else None),
             "classification": ("cached across frames (cells not re-read: not the headline "
                                "configuration)" if args.cache_classification else "every frame"),
-            "samples_per_frame": frame_samples[0] if len(frame_samples) == 1 else frame_samples,
+            "samples_per_frame": (frame_samples[0] if len(frame_samples) == 1 else
+                                  (round(sum(frame_samples) / len(frame_samples))
+                                   if args.fly_through else frame_samples)),
+            "camera": ("fly-through: every frame a camera the driver has never seen (0.1 degree "
+                       "of orbit per frame; plan cache useless)" if args.fly_through else
+                       f"orbit of {len(cameras)} views (plans cached)" if args.orbit else
+                       "static (the frame plan is made once)"),
+            # frames rendered before the W warm-up steps, all untimed: the sample count of every
+            # camera (stats build of the march), then the frames that bring the clocks up and let
+            # the C++ driver finish measuring how the two kernels share the GPU
+            # (corun.timed_windows windows of frames that fill 8 ms each)
+            "untimed_frames": {"sample_count": len(cameras), "settle": burst, "warmup": args.warmup},
+            "host_us_per_frame": host_us,
             "self_checks": checks,
         },
         "roofline": roofline,

@@ -267,7 +267,21 @@ typedef struct {
   int64_t piece_end;
   int64_t send_floats;    /* total size of the send / recv buffers */
   int64_t recv_floats;
+  int32_t piece_layout;   /* AVR_PIECES_CONTIGUOUS / AVR_PIECES_ROW_BANDS (see below) */
+  int32_t band_rows;
 } avr_frame_plan_info;
+
+/* How the image is dealt to the ranks' pieces.  AVR_PIECES_CONTIGUOUS is the reference's
+ * partition (DirectSendBase.cpp:59-74) and what Compositor::compose promises its caller.
+ * AVR_PIECES_ROW_BANDS deals bands of band_rows image rows round-robin (band b -> piece b % N):
+ * every rank then receives and folds the same share of every screen region (contiguous pieces of
+ * a scene that covers a third of the image leave some ranks with nothing and others with
+ * everything).  Per-pixel results do not depend on which rank folds a pixel, so the gathered
+ * image is identical; piece_begin is 0 and piece_end the piece's pixel count there (its rows in
+ * image order), the gathered buffer is piece-major, and avr_assemble_rows restores image order.
+ * Used by the frame driver (avr_renderer), whose caller only ever sees the gathered image. */
+#define AVR_PIECES_CONTIGUOUS 0
+#define AVR_PIECES_ROW_BANDS 1
 
 /* One run as seen by the exchange (for inspection and tests). */
 typedef struct {
@@ -282,6 +296,11 @@ int avr_frame_plan_create(const avr_box *all_boxes, const int32_t *owner, int n_
                           int n_ranks, int rank, const int32_t *group_order,
                           const avr_paint_params *params, const avr_camera *camera,
                           avr_frame_plan **out_plan);
+/* The same with a piece layout (avr_frame_plan_create = AVR_PIECES_CONTIGUOUS). */
+int avr_frame_plan_create_pieces(const avr_box *all_boxes, const int32_t *owner, int n_boxes,
+                                 int n_ranks, int rank, const int32_t *group_order,
+                                 const avr_paint_params *params, const avr_camera *camera,
+                                 int piece_layout, int band_rows, avr_frame_plan **out_plan);
 /* The same plan for layers that are only known as images with a depth hint -- the generic
  * Compositor::compose(Image*, MPI_Group, MPI_Comm) of a LayeredImageInterface
  * (DirectSend/Base/DirectSendBase.cpp:316-458): hints[l] / owner[l] for ALL layers of all ranks in
@@ -490,11 +509,14 @@ int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
 int avr_renderer_set_classify_share(avr_renderer *renderer, int bytes);
 int avr_renderer_corun_state(const avr_renderer *renderer, int *overlap_out,
                              int *reserve_bytes_out, int *settled_out, long *windows_out);
-/* Whether the driver tightens the exchange layout (avr_frame_plan_tighten) of a plan when its
- * camera and parameters are seen a second time (default 1; the 32 most recently used plans are
- * kept).  The same on
- * every rank.  Never changes results. */
+/* Whether the driver tightens the exchange layout (avr_frame_plan_tighten) of every plan it makes
+ * (default 1; the 32 most recently used plans are kept, so a camera that repeats pays nothing).
+ * The same on every rank.  Never changes results. */
 int avr_renderer_set_tighten(avr_renderer *renderer, int enabled);
+/* How the image is dealt to the ranks' pieces: AVR_PIECES_ROW_BANDS with bands of 8 rows by
+ * default (the caller only sees the gathered image), AVR_PIECES_CONTIGUOUS for the reference's
+ * partition.  band_rows: a power of two.  The same on every rank.  Never changes results. */
+int avr_renderer_set_piece_layout(avr_renderer *renderer, int piece_layout, int band_rows);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream: a HIP stream whose queued work
@@ -576,6 +598,17 @@ int avr_tight_bounds(const avr_box *all_boxes, int n_boxes, const double fallbac
 int avr_bbox_overlay(avr_context *ctx, const double bounds_min[3], const double bounds_max[3],
                      const avr_camera *camera, int sqrt_antialiasing, int width, int height,
                      int64_t pixel_begin, int64_t pixel_end, float *image, uint8_t *rgb8);
+/* The same on this rank's piece of a frame plan (either piece layout): piece = the piece's pixels
+ * as avr_fold_plan delivers them, rgb8 (may be NULL) its 8-bit twin. */
+int avr_bbox_overlay_piece(avr_context *ctx, const avr_frame_plan *plan, const double bounds_min[3],
+                           const double bounds_max[3], const avr_camera *camera, float *piece,
+                           uint8_t *rgb8);
+/* Gathered pieces (piece-major: piece 0's pixels, then piece 1's, ... as avr_gather delivers them)
+ * -> the image in row order; flip != 0: rows top-down (the output file's order; pieces hold the
+ * bottom-up image of the renderer).  With contiguous pieces the gathered buffer already is the
+ * image, so this is a (flipped) copy -- avr_flip_rows generalised to AVR_PIECES_ROW_BANDS. */
+int avr_assemble_rows(avr_context *ctx, const avr_frame_plan *plan, const void *gathered,
+                      int bytes_per_pixel, int flip, void *image);
 
 /* ---- scene statistics -------------------------------------------------- */
 

@@ -47,6 +47,12 @@ ap.add_argument("--rccl-latency-us", type=float, default=None,
                 help="launch-to-completion latency of a small grouped send/recv round; default: "
                      "measured here on a one-rank RCCL communicator")
 ap.add_argument("--only-rank", type=int, default=-1)
+ap.add_argument("--no-rccl", action="store_true",
+                help="do NOT keep a live one-rank RCCL communicator in every share process (round "
+                     "2's way; the default since round 3 is the N-GPU job's situation: RCCL "
+                     "initialised and used before the renderer exists)")
+ap.add_argument("--contiguous-pieces", action="store_true",
+                help="the reference's contiguous pieces instead of the driver's row bands")
 ap.add_argument("--overlap", type=int, default=-1, help="avr_renderer_set_overlap")
 ap.add_argument("--classify-share", type=int, default=-1, help="avr_renderer_set_classify_share")
 ap.add_argument("--worker", type=int, nargs=2, metavar=("N_RANKS", "RANK"), default=None,
@@ -69,12 +75,32 @@ def measure_share(n_ranks, rank):
     merged, mine = [], iter(local)
     for b in all_boxes:
         merged.append(next(mine) if b.owner == rank else b)
+    resident = None
+    if not args.no_rccl:
+        # what a rank of the real job has in its process: an initialised, used RCCL communicator
+        # (a one-rank one is all a single GPU can hold)
+        import ctypes as C
+        from amrvolumerenderer_amd import _capi
+        resident = runtime.Comm(0, 0, 1, lambda ident: ident)
+        L = _capi.lib()
+        hints, owner1, plan1 = (C.c_float * 1)(1.0), (C.c_int32 * 1)(0), C.c_void_p()
+        _capi.check(L.avr_layered_plan_create(hints, owner1, 1, 1, 0, None, 64, 64, C.byref(plan1)))
+        with torch.cuda.stream(ctx.stream):
+            a = torch.zeros(64 * 64 * 5, device=device)
+            b = torch.zeros(64 * 64 * 5, device=device)
+        for _ in range(4):
+            _capi.check(L.avr_exchange(ctx._handle, plan1, resident._handle, C.c_void_p(a.data_ptr()),
+                                       C.c_void_p(b.data_ptr())))
+        ctx.synchronize()
+        L.avr_frame_plan_destroy(plan1)
     comm = runtime.Comm.solo(rank, n_ranks) if n_ranks > 1 else None
     r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, rank,
                                n_ranks, comm)
     r.set_options(args.march_occupancy, False)
     r.set_overlap(args.overlap)
     r.set_classify_share(args.classify_share)
+    if args.contiguous_pieces:
+        r.set_piece_layout(0, 1)
     counter = torch.zeros(1, dtype=torch.int64, device=device)
     kw = dict(use_visibility_graph=True, draw_bounds=False)
     r.render(args.size, args.size, args.transparency, 1, cam, samples=counter, **kw)
@@ -164,7 +190,10 @@ def child(extra):
     raise SystemExit(f"worker failed: {' '.join(cmd)}\n{out.stdout[-2000:]}\n{out.stderr[-2000:]}")
 
 
-print(f"{args.config}, {args.size}^2, ownership {args.ownership}", flush=True)
+print(f"{args.config}, {args.size}^2, ownership {args.ownership}, "
+      f"{'contiguous pieces' if args.contiguous_pieces else 'row-band pieces'}, "
+      f"{'no RCCL in the share processes' if args.no_rccl else 'live one-rank RCCL communicator in every share process'}",
+      flush=True)
 summary = []
 for n_ranks in args.ranks:
     per_rank = []
