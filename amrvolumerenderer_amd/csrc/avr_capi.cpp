@@ -84,12 +84,37 @@ class StagingRing {
       if (slot.dev != nullptr) (void)hipFree(slot.dev);
       if (slot.host != nullptr) (void)hipHostFree(slot.host);
       if (slot.done != nullptr) (void)hipEventDestroy(slot.done);
+      if (slot.consumed != nullptr) (void)hipEventDestroy(slot.consumed);
       slot = Slot{};
+    }
+  }
+
+  // Copies run on this stream instead of the consumer's (nullptr: on the consumer's, the default).
+  // The consumer then only waits for an event that is usually long signalled -- the host runs
+  // frames ahead of the GPU -- instead of executing the copy between two of its kernels
+  // (measured on a rank of eight: 17 + 5 + 8 us between two marches for the waits, the copy and
+  // the launch; tools/share_timeline.py).
+  void set_upload_stream(hipStream_t stream) { upload_stream_ = stream; }
+
+  // With a separate upload stream a block's device twin is no longer protected by stream order
+  // (the copy of a later batch could overtake the kernels that still read this one): the
+  // consumer stream records, after the batch's kernels, that the twin is free.  Done lazily --
+  // by the next begin(), when every launch of the batch has been issued (a context is used by
+  // one thread).
+  void close_batch() {
+    if (current_ != nullptr && current_->consumer != nullptr) {
+      if (current_->consumed == nullptr) {
+        hip_check(hipEventCreateWithFlags(&current_->consumed, hipEventDisableTiming), "hipEventCreate");
+      }
+      hip_check(hipEventRecord(current_->consumed, current_->consumer), "hipEventRecord(staging)");
+      current_->consumer = nullptr;
+      current_->consumed_pending = true;
     }
   }
 
   // Starts a batch with room for `bytes` in `items` arrays.
   void begin(size_t bytes, int items) {
+    close_batch();
     current_ = &slots_[next_];
     next_ = (next_ + 1) % kSlots;
     if (current_->done == nullptr) {
@@ -98,6 +123,10 @@ class StagingRing {
     if (current_->pending) {
       wait_event(current_->done, "hipEventQuery(staging)");
       current_->pending = false;
+    }
+    if (current_->consumed_pending) {
+      wait_event(current_->consumed, "hipEventQuery(staging)");
+      current_->consumed_pending = false;
     }
     const size_t need = bytes + static_cast<size_t>(items + 1) * kAlign;
     if (need > current_->capacity) {
@@ -133,20 +162,30 @@ class StagingRing {
   // pinned memory was measured to block the host until the stream had drained, every few frames
   // (5-7 ms with five 1.3 ms frames queued; tools/host_stalls.py), and a launch never does.
   void commit(hipStream_t stream) {
+    hipStream_t copier = (upload_stream_ != nullptr) ? upload_stream_ : stream;
     if (used_ != 0) {
-      const int status = launch_upload(current_->host_mapped, current_->dev, used_, stream);
+      const int status = launch_upload(current_->host_mapped, current_->dev, used_, copier);
       if (status != AVR_OK) throw HipFailure(g_last_error);
     }
-    hip_check(hipEventRecord(current_->done, stream), "hipEventRecord(staging)");
+    hip_check(hipEventRecord(current_->done, copier), "hipEventRecord(staging)");
     current_->pending = true;
+    if (copier != stream) {
+      hip_check(hipStreamWaitEvent(stream, current_->done, 0), "hipStreamWaitEvent(staging)");
+      current_->consumer = stream;  // close_batch() records when its kernels are through
+    }
   }
 
   // Blocks until every committed batch has been copied (before the context's stream changes).
   void drain() {
+    close_batch();
     for (Slot& slot : slots_) {
       if (slot.pending) {
         wait_event(slot.done, "hipEventQuery(staging)");
         slot.pending = false;
+      }
+      if (slot.consumed_pending) {
+        wait_event(slot.consumed, "hipEventQuery(staging)");
+        slot.consumed_pending = false;
       }
     }
   }
@@ -157,9 +196,13 @@ class StagingRing {
     void* host = nullptr;
     void* host_mapped = nullptr;  // device address of `host`
     size_t capacity = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;      // the copy has run: the pinned block may be refilled
     bool pending = false;
+    hipEvent_t consumed = nullptr;  // separate upload stream: the kernels reading the twin are through
+    bool consumed_pending = false;
+    hipStream_t consumer = nullptr;
   };
+  hipStream_t upload_stream_ = nullptr;
   Slot slots_[kSlots];
   Slot* current_ = nullptr;
   int next_ = 0;
@@ -404,6 +447,10 @@ namespace avr {
 void* context_stream(avr_context* ctx) {
   bind_device(ctx);
   return ctx->stream;
+}
+void context_set_upload_stream(avr_context* ctx, void* stream) {
+  ctx->staging.drain();
+  ctx->staging.set_upload_stream(static_cast<hipStream_t>(stream));
 }
 }  // namespace avr
 

@@ -326,6 +326,85 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
   });
 }
 
+int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_order,
+                        int64_t n_pixels, int bytes_per_pixel, const void* image, void* slices) {
+  return guarded([&]() -> int {
+    require(comm != nullptr, "null communicator");
+    hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
+    const int n = comm->n_ranks, me = comm->rank;
+    require(n_pixels >= 0 && bytes_per_pixel > 0, "invalid image description");
+    // group position k <-> rank
+    std::vector<int> rank_at(static_cast<size_t>(n)), position_of(static_cast<size_t>(n), -1);
+    for (int k = 0; k < n; ++k) {
+      const int member = group_order != nullptr ? group_order[k] : k;
+      require(member >= 0 && member < n && position_of[static_cast<size_t>(member)] < 0,
+              "group_order must be a permutation of the ranks");
+      rank_at[static_cast<size_t>(k)] = member;
+      position_of[static_cast<size_t>(member)] = k;
+    }
+    const int64_t piece_size = n_pixels / n;  // getPieceRange (DirectSendBase.cpp:59-74)
+    auto piece_range = [&](int k, int64_t* begin, int64_t* end) {
+      *begin = piece_size * k;
+      *end = (k < n - 1) ? *begin + piece_size : n_pixels;
+    };
+    int64_t my_begin = 0, my_end = 0;
+    const int my_position = position_of[static_cast<size_t>(me)];
+    piece_range(my_position, &my_begin, &my_end);
+    const int64_t my_bytes = (my_end - my_begin) * bytes_per_pixel;
+    require(n_pixels == 0 || (image != nullptr && slices != nullptr), "null image");
+    const char* src = static_cast<const char*>(image);
+    char* dst = static_cast<char*>(slices);
+    // the block this rank keeps: its own piece of its own image, at its own group position
+    auto keep_own = [&] {
+      if (my_bytes > 0) {
+        avr::hip_ok(hipMemcpyAsync(dst + my_position * my_bytes, src + my_begin * bytes_per_pixel,
+                                   static_cast<size_t>(my_bytes), hipMemcpyDeviceToDevice, stream),
+                    "hipMemcpyAsync(exchange_pieces)");
+      }
+    };
+    if (comm->solo || (n == 1 && comm->nccl == nullptr && !comm->local)) {
+      keep_own();
+      return AVR_OK;
+    }
+    if (comm->local) {
+      avr::LocalWorld& world = *comm->local;
+      drain(stream);  // my image is complete
+      world.base[static_cast<size_t>(me)] = src;
+      world.barrier();
+      for (int k = 0; k < n; ++k) {  // the image of the rank at position k, my piece of it
+        if (my_bytes == 0) break;
+        avr::hip_ok(hipMemcpyAsync(dst + k * my_bytes,
+                                   world.base[static_cast<size_t>(rank_at[static_cast<size_t>(k)])] +
+                                       my_begin * bytes_per_pixel,
+                                   static_cast<size_t>(my_bytes), hipMemcpyDeviceToDevice, stream),
+                    "hipMemcpyAsync(exchange_pieces)");
+      }
+      drain(stream);
+      world.barrier();  // every rank has pulled: the images may be rewritten
+      return AVR_OK;
+    }
+    const avr::Rccl& api = avr::rccl();
+    if (n > 1) keep_own();
+    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    for (int k = 0; k < n; ++k) {
+      const int peer = rank_at[static_cast<size_t>(k)];
+      if (peer == me && n > 1) continue;  // (a one-rank communicator sends to itself on purpose)
+      int64_t b = 0, e = 0;
+      piece_range(k, &b, &e);
+      if (e > b) {  // piece k of my image -> the rank at position k
+        avr::nccl_ok(api.send(src + b * bytes_per_pixel, static_cast<size_t>((e - b) * bytes_per_pixel),
+                              ncclChar, peer, comm->nccl, stream), "ncclSend");
+      }
+      if (my_bytes > 0) {  // my piece of its image, into the block of its position
+        avr::nccl_ok(api.recv(dst + k * my_bytes, static_cast<size_t>(my_bytes), ncclChar, peer,
+                              comm->nccl, stream), "ncclRecv");
+      }
+    }
+    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    return AVR_OK;
+  });
+}
+
 int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const void* piece,
                int bytes_per_pixel, void* full, int root) {
   return guarded([&]() -> int {

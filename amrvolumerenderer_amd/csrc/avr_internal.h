@@ -355,6 +355,8 @@ bool visibility_order(avr_visibility_graph* graph, const avr_camera& camera, flo
 void set_error(const std::string& message);
 // The context's HIP stream (hipStream_t; created on first use) with its device made current.
 void* context_stream(avr_context* ctx);
+// Descriptor copies of this context run on `stream` (hipStream_t; nullptr = on its own stream).
+void context_set_upload_stream(avr_context* ctx, void* stream);
 
 }  // namespace avr
 

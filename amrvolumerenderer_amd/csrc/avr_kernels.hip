@@ -522,6 +522,8 @@ render_runs_kernel(
 
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int lane = static_cast<int>(threadIdx.x) & 63;
+#if !defined(AVR_WAVE_SHAPE) || AVR_WAVE_SHAPE == 0
+  constexpr int kWaveW = 8, kWaveH = 8;
   const int wave_x0 = tile_x * kTile + (wave & 1) * 8;  // wave-uniform 8x8 sub-tile
   const int wave_y0 = tile_y * kTile + (wave >> 1) * 8;
   // lane -> pixel: every 16 consecutive lanes (the unit the texture addresser works on) cover a
@@ -529,6 +531,21 @@ render_runs_kernel(
   // bricklets (cache lines) per address-processing group
   const int px = wave_x0 + (lane & 3) + ((lane >> 2) & 4);
   const int py = wave_y0 + ((lane >> 2) & 3) + ((lane >> 3) & 4);
+#elif AVR_WAVE_SHAPE == 1
+  // experiment: a wave is a 16 x 4 strip (four 4 x 4 patches side by side)
+  constexpr int kWaveW = 16, kWaveH = 4;
+  const int wave_x0 = tile_x * kTile;
+  const int wave_y0 = tile_y * kTile + wave * 4;
+  const int px = wave_x0 + (lane & 3) + ((lane >> 4) << 2);
+  const int py = wave_y0 + ((lane >> 2) & 3);
+#else
+  // experiment: a wave is a 4 x 16 column (four 4 x 4 patches on top of each other)
+  constexpr int kWaveW = 4, kWaveH = 16;
+  const int wave_x0 = tile_x * kTile + wave * 4;
+  const int wave_y0 = tile_y * kTile;
+  const int px = wave_x0 + (lane & 3);
+  const int py = wave_y0 + ((lane >> 2) & 3) + ((lane >> 4) << 2);
+#endif
   const bool live = (px < fc.width) && (py < fc.height);
   const int64_t n_pixels = static_cast<int64_t>(fc.width) * fc.height;
   const int64_t p = static_cast<int64_t>(py) * fc.width + px;
@@ -548,8 +565,8 @@ render_runs_kernel(
     for (int position = (run > 0) ? run_end[run - 1] : 0; position < end; ++position) {
       const BoxDev& box = boxes[order[position]];
       // wave-uniform cull against the box's conservative screen rectangle
-      if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + 7 || box.rect[3] < wave_y0 ||
-          box.rect[1] > wave_y0 + 7) {
+      if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + (kWaveW - 1) || box.rect[3] < wave_y0 ||
+          box.rect[1] > wave_y0 + (kWaveH - 1)) {
         continue;
       }
       float tmin = -AVR_INF;

@@ -80,10 +80,20 @@ CONFIG_IMAGE = {"config1": (256, 256), "config2": (1024, 1024), "config3": (2048
                 "hostbound": (2048, 2048)}
 
 
-def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
-    """Times the oracle (the CPU restatement of VolumePainter::paint, oracle/avr_oracle.c) on
-    a bounded stratified sample of this scene's boxes at the full image size, on the host
-    cores of this box.  Reported beside the GPU number; never the thing measured or shipped."""
+def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_samples):
+    """The reference's frame in the reference's shape, on the host cores of this box, through the
+    oracle (the CPU restatement, oracle/avr_oracle.c) -- reported beside the GPU number; never the
+    thing measured or shipped.
+
+    renderSingleTrial times three stages (reportStageTime, VolumeRenderer.cpp:1121-1136):
+    per-box rendering (:1200-1219: VolumePainter::paint into one full-frame layer per box),
+    compositing (:1231-1253: composeLayered) and gather + write; the reference is serial per rank
+    (AMReX_OMP OFF) and parallel over MPI ranks.  Here, inside ~`seconds` of CPU time: every 4th
+    box of the level-major list is painted at full resolution on T threads (OpenMP over image
+    rows stands in for T ranks painting their own boxes), every 16th also on one thread (= one
+    reference rank); the painted layers are folded by orc_compose_layered on one thread (what one
+    rank does for its piece, times the ranks); the result is converted to bytes.  Stage times of
+    the whole frame are extrapolated by samples (paint) and by layers (compose) and say so."""
     import numpy as np
     from oracle import oracle as O
     threads = min(os.cpu_count() or 1, 16)
@@ -97,31 +107,63 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds):
                        renderer.reference_sample_distance, spec.bounds.min_corner,
                        spec.bounds.max_corner)
     n = len(local_boxes)
-    # stratified: a stride-16 sweep over the level-major box list (offsets 0, 8, 4, 12, ...), so
-    # any prefix is spread over all levels; stop at the time budget
-    offsets = [0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15]
-    picks = [i for o in offsets for i in range(o, n, 16)]
-    total_samples, total_time, used = 0, 0.0, 0
-    for i in picks * 8:   # whole frames back to back until the time budget is reached
+    stride = 4 if n >= 16 else 1
+    picks = list(range(0, n, stride))
+    budget_end = time.perf_counter() + seconds
+    layers, hints = [], []
+    paint_s = paint_samples = 0
+    serial_s = serial_samples = 0
+    for count, i in enumerate(picks):
         box = local_boxes[i]
-        cells = box.values.cpu().numpy()
-        ob = O.make_box(cells, box.min_corner, box.max_corner)
+        ob = O.make_box(box.values.cpu().numpy(), box.min_corner, box.max_corner)
         t0 = time.perf_counter()
-        _, ns = O.paint_box(ob, otr, op, ocam, threads=threads)
-        total_time += time.perf_counter() - t0
-        total_samples += ns
-        used += 1
-        if total_time >= seconds:
+        layer, ns = O.paint_box(ob, otr, op, ocam, threads=threads)
+        paint_s += time.perf_counter() - t0
+        paint_samples += ns
+        layers.append(layer)
+        hints.append(O.box_depth_hint(ob, ocam))
+        if count % 4 == 0 and time.perf_counter() < budget_end:   # one reference rank
+            t0 = time.perf_counter()
+            _, ns1 = O.paint_box(ob, otr, op, ocam, threads=1)
+            serial_s += time.perf_counter() - t0
+            serial_samples += ns1
+        if time.perf_counter() > budget_end and len(layers) >= 8:
             break
+    used = len(layers)
+    t0 = time.perf_counter()
+    image, _, _ = O.compose_layered(layers, hints, [0] * used, list(range(used)), 1)
+    compose_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.quantize_rgb8(image, params.width, params.height)
+    bytes_s = time.perf_counter() - t0
+    # the whole frame: paint scales with the samples, the fold with the layers
+    total = float(frame_samples)
+    paint_frame = paint_s * total / max(paint_samples, 1)
+    paint_serial = serial_s * total / max(serial_samples, 1)
+    compose_serial = compose_s * n / used
+    compose_ranks = compose_serial / threads    # every rank folds its own 1/T of the pixels
+    frame = paint_frame + compose_ranks + bytes_s
+    frame_serial = paint_serial + compose_serial + bytes_s
     return {
-        "value": round(total_samples / max(total_time, 1e-9) / 1e6, 3),
-        "unit": "Mray-samples/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"oracle VolumePainter::paint of {used} box paints ({n} boxes in the scene; "
-                  f"stride-16 sweeps of the level-major box list, repeated) at {params.width}x{params.height}, same camera and "
-                  f"transfer function, {total_samples} samples in {total_time:.1f} s, "
-                  f"OpenMP over image rows",
+        "value": round(total / frame / 1e6, 3), "unit": "Mray-samples/s", "cores": threads,
+        "kind": "port", "frames_per_s": round(1.0 / frame, 4),
+        "stages_s": {"per_box_rendering": round(paint_frame, 3),
+                     "compositing": round(compose_ranks, 3),
+                     "gather_and_bytes": round(bytes_s, 3)},
+        "one_rank": {"frames_per_s": round(1.0 / frame_serial, 4),
+                     "value": round(total / frame_serial / 1e6, 3),
+                     "stages_s": {"per_box_rendering": round(paint_serial, 3),
+                                  "compositing": round(compose_serial, 3),
+                                  "gather_and_bytes": round(bytes_s, 3)}},
+        "sample": f"oracle frame in the reference's stages (VolumeRenderer.cpp:1121-1136) at "
+                  f"{params.width}x{params.height}, same camera and transfer function: "
+                  f"VolumePainter::paint of {used} of the {n} boxes (every {stride}th of the "
+                  f"level-major list, {paint_samples} samples in {paint_s:.2f} s on {threads} "
+                  f"OpenMP threads over image rows; {serial_samples} samples in {serial_s:.2f} s "
+                  f"on one thread = one reference rank), orc_compose_layered of those {used} "
+                  f"full-frame layers on one thread ({compose_s:.2f} s; divided by {threads} for "
+                  f"{threads} ranks folding their own pieces), 8-bit conversion {bytes_s:.3f} s; "
+                  f"stage times extrapolated to the frame's {int(total)} samples / {n} layers",
     }
 
 
@@ -517,7 +559,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, local_boxes, renderer, rparams, cameras[0],
-                                           args.cpu_seconds)
+                                           args.cpu_seconds, frame_samples[0])
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

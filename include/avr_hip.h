@@ -449,6 +449,16 @@ int avr_comm_size(const avr_comm *comm);
  * context's stream. */
 int avr_exchange(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm, const float *send,
                  float *recv);
+/* Classic direct send of ONE image per rank -- DirectSendBase::compose(localImage, sendGroup,
+ * recvGroup, comm) for a plain (not layered) image, DirectSend/Base/DirectSendBase.cpp:76-177,
+ * 257-281: every rank's image (n_pixels * bytes_per_pixel bytes, device) is cut into the n pieces of
+ * avr_piece_range; piece k goes to the rank at position k of group_order (NULL = rank order).
+ * Received: `slices` = n blocks of this rank's own piece (its pixel count * bytes_per_pixel bytes
+ * each), block j cut from the image of the rank at group position j -- the order in which
+ * ProcessIncomingImages blends them (:179-255: the lower position on top).  One grouped ncclSend /
+ * ncclRecv round on the context's stream; fold the blocks with avr_blend_regions. */
+int avr_exchange_pieces(avr_context *ctx, avr_comm *comm, const int32_t *group_order,
+                        int64_t n_pixels, int bytes_per_pixel, const void *image, void *slices);
 /* ImageFull::Gather: every rank's piece (bytes_per_pixel bytes per pixel: 20 for the depth-sort
  * image, 3 for its RGB8 bytes) lands at its pixel range in `full` on rank `root` (full is ignored
  * elsewhere).  Collective; on the context's stream. */

@@ -249,7 +249,7 @@ inline std::pair<int64_t, int64_t> blend_regions_host(Context& context, int kind
 // by depth hint and left-folded.)  `layers` exposes getLayerCount(), getLayer(i) (an image with
 // getColorBuffer()/getNumberOfPixels()) and getLayerDepthHint(i), as LayeredVolumeImage does.
 // Multi-rank compositing goes through the frame plan (avr_frame_plan_*) and RCCL.
-template <class LayeredT>
+template <class ConcreteT, class LayeredT>
 std::vector<float> compose_single_rank(Context& context, LayeredT& layers, int64_t n_pixels) {
   const int count = layers.getLayerCount();
   std::vector<float> hints(static_cast<std::size_t>(count));
@@ -268,7 +268,10 @@ std::vector<float> compose_single_rank(Context& context, LayeredT& layers, int64
   std::vector<const float*> slices;
   for (int l = 0; l < count; ++l) {
     auto buffer = std::make_unique<DeviceBuffer<float>>(floats);
-    buffer->upload(layers.getLayer(order[static_cast<std::size_t>(l)])->getColorBuffer(), floats);
+    // (getLayer hands out the base class `Image`, Common/LayeredImageInterface.hpp:17-20)
+    buffer->upload(static_cast<ConcreteT*>(layers.getLayer(order[static_cast<std::size_t>(l)]))
+                       ->getColorBuffer(),
+                   floats);
     slices.push_back(buffer->data());
     device_layers.push_back(std::move(buffer));
   }
@@ -325,16 +328,104 @@ class Communicator {
 // ---- Compositor plugin (Common/Compositor.hpp:19-40) -------------------------------------------
 // HipDirectSend::compose has the reference's call shape
 //     std::unique_ptr<Image> compose(Image* localImage, MPI_Group group, MPI_Comm communicator)
-// and DirectSendBase's behaviour (DirectSend/Base/DirectSendBase.cpp:285-458): a localImage that
-// offers the LayeredImageInterface (getLayerCount / getLayer / getLayerDepthHint /
-// createEmptyLayer, Common/LayeredImageInterface.hpp:9-28) is composited by global depth order
-// with same-owner runs folded on the owner; the result is this rank's piece
-// [k * floor(P/N), (k+1) * floor(P/N)) (k = position in the ordered group) of the fully composited
-// image, as a new image of the layers' type.  The layers are host images as in the reference
-// (ImageRGBAFloatColorDepthSort: getColorBuffer(), 5 floats per pixel); they are staged to HBM,
-// exchanged over RCCL and folded there.  This is the drop-in for code that already has painted
-// layers; a renderer that lets this library paint as well uses FrameDriver below and never
-// materialises per-box layers.
+// and DirectSendBase's behaviour (DirectSend/Base/DirectSendBase.cpp:285-458):
+//  * a localImage that offers the LayeredImageInterface (getLayerCount / getLayer /
+//    getLayerDepthHint / createEmptyLayer, Common/LayeredImageInterface.hpp:9-28) is composited by
+//    global depth order with same-owner runs folded on the owner (composeLayered, :316-458);
+//  * any other image takes the classic direct send (:257-281, 76-255): every rank's image is cut
+//    into pieces, piece k goes to the rank at position k of the group, which blends what it
+//    receives in group order (the lower position on top).
+// Either way the result is this rank's piece [k * floor(P/N), (k+1) * floor(P/N)) (k = position in
+// the ordered group) of the fully composited image, as a new image of the input's type.
+//
+// The images are host images as in the reference (ImageColorOnly<Features>: getColorBuffer());
+// they are staged to HBM, exchanged over RCCL and blended there.  A layer whose getColorBuffer()
+// already IS device memory is used in place.  Every buffer the compositor needs -- the device
+// staging of the layers, a two-slot pinned upload ring, send / receive / piece buffers -- is
+// pooled in the object and only ever grows: after the first frame of a given shape a compose
+// allocates nothing (allocations() counts; tests/cxx/adapter_test.cpp asserts it).  Uploads are
+// asynchronous: while layer i travels to the GPU, layer i+1 is copied into the other pinned slot.
+// This is the drop-in for code that already has painted layers; a renderer that lets this library
+// paint as well uses FrameDriver below and never materialises per-box layers.
+
+// Grow-only buffers; every (re)allocation is counted by the owner.
+template <typename T>
+class PooledDeviceBuffer {
+ public:
+  PooledDeviceBuffer() = default;
+  ~PooledDeviceBuffer() {
+    if (ptr_ != nullptr) (void)hipFree(ptr_);
+  }
+  PooledDeviceBuffer(const PooledDeviceBuffer&) = delete;
+  PooledDeviceBuffer& operator=(const PooledDeviceBuffer&) = delete;
+  // at least `count` elements (contents are not kept when it grows)
+  T* reserve(std::size_t count, std::size_t* allocations) {
+    if (count > capacity_) {
+      if (ptr_ != nullptr) (void)hipFree(ptr_);
+      ptr_ = nullptr;
+      capacity_ = 0;
+      hip_ok(hipMalloc(reinterpret_cast<void**>(&ptr_), count * sizeof(T)), "hipMalloc(pool)");
+      capacity_ = count;
+      ++*allocations;
+    }
+    return ptr_;
+  }
+
+ private:
+  T* ptr_ = nullptr;
+  std::size_t capacity_ = 0;
+};
+
+class PooledPinnedBuffer {
+ public:
+  PooledPinnedBuffer() = default;
+  ~PooledPinnedBuffer() {
+    if (ptr_ != nullptr) (void)hipHostFree(ptr_);
+    if (free_ != nullptr) (void)hipEventDestroy(free_);
+  }
+  PooledPinnedBuffer(const PooledPinnedBuffer&) = delete;
+  PooledPinnedBuffer& operator=(const PooledPinnedBuffer&) = delete;
+  void* reserve(std::size_t bytes, std::size_t* allocations) {
+    if (bytes > capacity_) {
+      wait();
+      if (ptr_ != nullptr) (void)hipHostFree(ptr_);
+      ptr_ = nullptr;
+      capacity_ = 0;
+      hip_ok(hipHostMalloc(&ptr_, bytes, hipHostMallocDefault), "hipHostMalloc(pool)");
+      capacity_ = bytes;
+      ++*allocations;
+    }
+    return ptr_;
+  }
+  // the copy out of this slot has been queued on `stream`: the slot is free when it has run
+  void in_flight(hipStream_t stream) {
+    if (free_ == nullptr) hip_ok(hipEventCreateWithFlags(&free_, hipEventDisableTiming), "hipEventCreate");
+    hip_ok(hipEventRecord(free_, stream), "hipEventRecord");
+    busy_ = true;
+  }
+  void wait() {
+    if (busy_) hip_ok(hipEventSynchronize(free_), "hipEventSynchronize");
+    busy_ = false;
+  }
+
+ private:
+  void* ptr_ = nullptr;
+  std::size_t capacity_ = 0;
+  hipEvent_t free_ = nullptr;
+  bool busy_ = false;
+};
+
+// Which Features::blend an image type carries (Common/ImageColorOnly.hpp:36-38: ColorType and
+// ColorVecSize are public members of every ImageColorOnly<Features>).
+template <class ConcreteT>
+constexpr int blend_kind_of() {
+  using Color = typename ConcreteT::ColorType;
+  if (std::is_same<Color, float>::value && ConcreteT::ColorVecSize == 5) return 0;  // depth sort
+  if (std::is_same<Color, float>::value && ConcreteT::ColorVecSize == 4) return 1;  // RGBA float
+  if (sizeof(Color) == 4 && ConcreteT::ColorVecSize == 1) return 2;                  // RGBA ubyte
+  return -1;
+}
+
 template <class Control>
 class HipDirectSend {
  public:
@@ -346,13 +437,39 @@ class HipDirectSend {
   HipDirectSend(Control& control, int device, Communicator* comm)
       : control_(control), context_(device), comm_(comm) {}
 
-  // ConcreteT: the layers' image type (the reference's ImageRGBAFloatColorDepthSort; getLayer
-  // and createEmptyLayer hand out its base class `Image` there).  LayeredT: an image that is
-  // also a LayeredImageInterface (the reference's LayeredVolumeImage).
+  // (re)allocations of pooled buffers so far: constant once the frames' shape has been seen
+  std::size_t allocations() const { return allocations_; }
+
+  // Compositor::compose.  ConcreteT: the image type that carries the pixels -- the layers' type
+  // for a layered image (the reference's ImageRGBAFloatColorDepthSort; getLayer and
+  // createEmptyLayer hand out its base class `Image` there), the image's own type otherwise.
+  // ImageT: what the caller holds (the reference's `Image`); LayeredT: the layered image class it
+  // may turn out to be (the reference's LayeredVolumeImage, found by dynamic_cast as in
+  // DirectSendBase.cpp:288-298).
+  template <class ConcreteT, class LayeredT, class ImageT, class GroupT, class CommT>
+  std::unique_ptr<ImageT> compose(ImageT* localImage, GroupT group, CommT communicator) {
+    if (localImage == nullptr) throw std::invalid_argument("compose: null image");
+    if (auto* layered = dynamic_cast<LayeredT*>(localImage)) {
+      if constexpr (blend_kind_of<ConcreteT>() == 0) {
+        return composeLayered<ConcreteT>(layered, group, communicator);
+      } else {
+        throw std::runtime_error("HipDirectSend: a layered image holds depth-sorted RGBA float layers");
+      }
+    }
+    auto* plain = dynamic_cast<ConcreteT*>(localImage);
+    if (plain == nullptr) {
+      throw std::runtime_error("HipDirectSend: the image is neither layered nor of the expected type");
+    }
+    return composeImage(plain, group, communicator);
+  }
+
+  // composeLayered (DirectSendBase.cpp:316-458) of a LayeredImageInterface.
   template <class ConcreteT, class LayeredT, class GroupT, class CommT>
-  auto compose(LayeredT* localImage, GroupT group, CommT /*communicator*/)
+  auto composeLayered(LayeredT* localImage, GroupT group, CommT /*communicator*/)
       -> decltype(localImage->createEmptyLayer(0, 0)) {
     if (localImage == nullptr) throw std::invalid_argument("compose: null image");
+    static_assert(blend_kind_of<ConcreteT>() == 0,
+                  "layered compositing blends depth-sorted RGBA float layers");
     const int n_ranks = control_.size(), rank = control_.rank();
     const int local_count = localImage->getLayerCount();
     // MPI_Allgather of the layer counts, MPI_Allgatherv of the depth hints (:329-361)
@@ -382,36 +499,135 @@ class HipDirectSend {
     std::unique_ptr<avr_frame_plan, void (*)(avr_frame_plan*)> plan_guard(plan, avr_frame_plan_destroy);
     avr_frame_plan_info info{};
     check(avr_frame_plan_get_info(plan, &info));
-    // stage the local layers, fold the local runs into the send layout
+    // the local layers in HBM (device-resident ones in place), then the owner-side run fold into
+    // the send layout
     const std::size_t floats = static_cast<std::size_t>(width) * height * 5;
-    std::vector<std::unique_ptr<DeviceBuffer<float>>> staged;
-    std::vector<const float*> pointers;
+    hipStream_t stream = static_cast<hipStream_t>(avr_context_stream(context_.get()));
+    std::vector<const float*> pointers(static_cast<std::size_t>(local_count), nullptr);
+    std::size_t staged = 0;
     for (int i = 0; i < local_count; ++i) {
-      auto buffer = std::make_unique<DeviceBuffer<float>>(floats);
-      buffer->upload(static_cast<ConcreteT*>(localImage->getLayer(i))->getColorBuffer(), floats);
-      pointers.push_back(buffer->data());
-      staged.push_back(std::move(buffer));
+      const float* pixels = static_cast<ConcreteT*>(localImage->getLayer(i))->getColorBuffer();
+      if (is_device_pointer(pixels)) {
+        pointers[static_cast<std::size_t>(i)] = pixels;
+      } else {
+        ++staged;
+      }
     }
-    DeviceBuffer<float> send(static_cast<std::size_t>(info.send_floats) + 1),
-        recv(static_cast<std::size_t>(info.recv_floats) + 1);
-    check(avr_pack_layers(context_.get(), plan, pointers.data(), local_count, send.data()));
-    check(avr_exchange(context_.get(), plan, comm_->get(), send.data(), recv.data()));
+    float* staging = layers_.reserve(staged * floats, &allocations_);
+    std::size_t slot = 0, at = 0;
+    for (int i = 0; i < local_count; ++i) {
+      if (pointers[static_cast<std::size_t>(i)] != nullptr) continue;
+      const float* pixels = static_cast<ConcreteT*>(localImage->getLayer(i))->getColorBuffer();
+      float* twin = staging + at * floats;
+      upload(pixels, twin, floats * sizeof(float), &slot, stream);
+      pointers[static_cast<std::size_t>(i)] = twin;
+      ++at;
+    }
+    float* send = send_.reserve(static_cast<std::size_t>(info.send_floats) + 1, &allocations_);
+    float* recv = recv_.reserve(static_cast<std::size_t>(info.recv_floats) + 1, &allocations_);
+    check(avr_pack_layers(context_.get(), plan, pointers.data(), local_count, send));
+    check(avr_exchange(context_.get(), plan, comm_->get(), send, recv));
     const std::size_t piece_pixels = static_cast<std::size_t>(info.piece_end - info.piece_begin);
-    DeviceBuffer<float> piece(piece_pixels * 5 + 1);
-    check(avr_fold_plan(context_.get(), plan, recv.data(), piece.data(), nullptr));
-    context_.synchronize();
+    float* piece = piece_.reserve(piece_pixels * 5 + 1, &allocations_);
+    check(avr_fold_plan(context_.get(), plan, recv, piece, nullptr));
     // the result image: this rank's pixel range, created like the reference's empty layer
     auto result = localImage->createEmptyLayer(static_cast<int>(info.piece_begin),
                                                static_cast<int>(info.piece_end));
-    piece.download(static_cast<ConcreteT*>(result.get())->getColorBuffer(), piece_pixels * 5);
+    download(piece, static_cast<ConcreteT*>(result.get())->getColorBuffer(),
+             piece_pixels * 5 * sizeof(float), stream);
+    return result;
+  }
+
+  // The classic direct send of one image per rank (DirectSendBase.cpp:257-281 with the receive
+  // group = the whole group, :300-311): piece k of every rank's image meets on the rank at group
+  // position k and is blended there in group order, the lower position on top
+  // (ProcessIncomingImages, :179-255, blends whichever neighbours have arrived; for the float
+  // types that association order is the reference's one degree of freedom -- here it is always
+  // the left fold).
+  template <class ConcreteT, class GroupT, class CommT>
+  auto composeImage(ConcreteT* localImage, GroupT group, CommT /*communicator*/)
+      -> decltype(localImage->createNew(0, 0)) {
+    constexpr int kind = blend_kind_of<ConcreteT>();
+    static_assert(kind >= 0, "no Features::blend of this image type is implemented on the GPU");
+    using Color = typename ConcreteT::ColorType;
+    constexpr std::size_t pixel_bytes = sizeof(Color) * ConcreteT::ColorVecSize;
+    if (localImage->getRegionBegin() != 0 ||
+        localImage->getRegionEnd() != localImage->getWidth() * localImage->getHeight()) {
+      throw std::invalid_argument("HipDirectSend: the local image must hold the whole frame");
+    }
+    const int n_ranks = control_.size(), rank = control_.rank();
+    const std::vector<int> ordered = control_.group_ranks(group);
+    if (static_cast<int>(ordered.size()) != n_ranks) {
+      throw std::invalid_argument("HipDirectSend: the group must hold every rank of the communicator");
+    }
+    std::vector<int32_t> group_order(ordered.begin(), ordered.end());
+    int position = 0;
+    while (position < n_ranks && group_order[static_cast<std::size_t>(position)] != rank) ++position;
+    const int64_t n_pixels = static_cast<int64_t>(localImage->getWidth()) * localImage->getHeight();
+    int64_t begin = 0, end = 0;
+    check(avr_piece_range(n_pixels, position, n_ranks, &begin, &end));
+    const std::size_t piece_bytes = static_cast<std::size_t>(end - begin) * pixel_bytes;
+    hipStream_t stream = static_cast<hipStream_t>(avr_context_stream(context_.get()));
+    const Color* pixels = localImage->getColorBuffer();
+    const void* image = pixels;
+    if (!is_device_pointer(pixels)) {
+      char* twin = image_.reserve(static_cast<std::size_t>(n_pixels) * pixel_bytes + 1, &allocations_);
+      std::size_t slot = 0;
+      upload(pixels, twin, static_cast<std::size_t>(n_pixels) * pixel_bytes, &slot, stream);
+      image = twin;
+    }
+    char* slices = slices_.reserve(piece_bytes * static_cast<std::size_t>(n_ranks) + 1, &allocations_);
+    check(avr_exchange_pieces(context_.get(), comm_->get(), group_order.data(), n_pixels,
+                              static_cast<int>(pixel_bytes), image, slices));
+    // left fold in group order: ((slice 0 over slice 1) over slice 2) ...
+    const char* top = slices;
+    char* scratch[2] = {fold_[0].reserve(piece_bytes + 1, &allocations_),
+                        fold_[1].reserve(piece_bytes + 1, &allocations_)};
+    for (int j = 1; j < n_ranks && end > begin; ++j) {
+      char* out = scratch[j & 1];
+      check(avr_blend_regions(context_.get(), kind, top, begin, end, slices + piece_bytes * j, begin,
+                              end, out));
+      top = out;
+    }
+    auto result = localImage->createNew(static_cast<int>(begin), static_cast<int>(end));
+    download(top, static_cast<ConcreteT*>(result.get())->getColorBuffer(), piece_bytes, stream);
     return result;
   }
 
  private:
+  // host -> HBM through the two-slot pinned ring, in chunks of at most 64 MiB: the CPU fills one
+  // slot while the DMA engine drains the other
+  void upload(const void* host, void* device, std::size_t bytes, std::size_t* slot, hipStream_t stream) {
+    constexpr std::size_t kChunk = std::size_t{64} << 20;
+    const char* src = static_cast<const char*>(host);
+    char* dst = static_cast<char*>(device);
+    for (std::size_t done = 0; done < bytes;) {
+      const std::size_t n = (bytes - done < kChunk) ? bytes - done : kChunk;
+      PooledPinnedBuffer& pinned = pinned_[*slot & 1];
+      pinned.wait();
+      void* block = pinned.reserve(n < kChunk && bytes > kChunk ? kChunk : n, &allocations_);
+      std::memcpy(block, src + done, n);
+      hip_ok(hipMemcpyAsync(dst + done, block, n, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+      pinned.in_flight(stream);
+      ++*slot;
+      done += n;
+    }
+  }
+  void download(const void* device, void* host, std::size_t bytes, hipStream_t stream) {
+    if (bytes != 0) {
+      hip_ok(hipMemcpyAsync(host, device, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    }
+    hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  }
+
   Control& control_;
   Context context_;
   std::unique_ptr<Communicator> owned_;
   Communicator* comm_ = nullptr;
+  std::size_t allocations_ = 0;
+  PooledDeviceBuffer<float> layers_, send_, recv_, piece_;
+  PooledDeviceBuffer<char> image_, slices_, fold_[2];
+  PooledPinnedBuffer pinned_[2];
 };
 
 // ---- frame driver: one rank's share of renderSingleTrial, pipelined (avr_renderer) --------------

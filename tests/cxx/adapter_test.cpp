@@ -72,31 +72,62 @@ struct ColorMapControlPoint {
 };
 using ColorMap = std::vector<ColorMapControlPoint>;
 
-struct DepthSortImage {  // ImageRGBAFloatColorDepthSort: 5 floats per pixel on the host
-  int width, height;
-  int regionBegin = 0;
-  std::vector<float> buffer;
-  DepthSortImage(int w, int h) : width(w), height(h), buffer(static_cast<size_t>(w) * h * 5) {}
+// Common/Image.hpp: the polymorphic base every image derives from (width, height, pixel region).
+struct Image {
+  int width, height, regionBegin, regionEnd;
+  Image(int w, int h, int begin, int end) : width(w), height(h), regionBegin(begin), regionEnd(end) {}
+  virtual ~Image() = default;
   int getWidth() const { return width; }
   int getHeight() const { return height; }
-  int getNumberOfPixels() const { return width * height; }
-  float* getColorBuffer() { return buffer.data(); }
-  const float* getColorBuffer() const { return buffer.data(); }
+  int getRegionBegin() const { return regionBegin; }
+  int getRegionEnd() const { return regionEnd; }
+  int getNumberOfPixels() const { return regionEnd - regionBegin; }
+  // createNew(regionBegin, regionEnd): same type, width and height, new region
+  virtual std::unique_ptr<Image> createNew(int begin, int end) const = 0;
 };
-struct Layered {  // LayeredVolumeImage: an Image that is also a LayeredImageInterface
-  int width = 0, height = 0;
+// Common/ImageColorOnly.hpp: ColorType / ColorVecSize / getColorBuffer() as the reference has them
+template <typename Features>
+struct ColorOnlyImage : Image {
+  using ColorType = typename Features::ColorType;
+  static constexpr int ColorVecSize = Features::ColorVecSize;
+  std::vector<ColorType> buffer;
+  ColorOnlyImage(int w, int h) : ColorOnlyImage(w, h, 0, w * h) {}
+  ColorOnlyImage(int w, int h, int begin, int end)
+      : Image(w, h, begin, end), buffer(static_cast<size_t>(end - begin) * ColorVecSize) {}
+  ColorType* getColorBuffer() { return buffer.data(); }
+  const ColorType* getColorBuffer() const { return buffer.data(); }
+  std::unique_ptr<Image> createNew(int begin, int end) const override {
+    return std::make_unique<ColorOnlyImage<Features>>(width, height, begin, end);
+  }
+};
+struct DepthSortFeatures {  // ImageRGBAFloatColorDepthSortFeatures
+  using ColorType = float;
+  static constexpr int ColorVecSize = 5;
+};
+struct FloatFeatures {  // ImageRGBAFloatColorOnlyFeatures
+  using ColorType = float;
+  static constexpr int ColorVecSize = 4;
+};
+struct UByteFeatures {  // ImageRGBAUByteColorOnlyFeatures
+  using ColorType = unsigned int;
+  static constexpr int ColorVecSize = 1;
+};
+using DepthSortImage = ColorOnlyImage<DepthSortFeatures>;  // ImageRGBAFloatColorDepthSort
+using FloatImage = ColorOnlyImage<FloatFeatures>;          // ImageRGBAFloatColorOnly
+using UByteImage = ColorOnlyImage<UByteFeatures>;          // ImageRGBAUByteColorOnly
+// LayeredVolumeImage: an Image that is also a LayeredImageInterface (getLayer hands out `Image*`)
+struct Layered : Image {
   std::vector<std::unique_ptr<DepthSortImage>> layers;
   std::vector<float> hints;
-  int getWidth() const { return width; }
-  int getHeight() const { return height; }
+  Layered(int w, int h) : Image(w, h, 0, w * h) {}
   int getLayerCount() const { return static_cast<int>(layers.size()); }
-  DepthSortImage* getLayer(int i) { return layers[static_cast<size_t>(i)].get(); }
+  Image* getLayer(int i) { return layers[static_cast<size_t>(i)].get(); }
   float getLayerDepthHint(int i) const { return hints[static_cast<size_t>(i)]; }
-  // createEmptyLayer(regionBegin, regionEnd): an image holding that pixel range
-  std::unique_ptr<DepthSortImage> createEmptyLayer(int begin, int end) const {
-    auto image = std::make_unique<DepthSortImage>(end - begin, 1);
-    image->regionBegin = begin;
-    return image;
+  std::unique_ptr<Image> createEmptyLayer(int begin, int end) const {
+    return std::make_unique<DepthSortImage>(width, height, begin, end);
+  }
+  std::unique_ptr<Image> createNew(int, int) const override {
+    throw std::runtime_error("LayeredVolumeImage does not support createNew");
   }
 };
 
@@ -219,9 +250,7 @@ int main(int argc, char** argv) {
       const int n_pixels = std::atoi(argv[4]);
       const std::vector<float> all =
           read_file<float>(argv[2], static_cast<size_t>(n_layers) * n_pixels * 5);
-      standin::Layered layered;
-      layered.width = n_pixels;
-      layered.height = 1;
+      standin::Layered layered(n_pixels, 1);
       layered.hints = read_file<float>(argv[5], static_cast<size_t>(n_layers));
       for (int l = 0; l < n_layers; ++l) {
         auto img = std::make_unique<standin::DepthSortImage>(n_pixels, 1);
@@ -229,7 +258,8 @@ int main(int argc, char** argv) {
                     sizeof(float) * static_cast<size_t>(n_pixels) * 5);
         layered.layers.push_back(std::move(img));
       }
-      const std::vector<float> out = avr::compose_single_rank(context, layered, n_pixels);
+      const std::vector<float> out =
+          avr::compose_single_rank<standin::DepthSortImage>(context, layered, n_pixels);
       write_file(argv[6], out.data(), out.size());
       return 0;
     }
@@ -364,9 +394,7 @@ int main(int argc, char** argv) {
             standin::ThreadControl control{&world, r};
             // (in the reference tree the communicator is RCCL over xGMI, built from MPI_COMM_WORLD;
             //  here the ranks share one GPU, so they are wired with the in-process communicator)
-            standin::Layered layered;  // geometry.localBoxes' layers of this rank, in order
-            layered.width = W;
-            layered.height = H;
+            standin::Layered layered(W, H);  // geometry.localBoxes' layers of this rank, in order
             for (int l = 0; l < n_layers; ++l) {
               if (owners[static_cast<size_t>(l)] != r) continue;
               auto img = std::make_unique<standin::DepthSortImage>(W, H);
@@ -380,8 +408,22 @@ int main(int argc, char** argv) {
             std::call_once(once, [&] { comms = avr::Communicator::local(n_ranks); });
             world.barrier();
             avr::HipDirectSend<standin::ThreadControl> compositor(control, 0, comms[static_cast<size_t>(r)].get());
-            auto piece = compositor.compose<standin::DepthSortImage>(&layered, group, 0);
-            std::memcpy(result.data() + static_cast<size_t>(piece->regionBegin) * 5, piece->getColorBuffer(),
+            // the caller holds an `Image*` (Compositor::compose's argument): the layered image is
+            // found by dynamic_cast as in DirectSendBase.cpp:288-298.  Three frames: after the
+            // first the pooled buffers have their size and nothing is allocated any more.
+            standin::Image* local = &layered;
+            std::unique_ptr<standin::Image> piece;
+            size_t after_first = 0;
+            for (int frame = 0; frame < 3; ++frame) {
+              piece = compositor.compose<standin::DepthSortImage, standin::Layered>(local, group, 0);
+              if (frame == 0) after_first = compositor.allocations();
+            }
+            if (compositor.allocations() != after_first) {
+              throw std::runtime_error("the compositor allocated after its first frame");
+            }
+            auto* pixels = static_cast<standin::DepthSortImage*>(piece.get());
+            std::memcpy(result.data() + static_cast<size_t>(piece->getRegionBegin()) * 5,
+                        pixels->getColorBuffer(),
                         sizeof(float) * static_cast<size_t>(piece->getNumberOfPixels()) * 5);
           } catch (const std::exception& e) {
             errors[static_cast<size_t>(r)] = e.what();
@@ -395,7 +437,70 @@ int main(int argc, char** argv) {
       write_file(argv[10], result.data(), result.size());
       return 0;
     }
-    std::fprintf(stderr, "usage: adapter_test paint|compose|frame|compose_ranks ...\n");
+    if (mode == "compose_image" && argc == 9) {
+      // classic direct send of ONE plain image per rank (DirectSendBase.cpp:257-281):
+      //   adapter_test compose_image <images.bin> <kind> <n_ranks> <W> <H> <group.bin> <out.bin>
+      // images.bin: n_ranks images of W*H pixels of the kind's pixel type; out: the gathered result
+      const int kind = std::atoi(argv[3]);
+      const int n_ranks = std::atoi(argv[4]);
+      const int W = std::atoi(argv[5]), H = std::atoi(argv[6]);
+      const size_t n_pixels = static_cast<size_t>(W) * H;
+      const size_t words = (kind == 0) ? 5 : (kind == 1) ? 4 : 1;  // 32-bit words per pixel
+      const std::vector<uint32_t> all =
+          read_file<uint32_t>(argv[2], static_cast<size_t>(n_ranks) * n_pixels * words);
+      const std::vector<int32_t> group32 = read_file<int32_t>(argv[7], static_cast<size_t>(n_ranks));
+      const std::vector<int> group(group32.begin(), group32.end());
+      standin::ThreadWorld world;
+      world.n = n_ranks;
+      std::vector<uint32_t> result(n_pixels * words, 0xdeadbeefu);
+      std::vector<std::string> errors(static_cast<size_t>(n_ranks));
+      std::vector<std::thread> threads;
+      auto comms = avr::Communicator::local(n_ranks);
+      auto run = [&](int r, auto image_tag) {
+        using ImageT = decltype(image_tag);
+        avr::hip_ok(hipSetDevice(0), "hipSetDevice");
+        standin::ThreadControl control{&world, r};
+        ImageT image(W, H);
+        std::memcpy(image.getColorBuffer(), all.data() + static_cast<size_t>(r) * n_pixels * words,
+                    n_pixels * words * 4);
+        avr::HipDirectSend<standin::ThreadControl> compositor(control, 0, comms[static_cast<size_t>(r)].get());
+        standin::Image* local = &image;  // not layered: the plugin takes the classic path
+        std::unique_ptr<standin::Image> piece;
+        size_t after_first = 0;
+        for (int frame = 0; frame < 2; ++frame) {
+          piece = compositor.template compose<ImageT, standin::Layered>(local, group, 0);
+          if (frame == 0) after_first = compositor.allocations();
+        }
+        if (compositor.allocations() != after_first) {
+          throw std::runtime_error("the compositor allocated after its first frame");
+        }
+        std::memcpy(result.data() + static_cast<size_t>(piece->getRegionBegin()) * words,
+                    static_cast<ImageT*>(piece.get())->getColorBuffer(),
+                    static_cast<size_t>(piece->getNumberOfPixels()) * words * 4);
+      };
+      for (int r = 0; r < n_ranks; ++r) {
+        threads.emplace_back([&, r] {
+          try {
+            if (kind == 0) run(r, standin::DepthSortImage(1, 1));
+            else if (kind == 1) run(r, standin::FloatImage(1, 1));
+            else run(r, standin::UByteImage(1, 1));
+          } catch (const std::exception& e) {
+            errors[static_cast<size_t>(r)] = e.what();
+          }
+        });
+      }
+      for (std::thread& t : threads) t.join();
+      for (const std::string& e : errors) {
+        if (!e.empty()) throw std::runtime_error("rank failed: " + e);
+      }
+      FILE* out = std::fopen(argv[8], "wb");
+      if (!out || std::fwrite(result.data(), 4, result.size(), out) != result.size()) {
+        throw std::runtime_error("cannot write the result");
+      }
+      std::fclose(out);
+      return 0;
+    }
+    std::fprintf(stderr, "usage: adapter_test paint|compose|frame|compose_ranks|compose_image ...\n");
     return 2;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "adapter_test: %s\n", e.what());

@@ -131,3 +131,53 @@ def test_adapter_compositor_plugin_compose(O, avr_lib, tmp_path, n_ranks, owners
                                    group_order=group)
     got = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
     assert_bit_equal(got, want, "C++ Compositor plugin compose")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n_ranks,group", [("depthsort", 3, [2, 0, 1]), ("rgba_f32", 4, [1, 3, 0, 2]),
+                                                ("rgba_u8", 2, [1, 0]), ("rgba_u8", 5, [4, 2, 0, 1, 3])])
+def test_adapter_compositor_plugin_classic_direct_send(O, avr_lib, tmp_path, kind, n_ranks, group):
+    """The non-layered dispatch of Compositor::compose (DirectSendBase.cpp:285-314 -> :257-281):
+    one plain image per rank, piece k of every image meets on the rank at group position k and is
+    blended there in group order, the lower position on top.  avr::HipDirectSend through
+    avr_exchange_pieces + avr_blend_regions, threads as ranks; against the chain of the oracle's
+    orc_blend_regions (ImageColorOnly::blend) over the same pieces, bit for bit -- the ubyte
+    blend with its wrap-around included."""
+    subprocess.run(["make", "-C", CXX, "adapter_test"], check=True, stdout=subprocess.DEVNULL)
+    W, H = 37, 29          # 1073 pixels: no piece boundary falls on a row boundary
+    n_pixels = W * H
+    rng = np.random.default_rng(20 + n_ranks)
+    kind_id = {"depthsort": 0, "rgba_f32": 1, "rgba_u8": 2}[kind]
+    images = []
+    for r in range(n_ranks):
+        if kind == "rgba_u8":
+            img = rng.integers(0, 2 ** 32, size=n_pixels, dtype=np.uint64).astype(np.uint32)
+        else:
+            alpha = rng.random(n_pixels, dtype=np.float32)
+            alpha[rng.random(n_pixels) < 0.2] = 0.0
+            alpha[rng.random(n_pixels) < 0.1] = 1.0
+            rgb = rng.random((n_pixels, 3), dtype=np.float32) * alpha[:, None]
+            cols = [rgb, alpha[:, None]]
+            if kind == "depthsort":
+                depth = rng.random(n_pixels, dtype=np.float32) * 4.0
+                depth[alpha == 0.0] = np.inf
+                depth[rng.random(n_pixels) < 0.05] = 1.5     # ties across ranks: the top one is in front
+                cols.append(depth[:, None])
+            img = np.ascontiguousarray(np.concatenate(cols, axis=1), dtype=np.float32)
+        images.append(img)
+    np.concatenate([i.reshape(-1).view(np.uint32) for i in images]).tofile(tmp_path / "i.bin")
+    np.asarray(group, np.int32).tofile(tmp_path / "g.bin")
+    subprocess.run([EXE, "compose_image", str(tmp_path / "i.bin"), str(kind_id), str(n_ranks), str(W),
+                    str(H), str(tmp_path / "g.bin"), str(tmp_path / "out.bin")], check=True, timeout=180)
+    words = {"depthsort": 5, "rgba_f32": 4, "rgba_u8": 1}[kind]
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.uint32).reshape(n_pixels, words)
+    want = np.empty_like(got)
+    for k in range(n_ranks):       # the rank at group position k composites piece k
+        b, e = O.piece_range(n_pixels, k, n_ranks)
+        acc = images[group[0]].reshape(n_pixels, -1)[b:e]
+        for j in range(1, n_ranks):
+            acc, ob, oe = O.blend_regions(kind, acc, b, e, images[group[j]].reshape(n_pixels, -1)[b:e],
+                                          b, e)
+            assert (ob, oe) == (b, e)
+        want[b:e] = np.ascontiguousarray(acc).view(np.uint32).reshape(e - b, words)
+    assert np.array_equal(got, want), f"classic direct send, {kind}, {n_ranks} ranks"

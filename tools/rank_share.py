@@ -53,6 +53,10 @@ ap.add_argument("--no-rccl", action="store_true",
                      "initialised and used before the renderer exists)")
 ap.add_argument("--contiguous-pieces", action="store_true",
                 help="the reference's contiguous pieces instead of the driver's row bands")
+ap.add_argument("--fly-through", action="store_true",
+                help="every frame a camera the driver has never seen (0.1 degree of orbit per "
+                     "frame): visibility order, frame plan, tightened exchange layout and per-box "
+                     "prologue are made per frame")
 ap.add_argument("--overlap", type=int, default=-1, help="avr_renderer_set_overlap")
 ap.add_argument("--classify-share", type=int, default=-1, help="avr_renderer_set_classify_share")
 ap.add_argument("--worker", type=int, nargs=2, metavar=("N_RANKS", "RANK"), default=None,
@@ -103,6 +107,15 @@ def measure_share(n_ranks, rank):
         r.set_piece_layout(0, 1)
     counter = torch.zeros(1, dtype=torch.int64, device=device)
     kw = dict(use_visibility_graph=True, draw_bounds=False)
+    view = [0]
+
+    class NextCamera:   # `cam` below: the default camera, or one that never repeats
+        def __call__(self):
+            if not args.fly_through:
+                return scenes.default_camera()
+            view[0] += 1
+            return scenes.orbit_camera(view[0], 3600)
+    next_cam = NextCamera()
     r.render(args.size, args.size, args.transparency, 1, cam, samples=counter, **kw)
     r.synchronize()
     samples = int(counter.item())
@@ -114,7 +127,7 @@ def measure_share(n_ranks, rank):
         elapsed = time.perf_counter() - begin
         if warm >= 30 and elapsed >= 0.5 and (elapsed >= 3.0 or r.corun_state()["settled"]):
             break
-        r.render(args.size, args.size, args.transparency, 1, cam, **kw)
+        r.render(args.size, args.size, args.transparency, 1, next_cam(), **kw)
         warm += 1
         if warm % 64 == 0:
             r.synchronize()
@@ -124,7 +137,7 @@ def measure_share(n_ranks, rank):
     r.host_profile(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.frames):
-        r.render(args.size, args.size, args.transparency, 1, cam, **kw)
+        r.render(args.size, args.size, args.transparency, 1, next_cam(), **kw)
     host = (time.perf_counter() - t0) / args.frames
     r.synchronize()
     torch.cuda.synchronize()
@@ -192,7 +205,8 @@ def child(extra):
 
 print(f"{args.config}, {args.size}^2, ownership {args.ownership}, "
       f"{'contiguous pieces' if args.contiguous_pieces else 'row-band pieces'}, "
-      f"{'no RCCL in the share processes' if args.no_rccl else 'live one-rank RCCL communicator in every share process'}",
+      f"{'no RCCL in the share processes' if args.no_rccl else 'live one-rank RCCL communicator in every share process'}"
+      f"{', FLY-THROUGH (a new camera every frame)' if args.fly_through else ''}",
       flush=True)
 summary = []
 for n_ranks in args.ranks:

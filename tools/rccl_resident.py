@@ -32,6 +32,7 @@ ap.add_argument("--trace-frames", type=int, default=0,
                 help="only play this many side-by-side frames (for a kernel trace) and exit")
 ap.add_argument("--n-ranks", type=int, default=1, help="play rank --rank of this many (solo exchange)")
 ap.add_argument("--rank", type=int, default=0)
+ap.add_argument("--ownership", default="morton")
 args = ap.parse_args()
 
 import torch
@@ -41,7 +42,7 @@ from amrvolumerenderer_amd.renderer import build_scene_on_device
 device = torch.device("cuda", 0)
 cam = scenes.default_camera()
 spec = scenes.config4("smooth")
-scenes.assign_owners(spec, args.n_ranks, "morton")
+scenes.assign_owners(spec, args.n_ranks, args.ownership)
 ctx = runtime.Context(0)
 all_boxes, local = build_scene_on_device(ctx, spec, args.rank)
 merged, mine = [], iter(local)
