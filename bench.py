@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--field", default="smooth", choices=["smooth", "noise", "radial"])
     ap.add_argument("--transparency", type=float, default=0.97)
-    ap.add_argument("--ownership", default="morton", choices=["morton", "morton_cost", "morton_pairs", "level_pairs", "round_robin",
+    ap.add_argument("--ownership", default="level_pairs", choices=["morton", "morton_cost", "morton_pairs", "level_pairs", "round_robin",
                              "block"])
     ap.add_argument("--antialiasing", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -101,3 +101,17 @@ def route(plans, send_buffers):
             assert plans[s].recv_splits[src] == plans[src].send_splits[s]
         recv.append(np.concatenate(parts) if parts else np.zeros(0, np.float32))
     return recv
+
+
+def piece_pixels(plan):
+    """Image pixel index of every pixel of plan.rank's piece, in the order avr_fold_plan delivers
+    them: the reference's contiguous range, or -- row bands (include/avr_hip.h,
+    AVR_PIECES_ROW_BANDS) -- the rows of the bands dealt to the piece, in image order."""
+    W = plan.width
+    if plan.piece_layout == 0:
+        return np.arange(plan.piece_begin, plan.piece_end, dtype=np.int64)
+    k = plan.piece_of_rank[plan.rank]
+    rows = [y for y in range(plan.height) if (y // plan.band_rows) % plan.n_ranks == k]
+    idx = (np.asarray(rows, dtype=np.int64)[:, None] * W + np.arange(W, dtype=np.int64)[None, :])
+    assert idx.size == plan.piece_end - plan.piece_begin
+    return idx.reshape(-1)

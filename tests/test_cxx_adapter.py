@@ -61,7 +61,9 @@ def test_adapter_single_rank_compose(O, avr_lib, tmp_path):
     # must still be the oracle's
     (3, "round_robin", 1, 330),
     # more ranks than the image has pieces of whole rows, and as many ranks as a node has GPUs
-    (5, "morton", 1, 3), (8, "round_robin", 1, 40), (8, "morton", 4, 3)])
+    (5, "morton", 1, 3), (8, "round_robin", 1, 40), (8, "morton", 4, 3),
+    # the ownership bench.py uses for N > 1
+    (4, "level_pairs", 1, 3), (8, "level_pairs", 1, 3)])
 def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, policy,
                                                  antialiasing, frames):
     """The whole frame driven from C++ over the C ABI alone: one avr::FrameDriver (the pipelined

@@ -351,7 +351,7 @@ def test_corun_tuning_never_changes_results(O, ctx):
                      "timed_windows": 0}
 
 
-def _simulated_frame(O, ctx, spec, cam, W, H, transparency, n_ranks, tighten, cells=None):
+def _simulated_frame(O, ctx, spec, cam, W, H, transparency, n_ranks, tighten, cells=None, bands=0):
     """The N-rank frame with the ranks played one after the other on this GPU: per rank its frame
     plan (tightened or not), classify + march into the send buffer, the all-to-all by hand, the
     fold.  Returns (image [W*H, 5], floats sent by all ranks, non-empty pixels the march found
@@ -370,7 +370,9 @@ def _simulated_frame(O, ctx, spec, cam, W, H, transparency, n_ranks, tighten, ce
     plans, sends = [], []
     try:
         for r in range(n_ranks):
-            plan = FramePlan(meta, params, cam, r, n_ranks)
+            # (bands: the frame driver's row-band pieces instead of the reference's ranges)
+            plan = FramePlan(meta, params, cam, r, n_ranks, piece_layout=1 if bands else 0,
+                             band_rows=bands or 1)
             if tighten:
                 plan.tighten()
             local = [device_box(ctx, cells[i], spec.boxes[i].min_corner, spec.boxes[i].max_corner,
@@ -389,7 +391,7 @@ def _simulated_frame(O, ctx, spec, cam, W, H, transparency, n_ranks, tighten, ce
             dev = torch.zeros(1, device=ctx.device)
         piece, _ = ctx.fold_plan(plan, dev, want_rgb8=True)
         ctx.synchronize()
-        image[plan.piece_begin:plan.piece_end] = piece.cpu().numpy()
+        image[PH.piece_pixels(plan)] = piece.cpu().numpy()
     return image, sum(p.send_floats for p in plans), int(counters[4].item())
 
 
@@ -422,6 +424,13 @@ def test_tightened_exchange_layout_is_exact(O, ctx, n_ranks, policy):
             assert_bit_equal(tight, want, "tightened layout")
             assert dropped == 0
             assert tight_floats <= loose_floats
+            # the frame driver's pieces: bands of rows dealt round-robin (97 rows: the last cycle
+            # is partial, and with 8 ranks x 16 rows some pieces have no rows at all)
+            for bands in (4, 16):
+                banded, banded_floats, dropped = _simulated_frame(
+                    O, ctx, spec, cam, W, H, transparency, n_ranks, bands == 4, cells, bands=bands)
+                assert_bit_equal(banded, want, f"row bands of {bands}")
+                assert dropped == 0
             saved.append(1.0 - tight_floats / loose_floats)
         assert saved[0] > 0.1 and saved[1] > 0.1   # the oblique views from outside
     finally:

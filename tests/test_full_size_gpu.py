@@ -64,20 +64,26 @@ def test_config4_single_rank_frame_is_the_oracles(O, ctx, config4):
         assert torch.equal(again, rgb8)
 
 
-@pytest.mark.parametrize("tighten", [False, True])
-def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config4, tighten):
+@pytest.mark.parametrize("tighten,policy,bands", [(False, "morton", 0), (True, "morton", 0),
+                                                  (True, "level_pairs", 8),
+                                                  (False, "level_pairs", 16)])
+def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config4, tighten, policy,
+                                                                  bands):
     """(tighten: the per-row exchange layout of avr_frame_plan_tighten instead of the runs'
-    rectangles -- same frame, fewer floats on the wire.)"""
+    rectangles -- same frame, fewer floats on the wire.  policy / bands: the ownership bench.py
+    uses for N > 1 and the frame driver's row-band pieces -- which rank folds a pixel never
+    changes it, which rank owns a box changes the run grouping exactly as in the oracle.)"""
     spec, cam, device_cells, layers, hints, ref, _ = config4
     n_ranks = 8
-    scenes.assign_owners(spec, n_ranks, "morton")
+    scenes.assign_owners(spec, n_ranks, policy)
     owners = [b.owner for b in spec.boxes]
     want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
     meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
     params = make_params(W, H, spec.scalar_range, TRANSPARENCY, ref, spec.bounds)
     plans, sends = [], []
     for r in range(n_ranks):
-        plan = FramePlan(meta, params, cam, r, n_ranks)
+        plan = FramePlan(meta, params, cam, r, n_ranks, piece_layout=1 if bands else 0,
+                         band_rows=bands or 1)
         if tighten:
             loose_floats = plan.send_floats
             plan.tighten()
@@ -97,8 +103,9 @@ def test_config4_eight_ranks_equal_the_oracles_eight_rank_compose(O, ctx, config
             dev = torch.zeros(1, device=ctx.device)
         piece, rgb8 = ctx.fold_plan(plan, dev, want_rgb8=True)
         ctx.synchronize()
-        got[plan.piece_begin:plan.piece_end] = piece.cpu().numpy()
-        got8[plan.piece_begin:plan.piece_end] = rgb8.cpu().numpy()
+        where = PH.piece_pixels(plan)
+        got[where] = piece.cpu().numpy()
+        got8[where] = rgb8.cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(got8, O.quantize_rgb8(want, W, H)[::-1].reshape(-1, 3))
     scenes.assign_owners(spec, 1, "morton")
