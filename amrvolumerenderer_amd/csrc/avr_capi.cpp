@@ -938,9 +938,12 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
                   float* out_piece, uint8_t* out_rgb8) {
   return guarded([&]() -> int {
     bind_device(ctx);
-    require(plan != nullptr && (out_piece != nullptr || out_rgb8 != nullptr), "null argument");
-    require(plan->info.recv_floats == 0 || recv_buffer != nullptr, "null receive buffer");
+    require(plan != nullptr, "null argument");
+    // (a rank whose piece is empty -- more ranks than pixels, or row bands on a short image --
+    // has nothing to fold and may pass empty buffers)
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
+    require(out_piece != nullptr || out_rgb8 != nullptr, "null argument");
+    require(plan->info.recv_floats == 0 || recv_buffer != nullptr, "null receive buffer");
     avr::FoldLaunch launch;
     const bool spans = plan->tightened && !plan->recv_spans.empty();
     ctx->staging.begin(plan->global_rects.size() * sizeof(avr::RunRectDev) +

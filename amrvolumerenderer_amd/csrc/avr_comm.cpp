@@ -21,6 +21,7 @@
 
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -272,20 +273,28 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
         world.sizes[static_cast<size_t>(me)][static_cast<size_t>(s)] = plan->send_splits[static_cast<size_t>(s)] * 4;
       }
       world.barrier();
-      for (int s = 0; s < n; ++s) {
-        const int64_t bytes = world.sizes[static_cast<size_t>(s)][static_cast<size_t>(me)];
-        if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
-          throw std::runtime_error("exchange: the ranks' frame plans disagree on a block size");
+      // (whatever goes wrong between the two meetings, the second one is still attended: the
+      // peers would otherwise wait for this rank forever)
+      std::exception_ptr failure;
+      try {
+        for (int s = 0; s < n; ++s) {
+          const int64_t bytes = world.sizes[static_cast<size_t>(s)][static_cast<size_t>(me)];
+          if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
+            throw std::runtime_error("exchange: the ranks' frame plans disagree on a block size");
+          }
+          if (bytes == 0) continue;
+          avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(s)],
+                                     world.base[static_cast<size_t>(s)] +
+                                         world.offsets[static_cast<size_t>(s)][static_cast<size_t>(me)],
+                                     static_cast<size_t>(bytes), hipMemcpyDeviceToDevice, stream),
+                      "hipMemcpyAsync(exchange)");
         }
-        if (bytes == 0) continue;
-        avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(s)],
-                                   world.base[static_cast<size_t>(s)] +
-                                       world.offsets[static_cast<size_t>(s)][static_cast<size_t>(me)],
-                                   static_cast<size_t>(bytes), hipMemcpyDeviceToDevice, stream),
-                    "hipMemcpyAsync(exchange)");
+        drain(stream);
+      } catch (...) {
+        failure = std::current_exception();
       }
-      drain(stream);
       world.barrier();  // every rank has pulled: the send buffers may be rewritten
+      if (failure) std::rethrow_exception(failure);
       return AVR_OK;
     }
     // RCCL: one grouped round; a rank's block for itself is a device copy
@@ -371,16 +380,22 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
       drain(stream);  // my image is complete
       world.base[static_cast<size_t>(me)] = src;
       world.barrier();
-      for (int k = 0; k < n; ++k) {  // the image of the rank at position k, my piece of it
-        if (my_bytes == 0) break;
-        avr::hip_ok(hipMemcpyAsync(dst + k * my_bytes,
-                                   world.base[static_cast<size_t>(rank_at[static_cast<size_t>(k)])] +
-                                       my_begin * bytes_per_pixel,
-                                   static_cast<size_t>(my_bytes), hipMemcpyDeviceToDevice, stream),
-                    "hipMemcpyAsync(exchange_pieces)");
+      std::exception_ptr failure;
+      try {
+        for (int k = 0; k < n; ++k) {  // the image of the rank at position k, my piece of it
+          if (my_bytes == 0) break;
+          avr::hip_ok(hipMemcpyAsync(dst + k * my_bytes,
+                                     world.base[static_cast<size_t>(rank_at[static_cast<size_t>(k)])] +
+                                         my_begin * bytes_per_pixel,
+                                     static_cast<size_t>(my_bytes), hipMemcpyDeviceToDevice, stream),
+                      "hipMemcpyAsync(exchange_pieces)");
+        }
+        drain(stream);
+      } catch (...) {
+        failure = std::current_exception();
       }
-      drain(stream);
       world.barrier();  // every rank has pulled: the images may be rewritten
+      if (failure) std::rethrow_exception(failure);
       return AVR_OK;
     }
     const avr::Rccl& api = avr::rccl();
@@ -437,18 +452,24 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       drain(stream);
       world.base[static_cast<size_t>(me)] = static_cast<const char*>(piece);
       world.barrier();
-      if (me == root) {
-        for (int s = 0; s < n; ++s) {
-          int64_t b = 0, e = 0;
-          piece_range(s, &b, &e);
-          if (e == b) continue;
-          avr::hip_ok(hipMemcpyAsync(dst + b * bytes_per_pixel, world.base[static_cast<size_t>(s)],
-                                     static_cast<size_t>(e - b) * bytes_per_pixel,
-                                     hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+      std::exception_ptr failure;
+      try {
+        if (me == root) {
+          for (int s = 0; s < n; ++s) {
+            int64_t b = 0, e = 0;
+            piece_range(s, &b, &e);
+            if (e == b) continue;
+            avr::hip_ok(hipMemcpyAsync(dst + b * bytes_per_pixel, world.base[static_cast<size_t>(s)],
+                                       static_cast<size_t>(e - b) * bytes_per_pixel,
+                                       hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+          }
+          drain(stream);
         }
-        drain(stream);
+      } catch (...) {
+        failure = std::current_exception();
       }
       world.barrier();
+      if (failure) std::rethrow_exception(failure);
       return AVR_OK;
     }
     const avr::Rccl& api = avr::rccl();

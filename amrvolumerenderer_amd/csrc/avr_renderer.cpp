@@ -699,16 +699,77 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // latency apart from the kernels before them, every frame.
     const int slot = static_cast<int>(r->frame & 1u);
     const int volume = static_cast<int>(r->frame % static_cast<unsigned>(AVR_CLASSIFIED_SLOTS));
-    ++r->frame;
     auto drain = [&] { r->drain_all(); };
 
-    FrameEvents timed;
+    // ---- everything that can fail for lack of memory happens BEFORE anything is queued and
+    // before the frame counter moves: a frame either is not started at all (the renderer stays
+    // usable) or has every buffer and event it needs.  (A failure later -- a launch, a collective
+    // -- leaves a frame half queued: the caller synchronises and tears the renderer down, on
+    // every rank; the peers of a failed rank are otherwise left waiting in the exchange.)
+    // 8-bit conversion is per pixel, so without antialiasing it is done on each rank's piece
+    // before the gather (3 bytes per pixel on the wire instead of 20); the wireframe of the tight
+    // bounds is per pixel too, so each rank overlays its own piece
+    const bool early_rgb8 = root == 1;
+    const bool overlay_piece = early_rgb8 && render->draw_bounds;
+    const bool gather_image = want_image != 0;  // the same on every rank: it adds a collective
+    const bool bytes_only = early_rgb8 && !overlay_piece && !gather_image;
+    // The gathered buffer is piece-major; with contiguous pieces that IS the image, with row
+    // bands avr_assemble_rows puts the rows back (for the bytes in the same pass that turns the
+    // bottom-up image into the file's top-down rows).
+    const bool banded = info.piece_layout == AVR_PIECES_ROW_BANDS;
+    const int64_t n_pixels = info.n_pixels;
+    const bool many = r->n_ranks > 1;
+    auto bytes_of = [](int64_t count, int each) {
+      return static_cast<size_t>(std::max<int64_t>(count, 1)) * static_cast<size_t>(each);
+    };
+    float* send = static_cast<float*>(r->send[slot].reserve(bytes_of(info.send_floats, 4), drain));
+    float* recv = many ? static_cast<float*>(r->recv.reserve(bytes_of(info.recv_floats, 4), drain))
+                       : nullptr;
+    float* piece = bytes_only ? nullptr
+                              : static_cast<float*>(r->piece.reserve(bytes_of(piece_pixels, 20), drain));
+    uint8_t* piece_rgb8 =
+        early_rgb8 ? static_cast<uint8_t*>(r->piece_rgb8.reserve(bytes_of(piece_pixels, 3), drain))
+                   : nullptr;
+    uint8_t* gathered_rgb8 = nullptr;
+    float* gathered_image = nullptr;
+    float* assembled = nullptr;
+    float* small = nullptr;
+    if (is_root) {
+      if (early_rgb8 && many) {
+        gathered_rgb8 = static_cast<uint8_t*>(r->full_rgb8.reserve(bytes_of(n_pixels, 3), drain));
+      }
+      if (many && ((early_rgb8 && gather_image && banded) || !early_rgb8)) {
+        gathered_image = static_cast<float*>(r->full_image.reserve(bytes_of(n_pixels, 20), drain));
+      }
+      if (!early_rgb8 && many && banded) {
+        assembled = static_cast<float*>(r->assembled_image.reserve(bytes_of(n_pixels, 20), drain));
+      }
+      if (!early_rgb8 && !gather_image) {
+        small = static_cast<float*>(
+            r->small_image.reserve(bytes_of(static_cast<int64_t>(width) * height, 20), drain));
+      }
+    }
+    struct TimedGuard {  // the frame's four timing events, destroyed unless the frame keeps them
+      FrameEvents events;
+      bool kept = false;
+      ~TimedGuard() {
+        if (kept) return;
+        for (hipEvent_t ev : {events.classify_begin, events.classify_end, events.march_begin,
+                              events.march_end}) {
+          if (ev != nullptr) (void)hipEventDestroy(ev);
+        }
+      }
+    } timed_guard;
+    FrameEvents& timed = timed_guard.events;
     if (r->timing) {
       timed.classify_begin = make_event(true);
       timed.classify_end = make_event(true);
       timed.march_begin = make_event(true);
       timed.march_end = make_event(true);
+      r->timed.reserve(r->timed.size() + 1);
     }
+    ++r->frame;
+
     // (the first frame after a drain classifies alone: no march to leave room for)
     abi_ok(avr_context_set_classify_lds_reserve(classify_ctx,
                                                 (overlap && !r->pipeline_idle) ? reserve : 0));
@@ -725,8 +786,6 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     if (r->marched_pending[volume]) {  // three frames ago this volume was marched
       hip_ok(hipStreamWaitEvent(stream_c, r->marched_event[volume], 0), "hipStreamWaitEvent");
     }
-    float* send = static_cast<float*>(
-        r->send[slot].reserve(static_cast<size_t>(std::max<int64_t>(info.send_floats, 1)) * 4, drain));
     if (!overlap && r->composed_pending[slot]) {  // (back to back: both waits precede the pair)
       hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
     }
@@ -776,36 +835,20 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     if (r->timing) hip_ok(hipEventRecord(timed.march_end, stream_m), "hipEventRecord");
     hip_ok(hipEventRecord(r->marched_event[volume], stream_m), "hipEventRecord");
     r->marched_pending[volume] = true;
-    if (r->timing) r->timed.push_back(timed);
+    if (r->timing) {
+      r->timed.push_back(timed);
+      timed_guard.kept = true;
+    }
 
     lap(2);
     // ---- stream X: exchange, fold, gather, frame tail ------------------------------------------
     hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[volume], 0), "hipStreamWaitEvent");
     const float* received = send;
-    if (r->n_ranks > 1) {
-      float* recv = static_cast<float*>(
-          r->recv.reserve(static_cast<size_t>(std::max<int64_t>(info.recv_floats, 1)) * 4, drain));
+    if (many) {
       abi_ok(avr_exchange(r->compose, plan, r->comm, send, recv));
       received = recv;
     }
     lap(3);
-    // 8-bit conversion is per pixel, so without antialiasing it is done on each rank's piece
-    // before the gather (3 bytes per pixel on the wire instead of 20); the wireframe of the tight
-    // bounds is per pixel too, so each rank overlays its own piece
-    const bool early_rgb8 = root == 1;
-    const bool overlay_piece = early_rgb8 && render->draw_bounds;
-    const bool gather_image = want_image != 0;  // the same on every rank: it adds a collective
-    const bool bytes_only = early_rgb8 && !overlay_piece && !gather_image;
-    float* piece = nullptr;
-    uint8_t* piece_rgb8 = nullptr;
-    if (!bytes_only) {
-      piece = static_cast<float*>(
-          r->piece.reserve(static_cast<size_t>(std::max<int64_t>(piece_pixels, 1)) * 20, drain));
-    }
-    if (early_rgb8) {
-      piece_rgb8 = static_cast<uint8_t*>(
-          r->piece_rgb8.reserve(static_cast<size_t>(std::max<int64_t>(piece_pixels, 1)) * 3, drain));
-    }
     abi_ok(avr_fold_plan(r->compose, plan, received, piece, overlay_piece ? nullptr : piece_rgb8));
     if (overlay_piece && piece_pixels > 0) {
       abi_ok(avr_bbox_overlay_piece(r->compose, plan, r->tight_min, r->tight_max, camera, piece,
@@ -815,25 +858,16 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     r->composed_pending[slot] = true;
 
     lap(4);
-    const int64_t n_pixels = info.n_pixels;
-    // The gathered buffer is piece-major; with contiguous pieces that IS the image, with row
-    // bands avr_assemble_rows puts the rows back (for the bytes in the same pass that turns the
-    // bottom-up image into the file's top-down rows).
-    const bool banded = info.piece_layout == AVR_PIECES_ROW_BANDS;
     if (early_rgb8) {
       uint8_t* full = piece_rgb8;
-      if (r->n_ranks > 1) {
-        full = is_root ? static_cast<uint8_t*>(r->full_rgb8.reserve(static_cast<size_t>(n_pixels) * 3, drain))
-                       : nullptr;
+      if (many) {
+        full = gathered_rgb8;
         abi_ok(avr_gather(r->compose, plan, r->comm, piece_rgb8, 3, full, 0));
       }
       if (is_root) abi_ok(avr_assemble_rows(r->compose, plan, full, 3, 1, rgb8_out));
       if (gather_image) {
-        if (r->n_ranks > 1) {
-          float* gathered = is_root ? image_out : nullptr;
-          if (is_root && banded) {
-            gathered = static_cast<float*>(r->full_image.reserve(static_cast<size_t>(n_pixels) * 20, drain));
-          }
+        if (many) {
+          float* gathered = is_root ? (banded ? gathered_image : image_out) : nullptr;
           abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, gathered, 0));
           if (is_root && banded) abi_ok(avr_assemble_rows(r->compose, plan, gathered, 20, 0, image_out));
         } else {
@@ -843,27 +877,22 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     } else {
       float* full = piece;
-      if (r->n_ranks > 1) {
-        full = is_root ? static_cast<float*>(r->full_image.reserve(static_cast<size_t>(n_pixels) * 20, drain))
-                       : nullptr;
+      if (many) {
+        full = gathered_image;
         abi_ok(avr_gather(r->compose, plan, r->comm, piece, 20, full, 0));
         if (is_root && banded) {
-          float* assembled = static_cast<float*>(
-              r->assembled_image.reserve(static_cast<size_t>(n_pixels) * 20, drain));
           abi_ok(avr_assemble_rows(r->compose, plan, full, 20, 0, assembled));
           full = assembled;
         }
       }
       if (is_root) {
-        float* small = gather_image ? image_out
-                                  : static_cast<float*>(r->small_image.reserve(
-                                        static_cast<size_t>(width) * height * 20, drain));
-        abi_ok(avr_downsample_depthsort(r->compose, full, width, height, root, small));
+        float* target = gather_image ? image_out : small;
+        abi_ok(avr_downsample_depthsort(r->compose, full, width, height, root, target));
         if (render->draw_bounds) {
           abi_ok(avr_bbox_overlay(r->compose, r->tight_min, r->tight_max, camera, 1, width, height, 0,
-                                  static_cast<int64_t>(width) * height, small, nullptr));
+                                  static_cast<int64_t>(width) * height, target, nullptr));
         }
-        abi_ok(avr_quantize_rgb8(r->compose, small, width, height, 5, rgb8_out));
+        abi_ok(avr_quantize_rgb8(r->compose, target, width, height, 5, rgb8_out));
       }
     }
     lap(5);

@@ -169,14 +169,15 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
 
 def profiled_traffic(args, world):
     """HBM bytes per paint-stage launch from the committed rocprofv3 PMC summary of THIS command
-    (profiles/r2_final/pmc_summary.txt: separate --pmc passes, tools/pmc_passes.sh).  FETCH_SIZE
+    (profiles/r3_final/pmc_summary.txt: separate --pmc passes, tools/pmc_passes.sh, taken at the
+    kernels of this commit -- the march with its RunSpanDev / band_shift arguments).  FETCH_SIZE
     and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane)
     coalesced stream, so the classify kernel's reads are doubled and the march's byte gathers
     are not (MI355X_MICROARCH.md, HBM).  Only valid for the default single-GPU workload."""
     default = (world == 1 and args.config == "config4" and args.field == "smooth"
                and args.transparency == 0.97 and not args.width and not args.height
                and args.antialiasing == 1 and args.orbit == 0 and not args.fly_through)
-    path = os.path.join(ROOT, "profiles", "r2_final", "pmc_summary.txt")
+    path = os.path.join(ROOT, "profiles", "r3_final", "pmc_summary.txt")
     if not default or not os.path.exists(path):
         return None, None
     counters, kernel = {}, None
@@ -194,7 +195,7 @@ def profiled_traffic(args, world):
                + counters[("render_runs_kernel", "WRITE_SIZE")])
     except KeyError:
         return None, None
-    return int(kib * 1024), "profiles/r2_final/pmc_summary.txt"
+    return int(kib * 1024), "profiles/r3_final/pmc_summary.txt"
 
 
 def launcher_command(n_ranks, port, argv):

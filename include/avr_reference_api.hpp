@@ -300,10 +300,23 @@ class Communicator {
   // One RCCL communicator per rank (= per GPU); collective over `control`.
   template <class Control>
   Communicator(Control& control, int device) {
-    char id[AVR_COMM_ID_BYTES];
+    // [id | ok flag]: the broadcast takes place whatever happened on rank 0 -- the other ranks are
+    // already waiting in it, and a rank 0 that threw first would leave them there
+    char id[AVR_COMM_ID_BYTES + 1];
     std::memset(id, 0, sizeof(id));
-    if (control.rank() == 0) check(avr_comm_unique_id(id));
-    control.broadcast(id, AVR_COMM_ID_BYTES, 0);
+    std::string failure;
+    if (control.rank() == 0) {
+      if (avr_comm_unique_id(id) == AVR_OK) {
+        id[AVR_COMM_ID_BYTES] = 1;
+      } else {
+        failure = avr_last_error();
+      }
+    }
+    control.broadcast(id, AVR_COMM_ID_BYTES + 1, 0);
+    if (id[AVR_COMM_ID_BYTES] != 1) {
+      throw std::runtime_error(failure.empty() ? "rank 0 could not create the communicator id"
+                                               : failure);
+    }
     check(avr_comm_create(device, id, control.rank(), control.size(), &comm_));
   }
   // n connected in-process communicators (one GPU, one host thread per rank): rehearsal only.
