@@ -16,9 +16,15 @@
 // N-rank frame where only one GPU is available (RCCL cannot place two ranks on one device); it is
 // not a performance path.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <exception>
@@ -26,6 +32,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "avr_internal.h"
@@ -114,6 +121,53 @@ struct LocalWorld {
   }
 };
 
+// ---- cross-process rehearsal communicator --------------------------------------------------
+// N rank PROCESSES sharing one GPU meet in a POSIX shared-memory segment: a header with a
+// sense-reversing barrier and, per rank, the block offsets / sizes of the collective in flight,
+// then one data region per rank.  Blocks travel device -> the sender's region -> device.
+struct SharedHeader {
+  static constexpr int kMaxRanks = 64;
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  int64_t offsets[kMaxRanks][kMaxRanks];  // [source][peer]: byte offset inside the source's region
+  int64_t sizes[kMaxRanks][kMaxRanks];
+};
+
+struct SharedWorld {
+  int n_ranks = 0;
+  std::string name;
+  void* mapping = nullptr;
+  size_t mapped_bytes = 0;
+  size_t capacity = 0;  // bytes per rank
+  bool owner = false;   // rank 0 removes the name when it goes
+  SharedHeader* header() const { return static_cast<SharedHeader*>(mapping); }
+  char* region(int rank) const {
+    const size_t head = (sizeof(SharedHeader) + 4095) / 4096 * 4096;
+    return static_cast<char*>(mapping) + head + static_cast<size_t>(rank) * capacity;
+  }
+  ~SharedWorld() {
+    if (mapping != nullptr) (void)munmap(mapping, mapped_bytes);
+    if (owner) (void)shm_unlink(name.c_str());
+  }
+  // Every rank arrives, or the wait gives up: a rehearsal must not hang a GPU box.
+  void barrier() {
+    SharedHeader* h = header();
+    const uint32_t mine = h->generation.load(std::memory_order_acquire);
+    if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == static_cast<uint32_t>(n_ranks)) {
+      h->arrived.store(0, std::memory_order_relaxed);
+      h->generation.fetch_add(1, std::memory_order_release);
+      return;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    for (unsigned spins = 0; h->generation.load(std::memory_order_acquire) == mine; ++spins) {
+      if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) {
+        throw std::runtime_error("shared communicator: a peer did not arrive within 120 s");
+      }
+    }
+  }
+};
+
 }  // namespace
 }  // namespace avr
 
@@ -123,6 +177,7 @@ struct avr_comm {
   int device = 0;
   ncclComm_t nccl = nullptr;                      // RCCL flavour
   std::shared_ptr<avr::LocalWorld> local;         // in-process flavour
+  std::unique_ptr<avr::SharedWorld> shared;       // cross-process flavour (one GPU, shared memory)
   bool solo = false;                              // one rank of N played alone (timing studies)
 };
 
@@ -222,6 +277,42 @@ int avr_comm_create_solo(int rank, int n_ranks, avr_comm** out_comm) {
   });
 }
 
+int avr_comm_create_shared(const char* name, int rank, int n_ranks, size_t capacity_bytes,
+                           avr_comm** out_comm) {
+  return guarded([&]() -> int {
+    require(out_comm != nullptr && name != nullptr && name[0] == '/', "invalid argument");
+    *out_comm = nullptr;
+    require(n_ranks >= 1 && n_ranks <= avr::SharedHeader::kMaxRanks && rank >= 0 && rank < n_ranks,
+            "invalid rank");
+    require(capacity_bytes > 0, "capacity_bytes must be positive");
+    auto world = std::make_unique<avr::SharedWorld>();
+    world->n_ranks = n_ranks;
+    world->name = name;
+    world->capacity = (capacity_bytes + 4095) / 4096 * 4096;
+    world->owner = rank == 0;
+    const size_t head = (sizeof(avr::SharedHeader) + 4095) / 4096 * 4096;
+    world->mapped_bytes = head + world->capacity * static_cast<size_t>(n_ranks);
+    // whoever comes first creates the segment; a new segment is all zeros (the barrier's state)
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) throw std::runtime_error(std::string("shm_open(") + name + ") failed");
+    if (ftruncate(fd, static_cast<off_t>(world->mapped_bytes)) != 0) {
+      (void)close(fd);
+      throw std::runtime_error("ftruncate of the shared segment failed");
+    }
+    void* mapping = mmap(nullptr, world->mapped_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    (void)close(fd);
+    if (mapping == MAP_FAILED) throw std::runtime_error("mmap of the shared segment failed");
+    world->mapping = mapping;
+    auto comm = std::make_unique<avr_comm>();
+    comm->rank = rank;
+    comm->n_ranks = n_ranks;
+    comm->shared = std::move(world);
+    comm->shared->barrier();  // everybody is attached before anybody communicates
+    *out_comm = comm.release();
+    return AVR_OK;
+  });
+}
+
 void avr_comm_destroy(avr_comm* comm) {
   if (comm == nullptr) return;
   if (comm->nccl != nullptr) {
@@ -259,6 +350,48 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
                                    static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
                     "hipMemcpyAsync(exchange)");
       }
+      return AVR_OK;
+    }
+    if (comm->shared) {
+      // cross-process rehearsal: my whole send buffer into my region, meet, pull my blocks, meet
+      avr::SharedWorld& world = *comm->shared;
+      const int64_t total = send_at[static_cast<size_t>(n)] * 4;
+      if (static_cast<size_t>(total) > world.capacity) {
+        throw std::runtime_error("shared communicator: the send buffer exceeds the segment's capacity");
+      }
+      std::exception_ptr failure;
+      try {
+        drain(stream);
+        if (total > 0) {
+          avr::hip_ok(hipMemcpy(world.region(me), send, static_cast<size_t>(total), hipMemcpyDeviceToHost),
+                      "hipMemcpy(exchange)");
+        }
+        for (int s = 0; s < n; ++s) {
+          world.header()->offsets[me][s] = send_at[static_cast<size_t>(s)] * 4;
+          world.header()->sizes[me][s] = plan->send_splits[static_cast<size_t>(s)] * 4;
+        }
+      } catch (...) {
+        failure = std::current_exception();
+      }
+      world.barrier();
+      try {
+        if (failure) std::rethrow_exception(failure);
+        for (int s = 0; s < n; ++s) {
+          const int64_t bytes = world.header()->sizes[s][me];
+          if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
+            throw std::runtime_error("exchange: the ranks' frame plans disagree on a block size");
+          }
+          if (bytes == 0) continue;
+          avr::hip_ok(hipMemcpy(recv + recv_at[static_cast<size_t>(s)],
+                                world.region(s) + world.header()->offsets[s][me],
+                                static_cast<size_t>(bytes), hipMemcpyHostToDevice),
+                      "hipMemcpy(exchange)");
+        }
+      } catch (...) {
+        failure = std::current_exception();
+      }
+      world.barrier();  // every rank has pulled: the regions may be rewritten
+      if (failure) std::rethrow_exception(failure);
       return AVR_OK;
     }
     if (comm->local) {
@@ -375,6 +508,38 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
       keep_own();
       return AVR_OK;
     }
+    if (comm->shared) {
+      avr::SharedWorld& world = *comm->shared;
+      const size_t image_bytes = static_cast<size_t>(n_pixels) * static_cast<size_t>(bytes_per_pixel);
+      if (image_bytes > world.capacity) {
+        throw std::runtime_error("shared communicator: the image exceeds the segment's capacity");
+      }
+      std::exception_ptr failure;
+      try {
+        drain(stream);
+        if (image_bytes > 0) {
+          avr::hip_ok(hipMemcpy(world.region(me), src, image_bytes, hipMemcpyDeviceToHost),
+                      "hipMemcpy(exchange_pieces)");
+        }
+      } catch (...) {
+        failure = std::current_exception();
+      }
+      world.barrier();
+      try {
+        if (failure) std::rethrow_exception(failure);
+        for (int k = 0; k < n && my_bytes > 0; ++k) {
+          avr::hip_ok(hipMemcpy(dst + k * my_bytes,
+                                world.region(rank_at[static_cast<size_t>(k)]) + my_begin * bytes_per_pixel,
+                                static_cast<size_t>(my_bytes), hipMemcpyHostToDevice),
+                      "hipMemcpy(exchange_pieces)");
+        }
+      } catch (...) {
+        failure = std::current_exception();
+      }
+      world.barrier();
+      if (failure) std::rethrow_exception(failure);
+      return AVR_OK;
+    }
     if (comm->local) {
       avr::LocalWorld& world = *comm->local;
       drain(stream);  // my image is complete
@@ -445,6 +610,46 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
                                    static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                    hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
       }
+      return AVR_OK;
+    }
+    if (comm->shared) {
+      avr::SharedWorld& world = *comm->shared;
+      const size_t mine = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
+      if (mine > world.capacity) {
+        throw std::runtime_error("shared communicator: the piece exceeds the segment's capacity");
+      }
+      std::exception_ptr failure;
+      try {
+        drain(stream);
+        if (mine > 0 && me != root) {
+          avr::hip_ok(hipMemcpy(world.region(me), piece, mine, hipMemcpyDeviceToHost), "hipMemcpy(gather)");
+        }
+      } catch (...) {
+        failure = std::current_exception();
+      }
+      world.barrier();
+      try {
+        if (failure) std::rethrow_exception(failure);
+        if (me == root) {
+          for (int s = 0; s < n; ++s) {
+            int64_t b = 0, e = 0;
+            piece_range(s, &b, &e);
+            if (e == b) continue;
+            const size_t bytes = static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel);
+            if (s == me) {
+              avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, piece, bytes, hipMemcpyDeviceToDevice),
+                          "hipMemcpy(gather)");
+            } else {
+              avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, world.region(s), bytes, hipMemcpyHostToDevice),
+                          "hipMemcpy(gather)");
+            }
+          }
+        }
+      } catch (...) {
+        failure = std::current_exception();
+      }
+      world.barrier();
+      if (failure) std::rethrow_exception(failure);
       return AVR_OK;
     }
     if (comm->local) {

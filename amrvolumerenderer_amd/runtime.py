@@ -587,6 +587,18 @@ class Comm:
         return self
 
     @classmethod
+    def shared(cls, name: str, rank: int, n_ranks: int, capacity_bytes: int = 256 << 20) -> "Comm":
+        """avr_comm_create_shared: rank processes sharing ONE GPU meet in a POSIX shared-memory
+        segment (collective).  Rehearsal of the multi-process flow, not a performance path."""
+        self = cls.__new__(cls)
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_comm_create_shared(name.encode(), self.rank, self.n_ranks,
+                                                       int(capacity_bytes), C.byref(handle)))
+        self._handle = handle
+        return self
+
+    @classmethod
     def from_process_group(cls, device_index: int, group=None) -> "Comm":
         """Bootstraps over an initialised torch.distributed group (any backend)."""
         import torch.distributed as dist

@@ -70,8 +70,14 @@ def parse_args():
                          "collectives (all_to_all_single / gather) and require rank 0's bytes to "
                          "equal the C++ driver's (grouped ncclSend / ncclRecv)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="debug: all ranks share cuda:0 and talk over gloo through host copies "
-                         "(exercises the N>1 code path on a 1-GPU box; not a measurement)")
+                    help="debug: all ranks share cuda:0 (RCCL refuses two ranks on one device) and "
+                         "the C++ frame driver's exchange / gather go through a shared-memory "
+                         "segment (avr_comm_create_shared): the whole N > 1 flow of this script -- "
+                         "gloo control plane, native driver, checks, JSON line -- on a 1-GPU box; "
+                         "not a measurement")
+    ap.add_argument("--rehearse-python-pipeline", action="store_true",
+                    help="with --rehearse-on-one-gpu: the torch.distributed frame loop over gloo "
+                         "through host copies instead of the C++ driver")
     return ap.parse_args()
 
 
@@ -293,9 +299,16 @@ def main():
     ctx = runtime.Context(local_rank)
     all_boxes, local_boxes = build_scene_on_device(ctx, spec, rank)
     torch.cuda.synchronize()
+    rehearsal_comm = None
+    if world > 1 and args.rehearse_on_one_gpu and not args.rehearse_python_pipeline:
+        # one segment per job: its name travels from rank 0 over the control plane
+        token = [f"/avr_bench_{os.getpid()}_{int(time.time() * 1e3) & 0xffffff:x}"]
+        dist.broadcast_object_list(token, src=0, group=group)
+        rehearsal_comm = runtime.Comm.shared(token[0], rank, world, 512 << 20)
     renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
-                             spec.scalar_range, rank, world, group,
-                             stage_through_host=args.rehearse_on_one_gpu,
+                             spec.scalar_range, rank, world, group, comm=rehearsal_comm,
+                             stage_through_host=(args.rehearse_on_one_gpu and
+                                                 rehearsal_comm is None),
                              march_workgroups_per_cu=args.march_occupancy,
                              stream_priorities=tuple(int(v) for v in args.priorities.split(",")),
                              cache_classification=args.cache_classification)
@@ -347,6 +360,8 @@ def main():
         # grouped ncclSend / ncclRecv (avr_exchange / avr_gather) against torch.distributed's
         # all_to_all_single / gather on the same RCCL transport -- rank 0's bytes must agree
         twin_group = group if args.rehearse_on_one_gpu else dist.new_group(backend="nccl")
+        # (the twin is the torch.distributed frame loop: over gloo through host copies when the
+        # ranks share one GPU)
         twin = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
                              spec.scalar_range, rank, world, twin_group, native=False,
                              stage_through_host=args.rehearse_on_one_gpu)
@@ -393,7 +408,8 @@ def main():
     # (N ranks: every frame is a collective, so every rank must run the same number of them --
     # a fixed count, well past the <= 1000 frames the search takes at short frames, instead of a
     # clock)
-    fixed_burst = 1600 if world > 1 else None
+    # (a one-GPU rehearsal moves every block through host memory: it is not there to settle)
+    fixed_burst = (48 if args.rehearse_on_one_gpu else 1600) if world > 1 else None
     while True:
         for _ in range(16):
             step(burst)
@@ -529,7 +545,9 @@ def main():
                         f"{len(cameras)} view(s)",
             "ownership": args.ownership, "runs_total": total_runs,
             "frame_driver": ("C++ (avr_renderer: 3 HIP streams" +
-                             (", RCCL exchange + gather" if world > 1 else "") + ")") if native
+                             ((", exchange + gather through shared memory (one-GPU rehearsal)"
+                               if rehearsal_comm is not None else ", RCCL exchange + gather")
+                              if world > 1 else "") + ")") if native
                             else ("Python pipeline (torch streams; gloo through host copies)"
                                   if args.rehearse_on_one_gpu else
                                   "Python pipeline with torch.distributed RCCL collectives -- the "

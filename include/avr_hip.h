@@ -440,6 +440,17 @@ int avr_comm_create_local(int n_ranks, avr_comm **out_comms /* [n_ranks] */);
  * tools/rank_share.py): only the block a rank keeps for itself moves, the peers' blocks of the
  * receive buffer keep whatever they held.  Frames rendered this way are not images. */
 int avr_comm_create_solo(int rank, int n_ranks, avr_comm **out_comm);
+/* Rehearsal of the N-rank frame across PROCESSES that share one GPU (RCCL refuses two ranks on
+ * one device): the ranks meet in the POSIX shared-memory segment `name` ("/something"; whoever
+ * comes first creates it, rank 0 removes the name when it is destroyed), capacity_bytes of staging
+ * per rank -- at least a rank's largest send buffer, piece or image.  Blocks travel device ->
+ * the sender's region -> device with the plans, offsets and ordering of the RCCL flavour; every
+ * call is host-synchronous and a peer that does not arrive within 120 s fails the call instead of
+ * hanging it.  Collective (the call returns when every rank has attached).  Not a performance
+ * path: it exists so that the whole multi-process flow -- control plane, frame driver, bench --
+ * runs where one GPU is all there is. */
+int avr_comm_create_shared(const char *name, int rank, int n_ranks, size_t capacity_bytes,
+                           avr_comm **out_comm);
 void avr_comm_destroy(avr_comm *comm);
 int avr_comm_rank(const avr_comm *comm);
 int avr_comm_size(const avr_comm *comm);

@@ -264,3 +264,109 @@ def test_native_rccl_exchange_and_gather_with_one_rank(O):
     assert np.array_equal(full8.cpu().numpy().reshape(H, W, 3)[::-1], O.quantize_rgb8(want, W, H))
     L.avr_frame_plan_destroy(plan)
     comm.close()
+
+
+def _native_worker(rank, world, port, policy, antialiasing, name, out_path):
+    """One rank PROCESS of the C++ frame driver on the shared GPU: avr_renderer with the
+    cross-process rehearsal communicator (avr_comm_create_shared) -- the plans, offsets and
+    ordering of the RCCL flavour, blocks through a shared-memory segment."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from amrvolumerenderer_amd import runtime, scenes
+        from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+        from helpers import device_box
+        from test_frame_plan import local_indices, oracle_overlay, painted_scene
+
+        root = int(round(antialiasing ** 0.5))
+        spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+        cams = [scenes.orbit_camera(3), scenes.default_camera(), scenes.orbit_camera(3)]
+        scenes.assign_owners(spec, world, policy)
+        owners = [b.owner for b in spec.boxes]
+        ctx = runtime.Context(0)
+        cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+        meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+        local = [device_box(ctx, cells[i], spec.boxes[i].min_corner, spec.boxes[i].max_corner,
+                            spec.boxes[i].level, rank)
+                 for i in scenes.local_box_indices(spec, rank)]
+        comm = runtime.Comm.shared(name, rank, world, 64 << 20)
+        renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
+                                 rank, world, dist.group.WORLD, comm=comm)
+        assert renderer.native is not None
+        # pipelined: three frames (two cameras, the first one again) without a host sync between
+        frames = [renderer.render(RenderParameters(W, H, 0.85, antialiasing), cam, want_image=True)
+                  for cam in cams]
+        renderer.synchronize()
+        info = renderer.native.plan_info()
+        assert info.piece_layout == 1 and info.band_rows == 8      # the driver's row bands
+        if rank == 0:
+            flags = []
+            for cam, (image, rgb8) in zip(cams, frames):
+                _, layers, hints, _ = painted_scene(O, spec, cam, W * root, H * root, 0.85)
+                want, _, _ = O.compose_layered(layers, hints, owners,
+                                               local_indices(owners, world), world)
+                if root > 1:
+                    want = O.downsample(want, W, H, root).reshape(-1, 5)
+                want = oracle_overlay(O, spec, cells, cam, want, W, H)
+                flags.append(np.array_equal(image.cpu().numpy().reshape(-1, 5).view(np.uint32),
+                                            want.view(np.uint32)))
+                flags.append(np.array_equal(rgb8.cpu().numpy(), O.quantize_rgb8(want, W, H)))
+            with open(out_path, "w") as fh:
+                fh.write(" ".join(str(int(f)) for f in flags))
+        else:
+            assert all(image is None and rgb8 is None for image, rgb8 in frames)
+        dist.barrier()
+        renderer.native.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,policy,antialiasing", [(3, "level_pairs", 1), (2, "morton", 4),
+                                                       (4, "round_robin", 1)])
+def test_native_driver_across_processes(tmp_path, world, policy, antialiasing):
+    """The C++ frame driver as N rank PROCESSES on one GPU (what `bench.py --gpus N` and the
+    reference's MPI ranks are), wired by the shared-memory rehearsal communicator: row-band pieces,
+    exchange layout tightened from the first frame, frames pipelined; rank 0's frames are the
+    oracle's N-rank compose bit for bit."""
+    out = tmp_path / "result.txt"
+    name = f"/avr_test_{os.getpid()}_{world}_{antialiasing}"
+    mp.spawn(_native_worker, args=(world, _free_port(), policy, antialiasing, name, str(out)),
+             nprocs=world, join=True)
+    flags = out.read_text().split()
+    assert len(flags) == 6 and all(f == "1" for f in flags), flags
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_bench_multi_rank_flow_on_one_gpu(n_ranks):
+    """`python bench.py --gpus N` end to end where one GPU is all there is: the script starts its
+    ranks itself (torch.distributed.run, as the driver does), the control plane runs over gloo,
+    every rank drives the C++ frame driver, and -- RCCL refusing two ranks on one device -- the
+    exchange and the gather go through the shared-memory rehearsal communicator.  Checks the
+    N > 1 code of the script, not a speed: rank 0's line, the sample-count identity, and that
+    the driver's collectives give the bytes of the torch.distributed frame loop."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    done = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks),
+         "--rehearse-on-one-gpu", "--config", "tiny", "--steps", "4", "--warmup", "1",
+         "--check-collectives"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+        text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [l for l in done.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, done.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n_ranks and line["steps"] == 4 and line["scaling"] == "strong"
+    assert line["config"]["frame_driver"].startswith("C++ (avr_renderer")
+    assert "shared memory" in line["config"]["frame_driver"]
+    assert line["config"]["self_checks"] == {"native_collectives_equal_torch_distributed": True}
+    assert line["config"]["exchange"]["layout"].startswith("per-row extents")
+    assert line["value"] > 0 and line["cpu_baseline"] is None
