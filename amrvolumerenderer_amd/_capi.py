@@ -92,6 +92,7 @@ class FramePlanInfo(C.Structure):
 
 
 PIECES_CONTIGUOUS, PIECES_ROW_BANDS = 0, 1
+DEFAULT_STREAM = C.c_void_p(-1).value    # AVR_DEFAULT_STREAM: the legacy default (null) stream
 
 
 class RunInfo(C.Structure):

@@ -659,7 +659,6 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // pass; the present one is admitted 6 per CU by its register budget and runs best uncapped
     // (config-4 frame: uncapped 1.06-1.07 ms, cap 5 1.09-1.11 ms).
     const int cap = (r->march_cap < 0) ? 0 : r->march_cap;
-    abi_ok(avr_context_set_march_occupancy(r->march, cap));
 
     // One rank: the classify pass of the next frame runs beside the march of this one (HBM-bound
     // beside issue-bound).  A rank's share of an N-rank frame is two SHORT kernels whose time is
@@ -689,9 +688,17 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     const int reserve = !overlap ? 0
                         : (r->share_fixed >= 0) ? r->share_fixed
                                                 : tuner.candidate * CoRunTuner::kReserveStep;
+    // (One stream per kernel kind.  Letting the odd frames take a second march or classify stream
+    // -- the frames are independent, so march(f+1) need not queue behind march(f) and its wait /
+    // record / copy packets could be worked off early -- was measured in round 3 and is worse by
+    // half: with a FOURTH concurrently active queue everything stalls, a 5 us descriptor copy
+    // takes 40-50 us, the frame of a rank of eight goes from 0.187 to 0.26-0.33 ms and the one-rank
+    // frame from 0.98 to 1.25-1.42 ms.  profiles/r3_experiments/.)
+    avr_context* march_ctx = r->march;
     avr_context* classify_ctx = overlap ? r->classify : r->march;
+    abi_ok(avr_context_set_march_occupancy(march_ctx, cap));
     hipStream_t stream_c = r->stream_of(classify_ctx);
-    hipStream_t stream_m = r->stream_of(r->march);
+    hipStream_t stream_m = r->stream_of(march_ctx);
     hipStream_t stream_x = r->stream_of(r->compose);
     // Send buffers alternate; the classified volumes rotate through three, so that the classify
     // stream may run a whole frame ahead of the march: with two, classify(f+1) and march(f) both
@@ -780,7 +787,10 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(0);
     // ---- stream C: classify pass of this frame into classified volume `slot` -------------------
     if (input_stream != nullptr) {  // the caller's cell data is produced on that stream
-      hip_ok(hipEventRecord(r->input_event, static_cast<hipStream_t>(input_stream)), "hipEventRecord");
+      hipStream_t producer = (input_stream == AVR_DEFAULT_STREAM)
+                                 ? nullptr  // recording on stream 0 IS recording on the null stream
+                                 : static_cast<hipStream_t>(input_stream);
+      hip_ok(hipEventRecord(r->input_event, producer), "hipEventRecord");
       hip_ok(hipStreamWaitEvent(stream_c, r->input_event, 0), "hipStreamWaitEvent");
     }
     if (r->marched_pending[volume]) {  // three frames ago this volume was marched
@@ -803,7 +813,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
-    abi_ok(avr_march_plan(r->march, r->scene, plan, volume, send, samples_out));
+    abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
     // the tuner's window: the period of a few frames between two events after the march
     if (tuner.tuning()) {
       if (tuner.closing) {

@@ -764,16 +764,14 @@ class NativeRenderer:
                     image = torch.empty((height, width, 5), dtype=torch.float32, device=self.device)
         if samples is not None and (samples.dtype != torch.int64 or samples.device != self.device):
             raise ValueError("samples must be an int64 tensor on the renderer's device")
-        # Cell data / the samples counter may have been written on the caller's stream.  The wait
-        # is placed here and not through avr_renderer_render's input_stream: torch's default
-        # stream has handle 0, which that argument reads as "nothing to wait for", and the
-        # driver's streams are non-blocking, so they never order themselves after the null stream.
-        # The classify pass runs on stream C or (back to back) on stream M: both wait.
-        if not caller.query():
-            self.streams[0].wait_stream(caller)
-            self.streams[1].wait_stream(caller)
+        # Cell data / the samples counter may have been written on the caller's stream: the driver
+        # orders this frame's classify pass (and with it the march) after that stream.  torch's
+        # default stream has handle 0, which the C ABI reads as "nothing to wait for": it is named
+        # by AVR_DEFAULT_STREAM (-1) instead -- the driver's streams are non-blocking and never
+        # order themselves after the null stream implicitly.
+        wait = None if caller.query() else C.c_void_p(caller.cuda_stream or _capi.DEFAULT_STREAM)
         _capi.check(_capi.lib().avr_renderer_render(
-            self._handle, C.byref(rp), C.byref(ccam), group, None,
+            self._handle, C.byref(rp), C.byref(ccam), group, wait,
             C.c_void_p(samples.data_ptr()) if samples is not None else None, int(bool(want_image)),
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
             C.c_void_p(image.data_ptr()) if image is not None else None))

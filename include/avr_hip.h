@@ -542,10 +542,9 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream: a HIP stream whose queued work
  * produces the cell data (or zeroes samples_out); the classify pass, and with it the march, is
- * ordered after it.  NULL means "nothing to wait for", NOT the legacy default stream (handle 0):
- * the driver's streams are non-blocking and never order themselves after that one implicitly, so
- * a caller that fills cells on the default stream passes hipStreamLegacy ((hipStream_t)1) or
- * orders avr_renderer_stream(r, 0) and (r, 1) after its work itself.
+ * ordered after it.  NULL means "nothing to wait for", NOT the legacy default stream (whose handle
+ * is 0 as well): the driver's streams are non-blocking and never order themselves after that one
+ * implicitly, so a caller that fills cells on the default stream passes AVR_DEFAULT_STREAM.
  * samples_out (device, may be NULL) as avr_paint_box.  want_image (the SAME on every rank: it
  * adds a gather of the float pieces): also deliver the gathered -- with antialiasing downsampled
  * and overlaid -- depth-sort image.  On rank 0: rgb8_out (device, width*height*3 bytes, rows
@@ -553,6 +552,7 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
  * width*height*5 floats, origin bottom-left).  Other ranks pass NULL for both.  The outputs are
  * complete when the compositing stream (avr_renderer_stream(r, 2)) reaches this point:
  * avr_renderer_synchronize, or order your stream after it. */
+#define AVR_DEFAULT_STREAM ((void *)(intptr_t)-1) /* input_stream: the legacy default (null) stream */
 int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
                         const avr_camera *camera, const int32_t *group_order, void *input_stream,
                         uint64_t *samples_out, int want_image, uint8_t *rgb8_out, float *image_out);
