@@ -218,6 +218,7 @@ SIGNATURES = {
     "avr_renderer_set_overlap": (C.c_int, [_vp, C.c_int]),
     "avr_comm_create_shared": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.POINTER(_vp)]),
     "avr_exchange_pieces": (C.c_int, [_vp, _vp, _ip, _i64, C.c_int, _vp, _vp]),
+    "avr_renderer_set_host_backpressure": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_tighten": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_piece_layout": (C.c_int, [_vp, C.c_int, C.c_int]),
     "avr_renderer_set_classify_share": (C.c_int, [_vp, C.c_int]),

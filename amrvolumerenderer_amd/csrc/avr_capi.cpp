@@ -95,6 +95,9 @@ class StagingRing {
   // (measured on a rank of eight: 17 + 5 + 8 us between two marches for the waits, the copy and
   // the launch; tools/share_timeline.py).
   void set_upload_stream(hipStream_t stream) { upload_stream_ = stream; }
+  // The owner keeps the host from running ahead by other means (the frame driver's host-side
+  // back-pressure): a skipped copy then leaves no packet at all on the consumer stream.
+  void set_lean(bool lean) { lean_ = lean; }
 
   // With a separate upload stream a block's device twin is no longer protected by stream order
   // (the copy of a later batch could overtake the kernels that still read this one): the
@@ -134,6 +137,7 @@ class StagingRing {
       if (current_->host != nullptr) (void)hipHostFree(current_->host);
       current_->dev = current_->host = nullptr;
       current_->capacity = 0;
+      current_->shadow.clear();
       size_t cap = 1 << 16;
       while (cap < need) cap *= 2;
       hip_check(hipMalloc(&current_->dev, cap), "hipMalloc(staging)");
@@ -162,6 +166,22 @@ class StagingRing {
   // pinned memory was measured to block the host until the stream had drained, every few frames
   // (5-7 ms with five 1.3 ms frames queued; tools/host_stalls.py), and a launch never does.
   void commit(hipStream_t stream) {
+    // A batch that equals what this slot's device twin already holds is not copied again: while
+    // camera and parameters repeat, a slot sees the same batch every kSlots calls, and the copy
+    // kernel with its event are two packets less between two kernels of the consumer stream (a
+    // rank of eight: 27 us from one march to the next, of a 0.19 ms frame).  The twin is intact:
+    // begin() has waited for the slot's previous copy, and nothing else writes it.
+    static const bool always_copy = std::getenv("AVR_ALWAYS_UPLOAD") != nullptr;  // A/B only
+    if (!always_copy && used_ != 0 && used_ == current_->shadow.size() &&
+        std::memcmp(current_->host, current_->shadow.data(), used_) == 0) {
+      // The slot's event is what keeps the host at most kSlots batches ahead of the consumer;
+      // unless the owner bounds the frames in flight itself (set_lean), it is still recorded.
+      if (!lean_) {
+        hip_check(hipEventRecord(current_->done, stream), "hipEventRecord(staging)");
+        current_->pending = true;
+      }
+      return;
+    }
     hipStream_t copier = (upload_stream_ != nullptr) ? upload_stream_ : stream;
     if (used_ != 0) {
       const int status = launch_upload(current_->host_mapped, current_->dev, used_, copier);
@@ -169,6 +189,8 @@ class StagingRing {
     }
     hip_check(hipEventRecord(current_->done, copier), "hipEventRecord(staging)");
     current_->pending = true;
+    current_->shadow.assign(static_cast<const char*>(current_->host),
+                            static_cast<const char*>(current_->host) + used_);
     if (copier != stream) {
       hip_check(hipStreamWaitEvent(stream, current_->done, 0), "hipStreamWaitEvent(staging)");
       current_->consumer = stream;  // close_batch() records when its kernels are through
@@ -198,11 +220,13 @@ class StagingRing {
     size_t capacity = 0;
     hipEvent_t done = nullptr;      // the copy has run: the pinned block may be refilled
     bool pending = false;
+    std::vector<char> shadow;       // what the device twin holds (host copy of the last batch copied)
     hipEvent_t consumed = nullptr;  // separate upload stream: the kernels reading the twin are through
     bool consumed_pending = false;
     hipStream_t consumer = nullptr;
   };
   hipStream_t upload_stream_ = nullptr;
+  bool lean_ = false;
   Slot slots_[kSlots];
   Slot* current_ = nullptr;
   int next_ = 0;
@@ -330,6 +354,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   avr::FramePlan& plan = cached ? *cached : local;
   if (plan.boxes.size() != static_cast<size_t>(n_boxes) || !plan.ready) {
     avr::plan_frame(boxes, n_boxes, transform, params, camera, &plan);
+    plan.march_items_ready = false;
   }
   if (n_runs == 0) return AVR_OK;
   require(plan.n_tables <= avr::kMaxLdsTables,
@@ -375,7 +400,10 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     }
   }
 
-  std::vector<avr::MarchItemDev>& items = ctx->march_items;  // scratch, reused across frames
+  // scratch, reused across frames; a frame plan's prologue keeps its own (they depend on the
+  // plan alone)
+  const bool keep_items = cached != nullptr;
+  std::vector<avr::MarchItemDev>& items = keep_items ? plan.march_items : ctx->march_items;
   size_t bytes = plan.boxes.size() * sizeof(avr::BoxDev);
   if (phases & kClassify) bytes += plan.classify_tile_begin.size() * sizeof(uint32_t);
   if (phases & kMarch) {
@@ -385,16 +413,19 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     require(run_rects.size() == static_cast<size_t>(n_runs) &&
                 run_blocks.size() == static_cast<size_t>(n_runs) * n_pieces,
             "run tables do not match the runs");
-    int previous = 0;
-    for (int r = 0; r < n_runs; ++r) {
-      require(run_end[r] >= previous && run_end[r] <= n_order, "run_end must be non-decreasing");
-      previous = run_end[r];
+    if (!(keep_items && plan.march_items_ready)) {
+      int previous = 0;
+      for (int r = 0; r < n_runs; ++r) {
+        require(run_end[r] >= previous && run_end[r] <= n_order, "run_end must be non-decreasing");
+        previous = run_end[r];
+      }
+      require(run_end[n_runs - 1] == n_order, "runs must cover box_order");
+      for (int i = 0; i < n_order; ++i) {
+        require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
+      }
+      avr::build_march_items(plan, box_order, run_end, n_runs, run_rects, &items);
+      plan.march_items_ready = keep_items;
     }
-    require(run_end[n_runs - 1] == n_order, "runs must cover box_order");
-    for (int i = 0; i < n_order; ++i) {
-      require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
-    }
-    avr::build_march_items(plan, box_order, run_end, n_runs, run_rects, &items);
     bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
              items.size() * sizeof(avr::MarchItemDev) +
              run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev) +
@@ -452,6 +483,7 @@ void context_set_upload_stream(avr_context* ctx, void* stream) {
   ctx->staging.drain();
   ctx->staging.set_upload_stream(static_cast<hipStream_t>(stream));
 }
+void context_set_lean_descriptors(avr_context* ctx, bool lean) { ctx->staging.set_lean(lean); }
 }  // namespace avr
 
 extern "C" {

@@ -135,6 +135,15 @@ struct RunSpanDev {
 constexpr int kMaxTightenedWidth = 65535;            // x0 / x1 are 16 bit
 constexpr int64_t kMaxTightenedBlockFloats = 0xffffffffLL;  // rel is 32 bit
 
+// One unit of march work: a screen super-tile of one run.  Runs are independent (each has its
+// own layer, started from the empty pixel), so a rank's runs are marched by different
+// workgroups; a frame's critical path is then one run's rays, not all of a rank's boxes.
+struct MarchItemDev {
+  uint32_t slot;  // Morton index of the super-tile; kNoMarchItem = padding
+  uint32_t run;
+};
+constexpr uint32_t kNoMarchItem = 0xffffffffu;
+
 // Host results for one frame over a list of boxes.
 struct FramePlan {
   FrameConsts consts;
@@ -144,16 +153,12 @@ struct FramePlan {
   std::vector<uint32_t> classify_tile_begin;  // n_boxes + 1: prefix sum of classify workgroups
   uint64_t classified_bytes = 0;              // size of the frame's classified buffer
   bool ready = false;                         // set by plan_frame
+  // the march's work items (build_march_items) of the frame plan this prologue belongs to: they
+  // follow from the plan alone, so a camera that repeats does not sort them again (35-45 us of the
+  // host's 0.1 ms per frame at N = 8)
+  std::vector<MarchItemDev> march_items;
+  bool march_items_ready = false;
 };
-
-// One unit of march work: a screen super-tile of one run.  Runs are independent (each has its
-// own layer, started from the empty pixel), so a rank's runs are marched by different
-// workgroups; a frame's critical path is then one run's rays, not all of a rank's boxes.
-struct MarchItemDev {
-  uint32_t slot;  // Morton index of the super-tile; kNoMarchItem = padding
-  uint32_t run;
-};
-constexpr uint32_t kNoMarchItem = 0xffffffffu;
 
 // Screen tiling of the march kernel: workgroup = 16 x 16 pixels, super-tile = 2 x 2 workgroups
 // (Morton order inside); the (super-tile, run) items are dealt round-robin to the 8 XCDs in the
@@ -357,6 +362,10 @@ void set_error(const std::string& message);
 void* context_stream(avr_context* ctx);
 // Descriptor copies of this context run on `stream` (hipStream_t; nullptr = on its own stream).
 void context_set_upload_stream(avr_context* ctx, void* stream);
+// The context's owner bounds the frames in flight itself: a descriptor batch that repeats then
+// leaves no packet at all on the stream (by default its event is still recorded, which is what
+// keeps the host a few batches ahead of the GPU at most).
+void context_set_lean_descriptors(avr_context* ctx, bool lean);
 
 }  // namespace avr
 

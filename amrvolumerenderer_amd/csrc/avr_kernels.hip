@@ -1417,9 +1417,11 @@ int launch_assemble_rows(const PieceMapDev& pieces, const uint8_t* src, int64_t 
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
   const bool wide = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
                     ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  // (a small grid: the pass runs beside the paint kernels of the next frames on the root rank and
+  // should take bandwidth, which it barely needs, not workgroup slots)
   if (wide) {
     const int64_t items = row_bytes / 16;
-    hipLaunchKernelGGL(assemble_rows_kernel<uint4>, dim3(grid_for(items * h, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(assemble_rows_kernel<uint4>, dim3(std::min(grid_for(items * h, 256), 256)), dim3(256), 0,
                        stream, reinterpret_cast<const uint4*>(src), items, pieces, flip,
                        reinterpret_cast<uint4*>(dst));
   } else if (row_bytes % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & 3u) == 0) &&

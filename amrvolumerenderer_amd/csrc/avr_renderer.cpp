@@ -31,6 +31,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "avr_corun.h"
@@ -134,6 +135,7 @@ struct avr_renderer {
   int piece_layout = AVR_PIECES_ROW_BANDS;
   int band_rows = 8;
   int overlap_classify = -1;  // -1: default (1 for one rank, 0 otherwise); see avr_renderer_set_overlap
+  int host_backpressure = -1;  // -1: default (ranks of several); see avr_renderer_set_host_backpressure
 
   // Frame plans by (render parameters, camera, group order), most recently used kept: a camera
   // that comes back (an orbit) finds its plan -- and, for N > 1, its tightened exchange layout.
@@ -155,13 +157,13 @@ struct avr_renderer {
     have_plan = false;
   }
 
-  DeviceBuffer send[2], recv, piece, piece_rgb8, full_rgb8, full_image, assembled_image, small_image;
-  // classified volume f % 3, send buffer f % 2
+  DeviceBuffer send[AVR_CLASSIFIED_SLOTS], recv, piece, piece_rgb8, full_rgb8, full_image, assembled_image, small_image;
+  // classified volume and send buffer f % 3
   hipEvent_t classified_event[AVR_CLASSIFIED_SLOTS] = {};  // classify pass of the volume finished
   hipEvent_t marched_event[AVR_CLASSIFIED_SLOTS] = {};     // march finished reading the volume
-  hipEvent_t composed_event[2] = {nullptr, nullptr};       // stream X finished reading send[slot]
+  hipEvent_t composed_event[AVR_CLASSIFIED_SLOTS] = {};    // stream X finished reading send[slot]
   hipEvent_t input_event = nullptr;
-  bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[2] = {false, false};
+  bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
   unsigned frame = 0;
 
   // host time spent inside avr_renderer_render, by section (avr_renderer_host_profile)
@@ -447,6 +449,16 @@ int avr_renderer_set_piece_layout(avr_renderer* r, int piece_layout, int band_ro
   });
 }
 
+int avr_renderer_set_host_backpressure(avr_renderer* r, int mode) {
+  return guarded([&]() -> int {
+    require(r != nullptr, "null renderer");
+    require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
+    r->drain_all();
+    r->host_backpressure = mode;
+    return AVR_OK;
+  });
+}
+
 int avr_renderer_set_overlap(avr_renderer* r, int overlap_classify) {
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
@@ -704,8 +716,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // stream may run a whole frame ahead of the march: with two, classify(f+1) and march(f) both
     // had to wait for the later of classify(f) and march(f-1) and started in lockstep, a launch
     // latency apart from the kernels before them, every frame.
-    const int slot = static_cast<int>(r->frame & 1u);
     const int volume = static_cast<int>(r->frame % static_cast<unsigned>(AVR_CLASSIFIED_SLOTS));
+    const int slot = volume;  // send buffers rotate with the classified volumes
     auto drain = [&] { r->drain_all(); };
 
     // ---- everything that can fail for lack of memory happens BEFORE anything is queued and
@@ -756,6 +768,33 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
             r->small_image.reserve(bytes_of(static_cast<int64_t>(width) * height, 20), drain));
       }
     }
+    // ---- back-pressure.  The frame re-uses the classified volume and the send buffer of the
+    // frame three before it.  Either the two streams wait for that frame's march and exchange /
+    // fold (two wait packets between this frame's kernels and their predecessors, and with the
+    // descriptor ring's events the host stays a few frames ahead), or -- for the short frames of
+    // a rank of several -- the HOST waits here until they are through and nothing is queued: every
+    // packet between two marches is microseconds of a rank's 0.17 ms frame (with the descriptor
+    // copies of a repeating camera skipped as well, a rank of eight went from 0.187 to 0.164 ms);
+    // at most three frames are then in flight.  One rank's 1 ms frames hide those packets and lose
+    // 1-2 % to the shorter queue (measured), so there the streams wait.
+    // avr_renderer_set_host_backpressure.
+    const bool host_side = (r->host_backpressure < 0) ? many : (r->host_backpressure != 0);
+    for (avr_context* ctx : {r->classify, r->march, r->compose}) {
+      avr::context_set_lean_descriptors(ctx, host_side);
+    }
+    auto host_wait = [&](hipEvent_t event) {
+      for (unsigned spins = 0;; ++spins) {
+        const hipError_t status = hipEventQuery(event);
+        if (status == hipSuccess) return;
+        if (status != hipErrorNotReady) hip_ok(status, "hipEventQuery");
+        (void)hipGetLastError();
+        if (spins > 64) std::this_thread::yield();
+      }
+    };
+    if (host_side) {
+      if (r->marched_pending[volume]) host_wait(r->marched_event[volume]);
+      if (r->composed_pending[slot]) host_wait(r->composed_event[slot]);
+    }
     struct TimedGuard {  // the frame's four timing events, destroyed unless the frame keeps them
       FrameEvents events;
       bool kept = false;
@@ -793,11 +832,17 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       hip_ok(hipEventRecord(r->input_event, producer), "hipEventRecord");
       hip_ok(hipStreamWaitEvent(stream_c, r->input_event, 0), "hipStreamWaitEvent");
     }
-    if (r->marched_pending[volume]) {  // three frames ago this volume was marched
-      hip_ok(hipStreamWaitEvent(stream_c, r->marched_event[volume], 0), "hipStreamWaitEvent");
-    }
-    if (!overlap && r->composed_pending[slot]) {  // (back to back: both waits precede the pair)
-      hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
+    // (With host-side back-pressure the re-use of the frame's classified volume and send buffer
+    // was settled before anything was queued; otherwise the streams wait -- unless the event has
+    // already happened.)
+    auto wait_unless_done = [&](hipStream_t stream, hipEvent_t event) {
+      if (hipEventQuery(event) == hipSuccess) return;
+      (void)hipGetLastError();  // hipErrorNotReady is not an error here
+      hip_ok(hipStreamWaitEvent(stream, event, 0), "hipStreamWaitEvent");
+    };
+    if (!host_side) {
+      if (r->marched_pending[volume]) wait_unless_done(stream_c, r->marched_event[volume]);
+      if (r->composed_pending[slot]) wait_unless_done(stream_m, r->composed_event[slot]);
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
     abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
@@ -808,9 +853,6 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
     if (overlap) {
       hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
-      if (r->composed_pending[slot]) {  // the frame before last is still exchanged / folded from it
-        hip_ok(hipStreamWaitEvent(stream_m, r->composed_event[slot], 0), "hipStreamWaitEvent");
-      }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
     abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));

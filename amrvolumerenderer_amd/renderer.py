@@ -144,7 +144,7 @@ class FrameRenderer:
         # timing events of every frame (bench.py's live kernel durations)
         self.kernel_events: Optional[list] = None
         self._frame = 0
-        self.last_plan = None
+        self._last_plan = None
         # ---- the native frame driver -------------------------------------------------------------
         # The process group is the CONTROL plane only (any backend; bench.py uses gloo): it carries
         # RCCL's 128-byte id from rank 0 to the others and the agreement below.  The data plane is
@@ -194,6 +194,13 @@ class FrameRenderer:
         # only (~60 us of the ~160 us a frame costs the host at N = 8) -- every frame still
         # classifies, marches, exchanges and folds.
         self._plan_cache = None
+
+    @property
+    def last_plan(self):
+        """The plan of the last frame rendered (runs, piece, exchange volume)."""
+        if self.native is not None:
+            return self.native.plan_info()
+        return self._last_plan
 
     @property
     def scalar_range(self):
@@ -316,8 +323,7 @@ class FrameRenderer:
             out = self.native.render(p.width, p.height, p.box_transparency, p.antialiasing, camera,
                                      p.use_visibility_graph, p.draw_bounds,
                                      p.write_visibility_graph, group_order, samples, want_image)
-            self.last_plan = self.native.plan_info()
-            return out
+            return out    # (last_plan asks the driver when somebody wants to know)
         key = (p.width, p.height, p.box_transparency, p.antialiasing, p.use_visibility_graph,
                tuple(camera.eye), tuple(camera.look_at), tuple(camera.up), camera.fov_y_degrees,
                camera.near_plane, camera.far_plane, tuple(self.scalar_range), id(self.color_map),
@@ -335,7 +341,7 @@ class FrameRenderer:
                     "visibility_graph_" if (p.write_visibility_graph and self.rank == 0) else None)
             plan = self.plan(params, camera, group_order)
             self._plan_cache = (key, params, root, plan)
-        self.last_plan = plan
+        self._last_plan = plan
         ctx, comm = self.march_ctx, self.comm_ctx
         slot = self._frame & 1
         self._frame += 1

@@ -683,6 +683,11 @@ class NativeRenderer:
         """avr_renderer_set_overlap (-1 default, 0 back to back, 1 classify beside the march)."""
         _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
 
+    def set_host_backpressure(self, mode: int = -1) -> None:
+        """avr_renderer_set_host_backpressure: -1 default (host-side for a rank of several), 0 the
+        streams wait for the frame three back, 1 the host does."""
+        _capi.check(_capi.lib().avr_renderer_set_host_backpressure(self._handle, int(mode)))
+
     def set_tighten(self, enabled: bool = True) -> None:
         """avr_renderer_set_tighten: per-row exchange layout of every plan the driver makes."""
         _capi.check(_capi.lib().avr_renderer_set_tighten(self._handle, int(bool(enabled))))
@@ -748,10 +753,19 @@ class NativeRenderer:
         """One frame (asynchronous).  Rank 0 returns (image [H, W, 5] or None, rgb8 [H, W, 3] with
         rows top-down); other ranks (None, None).  The tensors are complete on stream X
         (self.streams[2]): synchronize(), or order your stream after it."""
-        rp = _capi.RenderParams(int(width), int(height), float(box_transparency), int(antialiasing),
-                                int(bool(use_visibility_graph)), int(bool(draw_bounds)),
-                                int(bool(write_visibility_graph)))
-        ccam = camera.to_c()
+        # (a camera and parameters that repeat are converted once: per frame the Python layer costs
+        # the host what matters beside a rank's 0.17 ms frame)
+        key = (width, height, box_transparency, antialiasing, use_visibility_graph, draw_bounds,
+               write_visibility_graph, camera.eye, camera.look_at, camera.up, camera.fov_y_degrees,
+               camera.near_plane, camera.far_plane)
+        if getattr(self, "_converted_key", None) != key:
+            self._converted = (
+                _capi.RenderParams(int(width), int(height), float(box_transparency),
+                                   int(antialiasing), int(bool(use_visibility_graph)),
+                                   int(bool(draw_bounds)), int(bool(write_visibility_graph))),
+                camera.to_c())
+            self._converted_key = key
+        rp, ccam = self._converted
         group = None
         if group_order is not None:
             group = (C.c_int32 * self.n_ranks)(*[int(g) for g in group_order])

@@ -518,6 +518,16 @@ int avr_renderer_invalidate(avr_renderer *renderer);
  * (1), or both run back to back on the march stream (0); -1 = default: whichever the driver
  * measures to be faster (avr_renderer_set_classify_share).  Never changes results. */
 int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
+/* A frame re-uses the classified volume and the send buffer of the frame three before it.
+ * 0: the frame's streams wait for that frame on the GPU (two wait packets; the host runs a few
+ * frames ahead).  1: the HOST waits inside avr_renderer_render until that frame's march and
+ * exchange / fold are through and queues no wait -- at most three frames in flight, and a
+ * descriptor batch that repeats (same camera and parameters) leaves no packet at all on the
+ * streams: for the short frames of a rank of several every packet between two kernels counts
+ * (a rank of eight of config-4: 0.187 -> 0.164 ms).  -1 (default): 1 for more than one rank,
+ * 0 for one rank (whose 1 ms frames hide the packets and lose 1-2 % to the shorter queue).
+ * Never changes results. */
+int avr_renderer_set_host_backpressure(avr_renderer *renderer, int mode);
 /* How the classify pass and the march of this rank share the GPU is measured by the driver on
  * the running pipeline, unless fixed here and / or by avr_renderer_set_overlap: the candidates --
  * back to back on one stream, or side by side with an LDS reserve of 0, 2, 4 ... KiB per classify

@@ -57,8 +57,6 @@ for order in args.orders:
     while n < 64 or (time.perf_counter() - begin < 3.0 and not r.corun_state()["settled"]):
         r.render(2048, 2048, 0.97, 1, cam, **kw)
         n += 1
-        if n % 64 == 0:
-            r.synchronize()
     r.synchronize()
     r.set_timing(True)
     t0 = time.perf_counter()

@@ -129,8 +129,6 @@ def measure_share(n_ranks, rank):
             break
         r.render(args.size, args.size, args.transparency, 1, next_cam(), **kw)
         warm += 1
-        if warm % 64 == 0:
-            r.synchronize()
     r.synchronize()
     torch.cuda.synchronize()
     r.set_timing(True)
