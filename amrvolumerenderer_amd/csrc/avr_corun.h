@@ -13,17 +13,27 @@
 // reaches -- whatever its arithmetic, occupancy or cache policy -- so the
 // frame is shortest where the two take equally long; how many classify workgroups a CU admits
 // (an LDS reserve per workgroup, avr_context_set_classify_lds_reserve) moves that balance, and
-// for the short kernels of an N-rank share running them back to back can win outright.  The
-// candidates are tried in turn on the running pipeline -- back to back, side by side with a
-// reserve of 0, 4, 8 ... KiB -- each for a window of frames whose period is timed with two HIP
-// events on the march stream; the driver refines around the best reserve, re-times back to back
-// against it, holds the winner, re-times it now and then and searches again if it has drifted.
-// Scheduling only: never changes results.
+// for the short kernels of an N-rank share running them back to back can win outright.  A third
+// way (round 3): every frame's classify pass and march back to back on ONE stream, the even
+// frames on one stream and the odd frames on another ("paired") -- the classify pass of frame f+1
+// still runs beside the march of frame f, but a march no longer queues behind its predecessor,
+// so its tail (a rank of eight keeps 3.3 of 6 waves per SIMD resident on average) runs beside
+// whatever the other stream has next: a rank of eight 0.165 -> 0.145 ms, one rank 0.986 -> 1.015.
+// The candidates are tried in turn on the running pipeline -- back to back, side by side with a
+// reserve of 0, 4, 8 ... KiB, paired with a reserve of 0, 8, 16 ... KiB -- each for a window of
+// frames whose period is timed with two HIP events on the march stream; the driver refines around
+// the best, re-times back to back against it, holds the winner, re-times it now and then and
+// searches again if it has drifted.  Scheduling only: never changes results.
 struct CoRunTuner {
   static constexpr int kBackToBack = -1;       // candidate: both kernels on the march stream
   static constexpr int kReserveStep = 2048;    // candidate k >= 0: side by side, reserve k * step
   static constexpr int kLastCandidate = 28;    // 56 KiB: two classify workgroups per CU
+  static constexpr int kPairedBase = 29;       // candidate kPairedBase + k: paired, reserve k * step
+  static constexpr int kLastPaired = kPairedBase + kLastCandidate;
   static constexpr int kCoarse = 2;            // the first pass takes every second reserve
+  static constexpr int kPairedCoarse = 4;      // ... of the paired layout every fourth
+  static bool is_paired(int c) { return c >= kPairedBase; }
+  static int reserve_index(int c) { return c >= kPairedBase ? c - kPairedBase : c; }
   static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate (at most)
   static constexpr int kWindowFrames = 40;     // frames timed per candidate (at most)
   static constexpr float kWindowMs = 8.0f;     // ... as many as fill this time, two at least: the
@@ -74,7 +84,7 @@ struct CoRunTuner {
   }
   void restart() {
     phase = kSearch;
-    candidate = best = (start_beside && last >= 0) ? 0 : first;
+    candidate = best = (start_beside && last >= 0) ? std::max(first, 0) : first;
     best_beside = 0;
     second_beside = -1;
     best_ms = best_beside_ms = second_beside_ms = 0.0f;
@@ -147,20 +157,35 @@ struct CoRunTuner {
       }
     }
     if (phase == kSearch) {
-      const int next = (candidate < 0) ? 0 : candidate + kCoarse;
-      if (next <= last) {
+      // back to back, the side-by-side reserves, then the paired ones
+      const int last_beside = std::min(last, kLastCandidate);
+      int next = -2;
+      if (candidate < 0) {
+        next = (last >= 0) ? 0 : -2;
+      } else if (!is_paired(candidate)) {
+        next = candidate + kCoarse;
+        if (next > last_beside) next = (last >= kPairedBase) ? std::max(first, kPairedBase) : -2;
+      } else {
+        next = candidate + kPairedCoarse;
+        if (next > last) next = -2;
+      }
+      if (next != -2) {
         candidate = next;
       } else {
         phase = kRefine;
       }
     }
     if (phase == kRefine) {
-      // best_beside - 1, then best_beside + 1 (those inside the range; the centre may move once)
+      // the neighbours of the best one inside its layout (the centre may move once)
       int next = -1;
       while (refined < 2 && next < 0) {
-        const int probe = best_beside + (refined == 0 ? -1 : 1);
+        const bool paired = is_paired(best_beside);
+        const int step = paired ? kPairedCoarse / 2 : 1;
+        const int lo = paired ? std::max(first, kPairedBase) : std::max(first, 0);
+        const int hi = paired ? last : std::min(last, kLastCandidate);
+        const int probe = best_beside + (refined == 0 ? -step : step);
         ++refined;
-        if (probe >= 0 && probe <= last && last > 0) next = probe;
+        if (probe >= lo && probe <= hi && hi > lo) next = probe;
       }
       if (next >= 0) {
         candidate = next;

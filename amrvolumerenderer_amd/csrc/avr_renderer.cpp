@@ -116,6 +116,7 @@ struct avr_renderer {
   avr_context* compose = nullptr;   // stream X (high priority)
   avr_context* classify = nullptr;  // stream C (default priority)
   hipStream_t upload = nullptr;     // stream U: descriptor copies of the classify pass and the march
+  avr_context* pair_b = nullptr;    // stream B of the paired layout (the odd frames'; high priority)
   avr_scene* scene = nullptr;
   avr_visibility_graph* visibility = nullptr;
   std::vector<avr_box> all_boxes;
@@ -136,6 +137,7 @@ struct avr_renderer {
   int band_rows = 8;
   int overlap_classify = -1;  // -1: default (1 for one rank, 0 otherwise); see avr_renderer_set_overlap
   int host_backpressure = -1;  // -1: default (ranks of several); see avr_renderer_set_host_backpressure
+  hipEvent_t paired_previous = nullptr;  // paired layout: the previous frame's classify pass finished
 
   // Frame plans by (render parameters, camera, group order), most recently used kept: a camera
   // that comes back (an orbit) finds its plan -- and, for N > 1, its tightened exchange layout.
@@ -180,12 +182,13 @@ struct avr_renderer {
   CoRunTuner tuner;
   hipEvent_t window_begin = nullptr, window_end = nullptr;  // timing events on the march stream
   bool last_overlap = false;  // what the last frame did (avr_renderer_corun_state)
+  bool last_paired = false;
   int last_reserve = 0;
   bool pipeline_idle = true;  // nothing in flight: the next classify pass has the GPU to itself
 
   ~avr_renderer() {
     (void)hipSetDevice(device);
-    for (avr_context* ctx : {classify, march, compose}) {
+    for (avr_context* ctx : {classify, march, compose, pair_b}) {
       if (ctx != nullptr) (void)avr_context_synchronize(ctx);
     }
     clear_timing();
@@ -213,6 +216,7 @@ struct avr_renderer {
     if (visibility != nullptr) avr_visibility_graph_destroy(visibility);
     if (scene != nullptr) avr_scene_destroy(scene);
     for (avr_context* ctx : {classify, march, compose}) avr_context_destroy(ctx);
+    if (pair_b != nullptr) avr_context_destroy(pair_b);
   }
 
   void clear_timing() {
@@ -228,6 +232,7 @@ struct avr_renderer {
 
   void drain_all() {
     for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
+    if (pair_b != nullptr) abi_ok(avr_context_synchronize(pair_b));
     pipeline_idle = true;
     tuner.drained();
   }
@@ -417,7 +422,7 @@ int avr_renderer_corun_state(const avr_renderer* r, int* overlap_out, int* reser
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
     const CoRunTuner& t = r->tuner;
-    if (overlap_out != nullptr) *overlap_out = r->last_overlap ? 1 : 0;
+    if (overlap_out != nullptr) *overlap_out = r->last_paired ? 2 : r->last_overlap ? 1 : 0;
     if (reserve_bytes_out != nullptr) *reserve_bytes_out = r->last_reserve;
     if (settled_out != nullptr) *settled_out = t.settled() ? 1 : 0;
     if (windows_out != nullptr) *windows_out = t.windows;
@@ -682,13 +687,20 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // avr_renderer_set_classify_share.  (A cached classification leaves nothing to tune.)
     CoRunTuner& tuner = r->tuner;
     {
-      int first = CoRunTuner::kBackToBack, last = CoRunTuner::kLastCandidate;
+      // overlap_classify: -1 everything, 0 back to back, 1 side by side, 2 paired
+      int first = CoRunTuner::kBackToBack, last = CoRunTuner::kLastPaired;
       if (r->cache_classification) {  // no classify pass to place
         first = last = (r->overlap_classify == 0) ? CoRunTuner::kBackToBack : 0;
       } else if (r->overlap_classify == 0) {
         last = first;
+      } else if (r->overlap_classify == 2) {
+        first = CoRunTuner::kPairedBase;
+        if (r->share_fixed >= 0) last = first;  // the caller's reserve, kept outside the scale
       } else {
-        if (r->overlap_classify > 0) first = 0;
+        if (r->overlap_classify > 0) {
+          first = 0;
+          last = CoRunTuner::kLastCandidate;
+        }
         if (r->share_fixed >= 0) {
           // one side-by-side candidate: the caller's reserve (kept outside the candidate scale)
           last = (first == CoRunTuner::kBackToBack) ? 0 : first;
@@ -697,17 +709,26 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       tuner.restrict_to(first, last, r->n_ranks == 1);
     }
     const bool overlap = tuner.candidate != CoRunTuner::kBackToBack;
+    const bool paired = CoRunTuner::is_paired(tuner.candidate);
     const int reserve = !overlap ? 0
-                        : (r->share_fixed >= 0) ? r->share_fixed
-                                                : tuner.candidate * CoRunTuner::kReserveStep;
+                        : (r->share_fixed >= 0)
+                            ? r->share_fixed
+                            : CoRunTuner::reserve_index(tuner.candidate) * CoRunTuner::kReserveStep;
     // (One stream per kernel kind.  Letting the odd frames take a second march or classify stream
     // -- the frames are independent, so march(f+1) need not queue behind march(f) and its wait /
     // record / copy packets could be worked off early -- was measured in round 3 and is worse by
     // half: with a FOURTH concurrently active queue everything stalls, a 5 us descriptor copy
     // takes 40-50 us, the frame of a rank of eight goes from 0.187 to 0.26-0.33 ms and the one-rank
     // frame from 0.98 to 1.25-1.42 ms.  profiles/r3_experiments/.)
+    // Paired layout (avr_corun.h): this frame's classify pass and march back to back on ONE
+    // stream, the even frames on stream M, the odd ones on stream B -- with stream X three active
+    // queues, the number this GPU runs side by side without penalty.
     avr_context* march_ctx = r->march;
-    avr_context* classify_ctx = overlap ? r->classify : r->march;
+    if (paired && (r->frame & 1u)) {
+      if (r->pair_b == nullptr) abi_ok(avr_context_create_with_priority(r->device, 1, &r->pair_b));
+      march_ctx = r->pair_b;
+    }
+    avr_context* classify_ctx = paired ? march_ctx : overlap ? r->classify : r->march;
     abi_ok(avr_context_set_march_occupancy(march_ctx, cap));
     hipStream_t stream_c = r->stream_of(classify_ctx);
     hipStream_t stream_m = r->stream_of(march_ctx);
@@ -779,8 +800,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // 1-2 % to the shorter queue (measured), so there the streams wait.
     // avr_renderer_set_host_backpressure.
     const bool host_side = (r->host_backpressure < 0) ? many : (r->host_backpressure != 0);
-    for (avr_context* ctx : {r->classify, r->march, r->compose}) {
-      avr::context_set_lean_descriptors(ctx, host_side);
+    for (avr_context* ctx : {r->classify, r->march, r->compose, r->pair_b}) {
+      if (ctx != nullptr) avr::context_set_lean_descriptors(ctx, host_side);
     }
     auto host_wait = [&](hipEvent_t event) {
       for (unsigned spins = 0;; ++spins) {
@@ -820,6 +841,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     abi_ok(avr_context_set_classify_lds_reserve(classify_ctx,
                                                 (overlap && !r->pipeline_idle) ? reserve : 0));
     r->last_overlap = overlap;
+    r->last_paired = paired;
     r->last_reserve = reserve;
     r->pipeline_idle = false;
 
@@ -844,14 +866,21 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       if (r->marched_pending[volume]) wait_unless_done(stream_c, r->marched_event[volume]);
       if (r->composed_pending[slot]) wait_unless_done(stream_m, r->composed_event[slot]);
     }
+    if (paired && r->paired_previous != nullptr) {  // one classify pass at a time
+      if (hipEventQuery(r->paired_previous) != hipSuccess) {
+        (void)hipGetLastError();
+        hip_ok(hipStreamWaitEvent(stream_c, r->paired_previous, 0), "hipStreamWaitEvent");
+      }
+    }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
     abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
     hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[volume];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
+    r->paired_previous = paired ? classified : nullptr;
 
     lap(1);
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
-    if (overlap) {
+    if (overlap && !paired) {  // (paired: the march follows its classify pass on the same stream)
       hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");

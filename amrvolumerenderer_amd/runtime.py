@@ -680,7 +680,8 @@ class NativeRenderer:
         _capi.check(_capi.lib().avr_renderer_synchronize(self._handle))
 
     def set_overlap(self, overlap_classify: int) -> None:
-        """avr_renderer_set_overlap (-1 default, 0 back to back, 1 classify beside the march)."""
+        """avr_renderer_set_overlap (-1 default: measured, 0 back to back, 1 classify beside the
+        march, 2 paired: frames alternate between two streams)."""
         _capi.check(_capi.lib().avr_renderer_set_overlap(self._handle, int(overlap_classify)))
 
     def set_host_backpressure(self, mode: int = -1) -> None:
@@ -710,7 +711,9 @@ class NativeRenderer:
         _capi.check(_capi.lib().avr_renderer_corun_state(self._handle, C.byref(overlap),
                                                          C.byref(reserve), C.byref(settled),
                                                          C.byref(windows)))
-        return {"classify": "beside the march" if overlap.value else "before the march",
+        layout = {0: "before the march", 1: "beside the march",
+                  2: "before its march, the frames alternating between two streams"}
+        return {"classify": layout.get(overlap.value, str(overlap.value)),
                 "lds_reserve_bytes": reserve.value, "settled": bool(settled.value),
                 "timed_windows": windows.value}
 

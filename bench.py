@@ -409,7 +409,7 @@ def main():
     # a fixed count, well past the <= 1000 frames the search takes at short frames, instead of a
     # clock)
     # (a one-GPU rehearsal moves every block through host memory: it is not there to settle)
-    fixed_burst = (48 if args.rehearse_on_one_gpu else 1600) if world > 1 else None
+    fixed_burst = (48 if args.rehearse_on_one_gpu else 2400) if world > 1 else None
     while True:
         for _ in range(16):
             step(burst)

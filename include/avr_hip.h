@@ -514,9 +514,16 @@ int avr_renderer_set_scalar_range(avr_renderer *renderer, const float scalar_ran
 /* avr_scene_invalidate for the renderer's scene: call after changing cell data in place while
  * cache_classification is on. */
 int avr_renderer_invalidate(avr_renderer *renderer);
-/* Whether the classify pass of frame i+1 runs on its own stream beside the march of frame i
- * (1), or both run back to back on the march stream (0); -1 = default: whichever the driver
- * measures to be faster (avr_renderer_set_classify_share).  Never changes results. */
+/* How a frame's two paint kernels are laid out on the streams:
+ *   0  back to back on the march stream;
+ *   1  side by side: the classify pass of frame i+1 on its own stream beside the march of frame i;
+ *   2  paired: every frame's classify pass and march back to back on ONE stream, the even frames
+ *      on stream M, the odd ones on a second stream -- the classify pass of frame i+1 still runs
+ *      beside the march of frame i, but a march never queues behind its predecessor, so its tail
+ *      runs beside whatever the other stream has next (a rank of eight of config-4: 0.165 ->
+ *      0.145 ms; one rank: 0.986 -> 1.015 ms);
+ *  -1  (default) whichever the driver measures to be fastest (avr_renderer_set_classify_share).
+ * Never changes results. */
 int avr_renderer_set_overlap(avr_renderer *renderer, int overlap_classify);
 /* A frame re-uses the classified volume and the send buffer of the frame three before it.
  * 0: the frame's streams wait for that frame on the GPU (two wait packets; the host runs a few

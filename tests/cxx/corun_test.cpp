@@ -2,6 +2,7 @@
 // decision logic is driven with synthetic frame periods -- a model GPU that answers every timed
 // window with the period of the candidate in use -- and must settle where that period is least.
 //   corun_test            runs all cases, prints "ok", exit code 0
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -173,6 +174,55 @@ int main() {
     }
     expect(good >= trials * 95 / 100, "noisy windows: within 2 % of the best in " +
                                           std::to_string(good) + " of " + std::to_string(trials));
+  }
+  {  // the paired layout is searched after the side-by-side reserves and wins where it is faster:
+     // a rank of eight (paired 0.145 ms at 0-16 KiB against the side-by-side dip of 0.165)
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastPaired, false);
+    auto model = [](int c) {
+      if (!CoRunTuner::is_paired(c)) return eighth(c) - 0.007f;  // dip 0.165 at 44 KiB
+      const float kib = 2.0f * static_cast<float>(CoRunTuner::reserve_index(c));
+      return kib <= 16.0f ? 0.145f : 0.145f + (kib - 16.0f) * 0.0008f;
+    };
+    const Run run = play(t, model, 4000);
+    expect(t.settled() && CoRunTuner::is_paired(run.candidate) &&
+               CoRunTuner::reserve_index(run.candidate) <= 8,
+           "a rank of eight settles on the paired layout, got " + std::to_string(run.candidate));
+    bool beside_first = true, seen_paired = false;
+    for (int c : run.tried) {
+      if (CoRunTuner::is_paired(c)) seen_paired = true;
+      if (seen_paired && !CoRunTuner::is_paired(c) && c >= 0 && t.phase == CoRunTuner::kSearch) {
+        beside_first = false;
+      }
+    }
+    expect(beside_first, "the paired reserves are tried after the side-by-side ones");
+  }
+  {  // ... and loses where it is slower: one rank (paired 1.015 ms at best against 1.000)
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastPaired, true);
+    auto model = [](int c) {
+      if (!CoRunTuner::is_paired(c)) return one_rank(c);
+      const float kib = 2.0f * static_cast<float>(CoRunTuner::reserve_index(c));
+      return 1.015f + 0.004f * std::fabs(kib - 16.0f);
+    };
+    const Run run = play(t, model, 4000);
+    expect(t.settled() && (run.candidate == 12 || run.candidate == 13),
+           "one rank stays side by side at 24-26 KiB, got " + std::to_string(run.candidate));
+    expect(run.frames < 480, "one rank settles within 480 frames with the paired layout in the "
+                             "search, took " + std::to_string(run.frames));
+  }
+  {  // the caller asked for the paired layout only: its reserves alone are searched
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kPairedBase, CoRunTuner::kLastPaired, true);
+    expect(t.candidate == CoRunTuner::kPairedBase, "paired only starts paired without a reserve");
+    const Run run = play(t, [](int c) {
+      return 0.145f + 0.001f * std::fabs(static_cast<float>(CoRunTuner::reserve_index(c)) - 6.0f);
+    }, 4000);
+    bool only_paired = true;
+    for (int c : run.tried) only_paired = only_paired && CoRunTuner::is_paired(c);
+    expect(t.settled() && only_paired && CoRunTuner::reserve_index(run.candidate) >= 4 &&
+               CoRunTuner::reserve_index(run.candidate) <= 8,
+           "paired only finds its dip, got " + std::to_string(run.candidate));
   }
   if (failures == 0) std::printf("ok\n");
   return failures == 0 ? 0 : 1;

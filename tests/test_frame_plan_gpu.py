@@ -318,12 +318,22 @@ def test_corun_tuning_never_changes_results(O, ctx):
         return renderer, out
 
     _, want = run(0, 0, 3)
-    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 1500), (4096, -1, 400)):
+    # (2: the paired layout -- every frame's two kernels on one stream, the frames alternating
+    # between two streams; with the reserve fixed, then searched; with host-side back-pressure)
+    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 2400), (4096, -1, 400), (8192, 2, 13),
+                                   (-1, 2, 600)):
         renderer, got = run(share, overlap, frames)
         state = renderer.native.corun_state()
         if overlap == 1:
             assert state == {"classify": "beside the march", "lds_reserve_bytes": share,
                              "settled": True, "timed_windows": 0}
+        elif overlap == 2 and share >= 0:
+            assert state == {"classify": "before its march, the frames alternating between two "
+                                         "streams", "lds_reserve_bytes": share, "settled": True,
+                             "timed_windows": 0}
+        elif overlap == 2:
+            assert state["classify"].startswith("before its march, the frames alternating")
+            assert state["timed_windows"] >= 4 and state["settled"]
         elif share < 0:
             assert state["timed_windows"] >= 4 and state["settled"]
             assert 0 <= state["lds_reserve_bytes"] <= 57344
