@@ -34,7 +34,7 @@ struct CoRunTuner {
   static constexpr int kPairedCoarse = 4;      // ... of the paired layout every fourth
   static bool is_paired(int c) { return c >= kPairedBase; }
   static int reserve_index(int c) { return c >= kPairedBase ? c - kPairedBase : c; }
-  static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate (at most)
+  static constexpr int kSettleFrames = 3;      // frames ignored after a change of candidate (at least)
   static constexpr int kWindowFrames = 40;     // frames timed per candidate (at most)
   static constexpr float kWindowMs = 8.0f;     // ... as many as fill this time, two at least: the
                                                // 0.2 ms frames of an N = 8 share need ~40 for a
@@ -52,6 +52,15 @@ struct CoRunTuner {
   int candidate = kBackToBack;
   int best = kBackToBack, best_beside = 0, second_beside = -1;
   float best_ms = 0.0f, best_beside_ms = 0.0f, second_beside_ms = 0.0f;
+  // the two best candidates of each layout ([0] side by side, [1] paired) during the search;
+  // best_beside / second_beside above are those of the layout the search went on with
+  int layout_best[2] = {0, kPairedBase}, layout_second[2] = {-1, -1};
+  float layout_best_ms[2] = {0.0f, 0.0f}, layout_second_ms[2] = {0.0f, 0.0f};
+  // A window timed while the candidates change reads the side-by-side layout 3-5 % slower than it
+  // runs once held (its two streams take tens of frames to find their phase; measured on config-2
+  // and config-3: 0.402 in the search, 0.381 held) and the paired layout as it is: paired is only
+  // gone on with if it wins by more than that.
+  static constexpr float kPairedMargin = 1.05f;
   int verify[3] = {0, 0, 0}, n_verify = 0, verify_at = 0;  // kVerify: candidates re-timed in turn
   int refined = 0;
   long windows = 0;
@@ -88,6 +97,10 @@ struct CoRunTuner {
     best_beside = 0;
     second_beside = -1;
     best_ms = best_beside_ms = second_beside_ms = 0.0f;
+    layout_best[0] = 0;
+    layout_best[1] = kPairedBase;
+    layout_second[0] = layout_second[1] = -1;
+    layout_best_ms[0] = layout_best_ms[1] = layout_second_ms[0] = layout_second_ms[1] = 0.0f;
     n_verify = verify_at = 0;
     refined = 0;
     interrupt();
@@ -105,7 +118,12 @@ struct CoRunTuner {
   Action frame() {
     if (closing) return kNothing;
     ++frames_at_candidate;
-    const int start = (phase == kHold) ? kHoldFrames : std::min(kSettleFrames, frames_per_window());
+    // After a change of candidate the two streams take a while to find their steady phase (side
+    // by side: tens of frames; a window timed right after the change read 3-5 % slow, which was
+    // harmless while every candidate was side by side and is not beside the paired layout, which
+    // settles at once): as many frames are let pass as the window then times.
+    const int start =
+        (phase == kHold) ? kHoldFrames : std::max(kSettleFrames, frames_per_window());
     if (!open && frames_at_candidate >= start) {
       open = true;
       window_length = frames_per_window();
@@ -143,17 +161,31 @@ struct CoRunTuner {
       best_ms = period_ms;
       best = candidate;
     }
-    if (phase != kVerify && candidate >= 0) {  // the two best reserves of the search
-      if (best_beside_ms == 0.0f || period_ms < best_beside_ms) {
-        if (best_beside_ms != 0.0f) {
-          second_beside = best_beside;
-          second_beside_ms = best_beside_ms;
+    if (phase != kVerify && candidate >= 0) {  // the two best reserves of the candidate's layout
+      const int layout = is_paired(candidate) ? 1 : 0;
+      if (layout_best_ms[layout] == 0.0f || period_ms < layout_best_ms[layout]) {
+        if (layout_best_ms[layout] != 0.0f) {
+          layout_second[layout] = layout_best[layout];
+          layout_second_ms[layout] = layout_best_ms[layout];
         }
-        best_beside_ms = period_ms;
-        best_beside = candidate;
-      } else if (second_beside < 0 || period_ms < second_beside_ms) {
-        second_beside = candidate;
-        second_beside_ms = period_ms;
+        layout_best_ms[layout] = period_ms;
+        layout_best[layout] = candidate;
+      } else if (layout_second[layout] < 0 || period_ms < layout_second_ms[layout]) {
+        layout_second[layout] = candidate;
+        layout_second_ms[layout] = period_ms;
+      }
+      // the layout to go on with: paired only if it wins by the margin (or is all there is)
+      const bool only_paired = first >= kPairedBase;
+      const bool go_paired =
+          only_paired || (layout_best_ms[1] != 0.0f &&
+                          (layout_best_ms[0] == 0.0f ||
+                           layout_best_ms[1] * kPairedMargin < layout_best_ms[0]));
+      const int chosen = go_paired ? 1 : 0;
+      if (layout_best_ms[chosen] != 0.0f) {
+        best_beside = layout_best[chosen];
+        best_beside_ms = layout_best_ms[chosen];
+        second_beside = layout_second[chosen];
+        second_beside_ms = layout_second_ms[chosen];
       }
     }
     if (phase == kSearch) {

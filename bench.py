@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--classify-share", type=int, default=-1,
                     help="LDS reserve (bytes) per classify workgroup beside the march; -1 = "
                          "balanced by the C++ driver (avr_renderer_set_classify_share)")
+    ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="avr_renderer_set_overlap: -1 measured by the driver (default), 0 back to "
+                         "back, 1 side by side, 2 paired (A/B only)")
     ap.add_argument("--no-self-check", action="store_true",
                     help="experiment builds only (tools/ab_*.sh variants that change results)")
     ap.add_argument("--check-collectives", action="store_true",
@@ -314,6 +317,8 @@ def main():
                              cache_classification=args.cache_classification)
     if renderer.native is not None and args.classify_share >= 0:
         renderer.native.set_classify_share(args.classify_share)
+    if renderer.native is not None and args.layout >= 0:
+        renderer.native.set_overlap(args.layout)
     rparams = RenderParameters(width=width, height=height, box_transparency=args.transparency,
                                antialiasing=args.antialiasing,
                                draw_bounds=False)  # not part of the metric
@@ -406,10 +411,10 @@ def main():
         return renderer.native is None or renderer.native.corun_state()["settled"]
 
     # (N ranks: every frame is a collective, so every rank must run the same number of them --
-    # a fixed count, well past the <= 1000 frames the search takes at short frames, instead of a
+    # a fixed count, well past the <= 2400 frames the search takes at short frames, instead of a
     # clock)
     # (a one-GPU rehearsal moves every block through host memory: it is not there to settle)
-    fixed_burst = (48 if args.rehearse_on_one_gpu else 2400) if world > 1 else None
+    fixed_burst = (48 if args.rehearse_on_one_gpu else 3200) if world > 1 else None
     while True:
         for _ in range(16):
             step(burst)

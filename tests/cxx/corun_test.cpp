@@ -94,7 +94,8 @@ int main() {
     expect(t.settled(), "one rank settles");
     expect(run.candidate == 12 || run.candidate == 13, "one rank holds 24-26 KiB, got " +
                                                             std::to_string(run.candidate));
-    expect(run.frames < 320, "one rank settles within 320 frames, took " + std::to_string(run.frames));
+    // (20 windows of 8 timed frames, each after 8 frames of settling, + the event lag)
+    expect(run.frames < 400, "one rank settles within 400 frames, took " + std::to_string(run.frames));
     int back_to_back = 0;
     for (int c : run.tried) back_to_back += (c == CoRunTuner::kBackToBack) ? 1 : 0;
     expect(run.tried.front() == 0 && back_to_back == 1 &&
@@ -148,7 +149,7 @@ int main() {
     CoRunTuner t;
     t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
     Run run = play(t, [](int c) { return 35.0f * one_rank(c); }, 5000);
-    expect(t.settled() && run.frames < 160, "35 ms frames settle within 160 frames, took " +
+    expect(t.settled() && run.frames < 180, "35 ms frames settle within 180 frames, took " +
                                                 std::to_string(run.frames));
     const int held = run.candidate;
     run = play(t, [](int c) { return 35.0f * one_rank(c); }, 2 * CoRunTuner::kHoldFrames + 40, 2, 0,
@@ -208,7 +209,7 @@ int main() {
     const Run run = play(t, model, 4000);
     expect(t.settled() && (run.candidate == 12 || run.candidate == 13),
            "one rank stays side by side at 24-26 KiB, got " + std::to_string(run.candidate));
-    expect(run.frames < 480, "one rank settles within 480 frames with the paired layout in the "
+    expect(run.frames < 560, "one rank settles within 560 frames with the paired layout in the "
                              "search, took " + std::to_string(run.frames));
   }
   {  // the caller asked for the paired layout only: its reserves alone are searched
