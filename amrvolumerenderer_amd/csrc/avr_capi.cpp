@@ -18,6 +18,9 @@
 
 namespace avr {
 
+static_assert((hipEventDisableTiming | hipEventDisableSystemFence) == (0x2u | 0x20000000u),
+              "avr::ordering_event_flags spells the flags out (avr_internal.h has no HIP header)");
+
 namespace {
 thread_local std::string g_last_error;
 }
@@ -107,7 +110,7 @@ class StagingRing {
   void close_batch() {
     if (current_ != nullptr && current_->consumer != nullptr) {
       if (current_->consumed == nullptr) {
-        hip_check(hipEventCreateWithFlags(&current_->consumed, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&current_->consumed, avr::ordering_event_flags()), "hipEventCreate");
       }
       hip_check(hipEventRecord(current_->consumed, current_->consumer), "hipEventRecord(staging)");
       current_->consumer = nullptr;
@@ -121,7 +124,7 @@ class StagingRing {
     current_ = &slots_[next_];
     next_ = (next_ + 1) % kSlots;
     if (current_->done == nullptr) {
-      hip_check(hipEventCreateWithFlags(&current_->done, hipEventDisableTiming), "hipEventCreate");
+      hip_check(hipEventCreateWithFlags(&current_->done, avr::ordering_event_flags()), "hipEventCreate");
     }
     if (current_->pending) {
       wait_event(current_->done, "hipEventQuery(staging)");

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 
 // How the classify pass and the march of a rank share the GPU is MEASURED, not assumed.  Beside
 // the march the classify pass takes memory-system time from it in proportion to the bandwidth it
@@ -60,9 +61,9 @@ struct CoRunTuner {
   // runs once held (its two streams take tens of frames to find their phase; measured on config-2
   // and config-3: 0.402 in the search, 0.381 held) and the paired layout as it is: paired is only
   // gone on with if it wins by more than that.
-  static constexpr float kPairedMargin = 1.05f;
+  static constexpr float kPairedMargin = 1.02f;
   int verify[3] = {0, 0, 0}, n_verify = 0, verify_at = 0;  // kVerify: candidates re-timed in turn
-  int refined = 0;
+  int refined = 0, repeated = 0;
   long windows = 0;
   // the window in progress
   int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
@@ -126,7 +127,12 @@ struct CoRunTuner {
         (phase == kHold) ? kHoldFrames : std::max(kSettleFrames, frames_per_window());
     if (!open && frames_at_candidate >= start) {
       open = true;
-      window_length = frames_per_window();
+      // paired, the window's two events must lie on the same one of the two streams (whose
+      // frames end in pairs, not evenly spaced: an odd window read a period 1/L short or long)
+      // (the finalists' windows are twice as long: 8 frames of 1 ms are good to 1.5 %, and the
+      // reserve next to the best one is often within that)
+      window_length = frames_per_window() * (phase == kVerify ? 2 : 1);
+      if (is_paired(candidate)) window_length += window_length & 1;
       return kOpenWindow;
     }
     if (open && frames_at_candidate >= start + window_length) {
@@ -145,9 +151,21 @@ struct CoRunTuner {
     last_period_ms = period_ms;
     static const bool trace = std::getenv("AVR_CORUN_TRACE") != nullptr;  // diagnostics
     if (trace) {
-      std::fprintf(stderr, "corun: phase %d candidate %d period %.4f ms\n", static_cast<int>(phase),
-                   candidate, period_ms);
+      timespec now{};
+      clock_gettime(CLOCK_MONOTONIC, &now);
+      std::fprintf(stderr, "corun: phase %d candidate %d period %.4f ms at %.4f\n",
+                   static_cast<int>(phase), candidate, period_ms,
+                   static_cast<double>(now.tv_sec) + 1e-9 * static_cast<double>(now.tv_nsec));
     }
+    // diagnostics: AVR_CORUN_REPEAT=n times every candidate n windows on end (how long a layout
+    // takes to reach its steady period after a change)
+    static const int repeat = std::getenv("AVR_CORUN_REPEAT") ? std::atoi(std::getenv("AVR_CORUN_REPEAT")) : 0;
+    if (repeat > 1 && phase != kHold && ++repeated < repeat) {
+      open = closing = false;
+      frames_at_candidate = std::max(kSettleFrames, frames_per_window()) - 1;
+      return;
+    }
+    repeated = 0;
     if (phase == kHold) {
       if (period_ms > best_ms * kDrift) {
         restart();

@@ -4,6 +4,7 @@
 #define AVR_INTERNAL_H
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -366,6 +367,17 @@ void context_set_upload_stream(avr_context* ctx, void* stream);
 // leaves no packet at all on the stream (by default its event is still recorded, which is what
 // keeps the host a few batches ahead of the GPU at most).
 void context_set_lean_descriptors(avr_context* ctx, bool lean);
+
+// Flags of the events that only ORDER work between this library's streams on ONE device (a
+// frame's classified volume -> its march -> its fold; the descriptor ring's slots): recorded
+// without the system-scope fence.  Whoever waits on them is another queue of the same GPU (the
+// kernel's own end-of-kernel release makes its writes visible there) or the host asking only
+// WHETHER the work is through (buffer re-use), never reading what it wrote -- results reach the
+// host through a stream / renderer synchronise, which fences.  Measured (tools/microbench/
+// packet_gap.hip): a record costs 3.0 us of stream time with the fence and 1.2 us without; with
+// two to three records between a frame's kernels and the next frame's: config-2 0.381 -> 0.376 ms,
+// config-4 0.992 -> 0.978 ms at fixed reserves.  (hipEventDisableTiming | hipEventDisableSystemFence)
+inline unsigned ordering_event_flags() { return 0x2u | 0x20000000u; }
 
 }  // namespace avr
 

@@ -272,7 +272,7 @@ int validate(const avr_render_params& p) {
 
 hipEvent_t make_event(bool timing) {
   hipEvent_t event = nullptr;
-  hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : hipEventDisableTiming),
+  hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : avr::ordering_event_flags()),
          "hipEventCreate");
   return event;
 }
@@ -324,6 +324,7 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     // but the march still starts 27 us after the one before it (the stream's event packets, not
     // the 5 us copy, are the gap), and the extra stream can push the classify stream onto a
     // hardware queue it shares: rank of eight 0.192 -> 0.192 ms (=1), 0.245 ms (=2).
+    if (const char* bp = std::getenv("AVR_HOST_BACKPRESSURE")) r->host_backpressure = std::atoi(bp);  // experiment
     const char* upload_env = std::getenv("AVR_UPLOAD_STREAM");
     const int upload_mode = upload_env != nullptr ? std::atoi(upload_env) : 0;
     if (upload_mode != 0) {
@@ -370,7 +371,8 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     for (hipEvent_t& ev : r->classified_event) ev = make_event(false);
     for (hipEvent_t& ev : r->marched_event) ev = make_event(false);
     for (hipEvent_t& ev : r->composed_event) ev = make_event(false);
-    r->input_event = make_event(false);
+    // (the caller's producer stream is not ours to reason about: this one keeps the system fence)
+    hip_ok(hipEventCreateWithFlags(&r->input_event, hipEventDisableTiming), "hipEventCreate");
     *out_renderer = r.release();
     return AVR_OK;
   });
