@@ -324,7 +324,6 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     // but the march still starts 27 us after the one before it (the stream's event packets, not
     // the 5 us copy, are the gap), and the extra stream can push the classify stream onto a
     // hardware queue it shares: rank of eight 0.192 -> 0.192 ms (=1), 0.245 ms (=2).
-    if (const char* bp = std::getenv("AVR_HOST_BACKPRESSURE")) r->host_backpressure = std::atoi(bp);  // experiment
     const char* upload_env = std::getenv("AVR_UPLOAD_STREAM");
     const int upload_mode = upload_env != nullptr ? std::atoi(upload_env) : 0;
     if (upload_mode != 0) {

@@ -225,6 +225,43 @@ int main() {
                CoRunTuner::reserve_index(run.candidate) <= 8,
            "paired only finds its dip, got " + std::to_string(run.candidate));
   }
+  {  // a near tie goes to the side-by-side layout (a window timed during the search reads it a
+     // few per cent slow; config-2: paired 0.400 in the search against 0.402, held 0.412 / 0.381)
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastPaired, true);
+    auto model = [](int c) {
+      if (c < 0) return 0.50f;
+      const float kib = 2.0f * static_cast<float>(CoRunTuner::reserve_index(c));
+      if (!CoRunTuner::is_paired(c)) return 0.46f - 0.001f * kib;  // 0.404 at 56 KiB
+      return 0.400f + 0.001f * kib;
+    };
+    const Run run = play(t, model, 6000);
+    expect(t.settled() && !CoRunTuner::is_paired(run.candidate) && run.candidate >= 26,
+           "a near tie stays side by side, got " + std::to_string(run.candidate));
+  }
+  {  // the windows of the paired layout have an even number of frames (both events on the same
+     // one of its two streams); the finalists' windows are twice as long
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kPairedBase, CoRunTuner::kLastPaired, true);
+    bool even = true, doubled = false;
+    int search_length = 0;
+    int ready_in = -1;
+    for (int frame = 0; frame < 4000 && !t.settled(); ++frame) {
+      if (t.closing) {
+        if (ready_in-- <= 0) t.report(0.381f);  // 8 / 0.381 = 21 frames per window
+        continue;
+      }
+      const CoRunTuner::Action action = t.frame();
+      if (action == CoRunTuner::kOpenWindow) {
+        even = even && (t.window_length % 2 == 0);
+        if (t.phase == CoRunTuner::kSearch) search_length = t.window_length;
+        if (t.phase == CoRunTuner::kVerify && t.window_length >= 2 * search_length - 2) doubled = true;
+      }
+      if (action == CoRunTuner::kCloseWindow) ready_in = 2;
+    }
+    expect(even, "paired windows have an even number of frames");
+    expect(doubled, "the finalists are timed over double windows");
+  }
   if (failures == 0) std::printf("ok\n");
   return failures == 0 ? 0 : 1;
 }
