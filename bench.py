@@ -429,27 +429,30 @@ def main():
         if burst % 64 == 0:
             renderer.synchronize()   # keep the queue short so the clock check means GPU time
     renderer.synchronize()
+    params, _ = renderer.make_params(rparams)
+    native = renderer.native is not None
     for i in range(args.warmup):
         step(i)
-    renderer.synchronize()
-    torch.cuda.synchronize()
 
     # ---- timed region: EXACTLY `steps` frames ----------------------------------------------
     # the two paint kernels' own durations are taken with HIP events on the streams they are
-    # launched on (classify on classify_ctx.stream, march on march_ctx.stream)
-    params, _ = renderer.make_params(rparams)
-    native = renderer.native is not None
+    # launched on (classify on classify_ctx.stream, march on march_ctx.stream).
+    # Nothing but the contract's synchronise (+ barrier) lies between the last warm-up frame and
+    # t0: this GPU drops its clocks when it idles and takes milliseconds to come back (measured
+    # with a sleep here: 0.5 ms idle 1.011 ms per frame over 20 steps, 5 ms 1.095, 50 ms 1.117 --
+    # the first march after the pause runs 1.25 ms instead of 0.97), so the untimed bookkeeping
+    # is not added to that pause.
     if native:
         renderer.native.set_timing(True)     # drains the streams, records the epoch
+        renderer.native.host_profile(reset=True)
     else:
+        renderer.synchronize()
         renderer.kernel_events = []
         epoch = torch.cuda.Event(enable_timing=True)
         epoch.record(renderer.march_ctx.stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    if native:
-        renderer.native.host_profile(reset=True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, timed=True)

@@ -5,6 +5,8 @@ cd "$(dirname "$0")/.." || exit 1
 R=$PWD
 out=$R/gpurun_out/r3_final
 mkdir -p $out
+part=${1:-all}   # "kernels" (tests, bench lines, kernel stats, PMC), "shares" (the N-rank model) or all
+if [ "$part" != shares ]; then
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $out/pytest.txt 2>&1 || { tail -40 $out/pytest.txt; exit 1; }
 tail -2 $out/pytest.txt
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $out/bench_20.json 2> $out/bench_20.err || { tail -20 $out/bench_20.err; exit 1; }
@@ -15,6 +17,8 @@ cd $R
 GRAFT_REPO_ROOT=$R timeout -k 10 1500 bash tools/pmc_passes.sh $out/pmc --steps 20 --warmup 3 > $out/pmc.log 2>&1 || { tail -20 $out/pmc.log; exit 1; }
 cd $R
 tail -60 $out/pmc.log
+fi
+[ "$part" = kernels ] && exit 0
 for policy in level_pairs morton; do
   timeout -k 10 900 python3 tools/rank_share.py --ownership $policy > $out/rank_share_$policy.txt 2> $out/rank_share_$policy.err || { tail -20 $out/rank_share_$policy.err; exit 1; }
   tail -5 $out/rank_share_$policy.txt
