@@ -87,40 +87,16 @@ class StagingRing {
       if (slot.dev != nullptr) (void)hipFree(slot.dev);
       if (slot.host != nullptr) (void)hipHostFree(slot.host);
       if (slot.done != nullptr) (void)hipEventDestroy(slot.done);
-      if (slot.consumed != nullptr) (void)hipEventDestroy(slot.consumed);
       slot = Slot{};
     }
   }
 
-  // Copies run on this stream instead of the consumer's (nullptr: on the consumer's, the default).
-  // The consumer then only waits for an event that is usually long signalled -- the host runs
-  // frames ahead of the GPU -- instead of executing the copy between two of its kernels
-  // (measured on a rank of eight: 17 + 5 + 8 us between two marches for the waits, the copy and
-  // the launch; tools/share_timeline.py).
-  void set_upload_stream(hipStream_t stream) { upload_stream_ = stream; }
   // The owner keeps the host from running ahead by other means (the frame driver's host-side
   // back-pressure): a skipped copy then leaves no packet at all on the consumer stream.
   void set_lean(bool lean) { lean_ = lean; }
 
-  // With a separate upload stream a block's device twin is no longer protected by stream order
-  // (the copy of a later batch could overtake the kernels that still read this one): the
-  // consumer stream records, after the batch's kernels, that the twin is free.  Done lazily --
-  // by the next begin(), when every launch of the batch has been issued (a context is used by
-  // one thread).
-  void close_batch() {
-    if (current_ != nullptr && current_->consumer != nullptr) {
-      if (current_->consumed == nullptr) {
-        hip_check(hipEventCreateWithFlags(&current_->consumed, avr::ordering_event_flags()), "hipEventCreate");
-      }
-      hip_check(hipEventRecord(current_->consumed, current_->consumer), "hipEventRecord(staging)");
-      current_->consumer = nullptr;
-      current_->consumed_pending = true;
-    }
-  }
-
   // Starts a batch with room for `bytes` in `items` arrays.
   void begin(size_t bytes, int items) {
-    close_batch();
     current_ = &slots_[next_];
     next_ = (next_ + 1) % kSlots;
     if (current_->done == nullptr) {
@@ -129,10 +105,6 @@ class StagingRing {
     if (current_->pending) {
       wait_event(current_->done, "hipEventQuery(staging)");
       current_->pending = false;
-    }
-    if (current_->consumed_pending) {
-      wait_event(current_->consumed, "hipEventQuery(staging)");
-      current_->consumed_pending = false;
     }
     const size_t need = bytes + static_cast<size_t>(items + 1) * kAlign;
     if (need > current_->capacity) {
@@ -185,32 +157,22 @@ class StagingRing {
       }
       return;
     }
-    hipStream_t copier = (upload_stream_ != nullptr) ? upload_stream_ : stream;
     if (used_ != 0) {
-      const int status = launch_upload(current_->host_mapped, current_->dev, used_, copier);
+      const int status = launch_upload(current_->host_mapped, current_->dev, used_, stream);
       if (status != AVR_OK) throw HipFailure(g_last_error);
     }
-    hip_check(hipEventRecord(current_->done, copier), "hipEventRecord(staging)");
+    hip_check(hipEventRecord(current_->done, stream), "hipEventRecord(staging)");
     current_->pending = true;
     current_->shadow.assign(static_cast<const char*>(current_->host),
                             static_cast<const char*>(current_->host) + used_);
-    if (copier != stream) {
-      hip_check(hipStreamWaitEvent(stream, current_->done, 0), "hipStreamWaitEvent(staging)");
-      current_->consumer = stream;  // close_batch() records when its kernels are through
-    }
   }
 
   // Blocks until every committed batch has been copied (before the context's stream changes).
   void drain() {
-    close_batch();
     for (Slot& slot : slots_) {
       if (slot.pending) {
         wait_event(slot.done, "hipEventQuery(staging)");
         slot.pending = false;
-      }
-      if (slot.consumed_pending) {
-        wait_event(slot.consumed, "hipEventQuery(staging)");
-        slot.consumed_pending = false;
       }
     }
   }
@@ -224,11 +186,7 @@ class StagingRing {
     hipEvent_t done = nullptr;      // the copy has run: the pinned block may be refilled
     bool pending = false;
     std::vector<char> shadow;       // what the device twin holds (host copy of the last batch copied)
-    hipEvent_t consumed = nullptr;  // separate upload stream: the kernels reading the twin are through
-    bool consumed_pending = false;
-    hipStream_t consumer = nullptr;
   };
-  hipStream_t upload_stream_ = nullptr;
   bool lean_ = false;
   Slot slots_[kSlots];
   Slot* current_ = nullptr;
@@ -481,10 +439,6 @@ namespace avr {
 void* context_stream(avr_context* ctx) {
   bind_device(ctx);
   return ctx->stream;
-}
-void context_set_upload_stream(avr_context* ctx, void* stream) {
-  ctx->staging.drain();
-  ctx->staging.set_upload_stream(static_cast<hipStream_t>(stream));
 }
 void context_set_lean_descriptors(avr_context* ctx, bool lean) { ctx->staging.set_lean(lean); }
 }  // namespace avr

@@ -361,8 +361,6 @@ bool visibility_order(avr_visibility_graph* graph, const avr_camera& camera, flo
 void set_error(const std::string& message);
 // The context's HIP stream (hipStream_t; created on first use) with its device made current.
 void* context_stream(avr_context* ctx);
-// Descriptor copies of this context run on `stream` (hipStream_t; nullptr = on its own stream).
-void context_set_upload_stream(avr_context* ctx, void* stream);
 // The context's owner bounds the frames in flight itself: a descriptor batch that repeats then
 // leaves no packet at all on the stream (by default its event is still recorded, which is what
 // keeps the host a few batches ahead of the GPU at most).

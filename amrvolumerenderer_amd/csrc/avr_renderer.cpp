@@ -115,7 +115,6 @@ struct avr_renderer {
   avr_context* march = nullptr;     // stream M (high priority)
   avr_context* compose = nullptr;   // stream X (high priority)
   avr_context* classify = nullptr;  // stream C (default priority)
-  hipStream_t upload = nullptr;     // stream U: descriptor copies of the classify pass and the march
   avr_context* pair_b = nullptr;    // stream B of the paired layout (the odd frames'; high priority)
   avr_scene* scene = nullptr;
   avr_visibility_graph* visibility = nullptr;
@@ -192,12 +191,6 @@ struct avr_renderer {
       if (ctx != nullptr) (void)avr_context_synchronize(ctx);
     }
     clear_timing();
-    if (upload != nullptr) {
-      for (avr_context* ctx : {classify, march}) {
-        if (ctx != nullptr) avr::context_set_upload_stream(ctx, nullptr);
-      }
-      (void)hipStreamDestroy(upload);
-    }
     for (hipEvent_t ev : {window_begin, window_end}) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
     }
@@ -318,29 +311,6 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     abi_ok(avr_context_create_with_priority(device_id, 1, &r->march));
     abi_ok(avr_context_create_with_priority(device_id, 1, &r->compose));
     abi_ok(avr_context_create_with_priority(device_id, 0, &r->classify));
-    // Experiment hook (tried and dropped): AVR_UPLOAD_STREAM=1 / 2 copies the per-frame
-    // descriptors of the two paint kernels on a stream of their own (default / highest priority
-    // class) instead of on the consumers' streams.  The copies then run long before the kernels,
-    // but the march still starts 27 us after the one before it (the stream's event packets, not
-    // the 5 us copy, are the gap), and the extra stream can push the classify stream onto a
-    // hardware queue it shares: rank of eight 0.192 -> 0.192 ms (=1), 0.245 ms (=2).
-    const char* upload_env = std::getenv("AVR_UPLOAD_STREAM");
-    const int upload_mode = upload_env != nullptr ? std::atoi(upload_env) : 0;
-    if (upload_mode != 0) {
-      hip_ok(hipSetDevice(device_id), "hipSetDevice");
-      // (the three frame streams first: HIP deals hardware queues in creation / first-use order)
-      for (avr_context* ctx : {r->classify, r->march, r->compose}) (void)avr::context_stream(ctx);
-      if (upload_mode == 2) {
-        int least = 0, greatest = 0;
-        hip_ok(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-        hip_ok(hipStreamCreateWithPriority(&r->upload, hipStreamNonBlocking, greatest),
-               "hipStreamCreate(upload)");
-      } else {
-        hip_ok(hipStreamCreateWithFlags(&r->upload, hipStreamNonBlocking), "hipStreamCreate(upload)");
-      }
-      avr::context_set_upload_stream(r->classify, r->upload);
-      avr::context_set_upload_stream(r->march, r->upload);
-    }
     if (const char* pattern = std::getenv("AVR_CLASSIFY_CU_MASK")) {  // experiment: see DESIGN.md
       abi_ok(avr_context_set_cu_mask_pattern(r->classify,
                                              static_cast<uint32_t>(std::strtoul(pattern, nullptr, 0))));

@@ -320,7 +320,10 @@ def test_corun_tuning_never_changes_results(O, ctx):
     _, want = run(0, 0, 3)
     # (2: the paired layout -- every frame's two kernels on one stream, the frames alternating
     # between two streams; with the reserve fixed, then searched; with host-side back-pressure)
-    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 2400), (4096, -1, 400), (8192, 2, 13),
+    # (frame counts: a window of this scene's 0.1 ms frames is 40 frames after 40 let pass, the
+    # finalists' windows 80: a whole search is 26 x 80 + 3 x 120 = 2440 frames, back to back against
+    # one fixed reserve 2 x 80 + 2 x 120 = 400)
+    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 3200), (4096, -1, 800), (8192, 2, 13),
                                    (-1, 2, 600)):
         renderer, got = run(share, overlap, frames)
         state = renderer.native.corun_state()
