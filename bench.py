@@ -451,16 +451,28 @@ def main():
         epoch = torch.cuda.Event(enable_timing=True)
         epoch.record(renderer.march_ctx.stream)
     torch.cuda.synchronize()
+    t0 = time.monotonic()
     if world > 1:
+        # The ranks leave a gloo barrier a few hundred microseconds apart, which is a tenth of
+        # the 3 ms a rank of eight times over 20 frames: after the barrier they agree on ONE start
+        # instant (CLOCK_MONOTONIC is the same clock in every process of the node) and every rank
+        # measures from it -- a rank that hears of it late starts late and is counted late.
         dist.barrier()
-    t0 = time.perf_counter()
+        start = torch.tensor([time.monotonic() + 3e-4], dtype=torch.float64)
+        dist.broadcast(start, src=0, group=group)
+        t0 = float(start.item())
+        while time.monotonic() < t0:
+            pass
     for i in range(args.steps):
         step(i, timed=True)
     renderer.synchronize()
     torch.cuda.synchronize()
+    # this rank's K frames are complete (every frame is a collective, so they are complete on every
+    # rank within an exchange of each other); the closing barrier's own latency is not frame time:
+    # the maximum over the ranks, below, is what makes the figure the slowest rank's
+    elapsed = time.monotonic() - t0
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
 
     t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
