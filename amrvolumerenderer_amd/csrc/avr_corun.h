@@ -24,7 +24,7 @@
 // reserve of 0, 4, 8 ... KiB, paired with a reserve of 0, 8, 16 ... KiB -- each for a window of
 // frames whose period is timed with two HIP events on the march stream; the driver refines around
 // the best, re-times back to back against it, holds the winner, re-times it now and then and
-// searches again if it has drifted.  Scheduling only: never changes results.
+// searches again if it has drifted (two slow windows in a row).  Scheduling only: never changes results.
 struct CoRunTuner {
   static constexpr int kBackToBack = -1;       // candidate: both kernels on the march stream
   static constexpr int kReserveStep = 2048;    // candidate k >= 0: side by side, reserve k * step
@@ -64,6 +64,7 @@ struct CoRunTuner {
   static constexpr float kPairedMargin = 1.02f;
   int verify[3] = {0, 0, 0}, n_verify = 0, verify_at = 0;  // kVerify: candidates re-timed in turn
   int refined = 0, repeated = 0;
+  bool drift_suspected = false;  // kHold: the last window read slow
   long windows = 0;
   // the window in progress
   int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
@@ -104,6 +105,7 @@ struct CoRunTuner {
     layout_best_ms[0] = layout_best_ms[1] = layout_second_ms[0] = layout_second_ms[1] = 0.0f;
     n_verify = verify_at = 0;
     refined = 0;
+    drift_suspected = false;
     interrupt();
   }
   void interrupt() {  // the pipeline drained or the candidate changed: the window is void
@@ -168,8 +170,18 @@ struct CoRunTuner {
     repeated = 0;
     if (phase == kHold) {
       if (period_ms > best_ms * kDrift) {
-        restart();
+        // one slow window (a hiccup of the exchange, another process on the node) is not a
+        // drift: the candidate is timed once more right away, and only a second slow window
+        // starts a new search (whose ~30 candidates include much slower ones)
+        if (drift_suspected) {
+          restart();
+        } else {
+          drift_suspected = true;
+          interrupt();
+          frames_at_candidate = kHoldFrames - std::max(kSettleFrames, frames_per_window());
+        }
       } else {
+        drift_suspected = false;
         best_ms = 0.75f * best_ms + 0.25f * period_ms;
         interrupt();
       }
