@@ -227,6 +227,7 @@ SIGNATURES = {
     "avr_renderer_reference_sample_distance": (C.c_int, [_vp, _fp]),
     "avr_renderer_render": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip, _vp,
                                        _vp, C.c_int, _vp, _vp]),
+    "avr_renderer_prepare": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip]),
     "avr_renderer_synchronize": (C.c_int, [_vp]),
     "avr_renderer_stream": (_vp, [_vp, C.c_int]),
     "avr_renderer_plan_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),

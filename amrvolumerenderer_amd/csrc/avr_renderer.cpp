@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -150,8 +151,13 @@ struct avr_renderer {
   uint64_t plan_clock = 0;
   avr_frame_plan* plan = nullptr;  // of the last frame (owned by `plans`)
   bool have_plan = false;
+  // avr_renderer_prepare may make a plan on another thread while a frame is being queued:
+  // `plans_mutex` guards the cache (and `plan`, which eviction spares), `making_mutex` lets one
+  // plan be made at a time (the visibility graph keeps state between calls).
+  std::mutex plans_mutex, making_mutex;
 
   void forget_plans() {
+    std::lock_guard<std::mutex> lock(plans_mutex);
     for (CachedPlan& entry : plans) avr_frame_plan_destroy(entry.plan);
     plans.clear();
     plan = nullptr;
@@ -268,6 +274,108 @@ hipEvent_t make_event(bool timing) {
   hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : avr::ordering_event_flags()),
          "hipEventCreate");
   return event;
+}
+
+// The frame plan of (render parameters, camera, group order): from the cache, or made now --
+// visibility order, layer plan, and for N > 1 the tightened exchange layout: host geometry only.
+// `use`: the caller renders with it (it becomes the renderer's current plan); otherwise it is only
+// put into the cache (avr_renderer_prepare, possibly on another thread than the frames').
+const avr_frame_plan* plan_for(avr_renderer* r, const avr_render_params& render,
+                               const avr_camera& camera, const int32_t* group_order, bool use) {
+  const int root = validate(render);
+  const int width = render.width, height = render.height;
+  PlanKey key;
+  key.render = render;
+  key.camera = camera;
+  if (group_order != nullptr) key.group.assign(group_order, group_order + r->n_ranks);
+  auto lookup = [&]() -> avr_frame_plan* {  // plans_mutex held
+    if (render.write_visibility_graph) return nullptr;
+    for (avr_renderer::CachedPlan& entry : r->plans) {
+      if (entry.key == key) {
+        entry.last_used = ++r->plan_clock;
+        if (use) {
+          r->plan = entry.plan;
+          r->have_plan = true;
+        }
+        return entry.plan;
+      }
+    }
+    return nullptr;
+  };
+  {
+    std::lock_guard<std::mutex> lock(r->plans_mutex);
+    if (avr_frame_plan* found = lookup()) return found;
+  }
+  std::lock_guard<std::mutex> making(r->making_mutex);
+  {  // (the other thread may have made it meanwhile)
+    std::lock_guard<std::mutex> lock(r->plans_mutex);
+    if (avr_frame_plan* found = lookup()) return found;
+  }
+  std::vector<int32_t> order;
+  const int32_t* group = group_order;
+  if (group == nullptr && r->visibility != nullptr) {
+    order.resize(static_cast<size_t>(r->n_ranks));
+    // aspect as VolumeRenderer.cpp:1114 computes it (float division of the image size)
+    const float aspect = static_cast<float>(width) / static_cast<float>(std::max(height, 1));
+    int succeeded = 1;
+    abi_ok(avr_visibility_order(r->visibility, &camera, aspect, render.use_visibility_graph,
+                                (render.write_visibility_graph && r->rank == 0)
+                                    ? "visibility_graph_"
+                                    : nullptr,
+                                order.data(), &succeeded, nullptr));
+    group = order.data();
+  }
+  avr_paint_params params{};
+  params.width = width * root;
+  params.height = height * root;
+  params.scalar_range[0] = r->scalar_range[0];
+  params.scalar_range[1] = r->scalar_range[1];
+  params.box_transparency = render.box_transparency;
+  params.reference_sample_distance = r->reference_sample_distance;
+  std::copy(r->bounds_min, r->bounds_min + 3, params.bounds_min);
+  std::copy(r->bounds_max, r->bounds_max + 3, params.bounds_max);
+  params.colormap = r->colormap.empty() ? nullptr : r->colormap.data();
+  params.colormap_count = static_cast<int32_t>(r->colormap.size());
+  avr_frame_plan* fresh = nullptr;
+  abi_ok(avr_frame_plan_create_pieces(r->all_boxes.data(), r->owner.data(),
+                                      static_cast<int>(r->all_boxes.size()), r->n_ranks, r->rank,
+                                      group, &params, &camera, r->piece_layout, r->band_rows,
+                                      &fresh));
+  if (r->n_ranks > 1 && r->tighten_exchange) {
+    // The exchange layout is tightened to the runs' per-row extents when the plan is made
+    // (25-50 % fewer bytes on the links from a camera's FIRST frame on; tens of microseconds
+    // of host geometry, avr_plan.cpp).  The decision depends on nothing but the renderer's
+    // settings, so every rank of the frame takes it alike.
+    const int status = avr_frame_plan_tighten(fresh, r->all_boxes.data(),
+                                              static_cast<int>(r->all_boxes.size()));
+    if (status != AVR_OK) {
+      avr_frame_plan_destroy(fresh);
+      abi_ok(status);
+    }
+  }
+  std::lock_guard<std::mutex> lock(r->plans_mutex);
+  if (r->plans.size() >= avr_renderer::kCachedPlans) {
+    // the least recently used one goes -- but never the current frame's (a frame being queued on
+    // another thread reads it; otherwise a plan is host data only: every launch copied what it
+    // reads into its own descriptors)
+    size_t oldest = r->plans.size();
+    for (size_t i = 0; i < r->plans.size(); ++i) {
+      if (r->plans[i].plan == r->plan && r->have_plan) continue;
+      if (oldest == r->plans.size() || r->plans[i].last_used < r->plans[oldest].last_used) {
+        oldest = i;
+      }
+    }
+    if (oldest != r->plans.size()) {
+      avr_frame_plan_destroy(r->plans[oldest].plan);
+      r->plans.erase(r->plans.begin() + static_cast<std::ptrdiff_t>(oldest));
+    }
+  }
+  r->plans.push_back(avr_renderer::CachedPlan{key, fresh, ++r->plan_clock});
+  if (use) {
+    r->plan = fresh;
+    r->have_plan = true;
+  }
+  return fresh;
 }
 
 }  // namespace
@@ -550,6 +658,15 @@ int avr_renderer_timings(avr_renderer* r, double* classify_ms, double* march_ms,
   });
 }
 
+int avr_renderer_prepare(avr_renderer* r, const avr_render_params* render, const avr_camera* camera,
+                         const int32_t* group_order) {
+  return guarded([&]() -> int {
+    require(r != nullptr && render != nullptr && camera != nullptr, "null argument");
+    (void)plan_for(r, *render, *camera, group_order, /*use=*/false);
+    return AVR_OK;
+  });
+}
+
 int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const avr_camera* camera,
                         const int32_t* group_order, void* input_stream, uint64_t* samples_out,
                         int want_image, uint8_t* rgb8_out, float* image_out) {
@@ -562,7 +679,6 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     require(!is_root || !want_image || image_out != nullptr,
             "want_image needs an image output buffer on the root rank");
     const int width = render->width, height = render->height;
-    const int render_w = width * root, render_h = height * root;
 
     using Clock = std::chrono::steady_clock;
     auto mark = Clock::now();
@@ -571,75 +687,9 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       r->host_seconds[section] += std::chrono::duration<double>(now - mark).count();
       mark = now;
     };
-    // ---- host plan (re-used while camera and parameters repeat) --------------------------------
-    PlanKey key;
-    key.render = *render;
-    key.camera = *camera;
-    if (group_order != nullptr) key.group.assign(group_order, group_order + r->n_ranks);
-    avr_renderer::CachedPlan* cached = nullptr;
-    if (!render->write_visibility_graph) {
-      for (avr_renderer::CachedPlan& entry : r->plans) {
-        if (entry.key == key) cached = &entry;
-      }
-    }
-    if (cached == nullptr) {
-      std::vector<int32_t> order;
-      const int32_t* group = group_order;
-      if (group == nullptr && r->visibility != nullptr) {
-        order.resize(static_cast<size_t>(r->n_ranks));
-        // aspect as VolumeRenderer.cpp:1114 computes it (float division of the image size)
-        const float aspect = static_cast<float>(width) / static_cast<float>(std::max(height, 1));
-        int succeeded = 1;
-        abi_ok(avr_visibility_order(r->visibility, camera, aspect, render->use_visibility_graph,
-                                    (render->write_visibility_graph && is_root) ? "visibility_graph_"
-                                                                                 : nullptr,
-                                    order.data(), &succeeded, nullptr));
-        group = order.data();
-      }
-      avr_paint_params params{};
-      params.width = render_w;
-      params.height = render_h;
-      params.scalar_range[0] = r->scalar_range[0];
-      params.scalar_range[1] = r->scalar_range[1];
-      params.box_transparency = render->box_transparency;
-      params.reference_sample_distance = r->reference_sample_distance;
-      std::copy(r->bounds_min, r->bounds_min + 3, params.bounds_min);
-      std::copy(r->bounds_max, r->bounds_max + 3, params.bounds_max);
-      params.colormap = r->colormap.empty() ? nullptr : r->colormap.data();
-      params.colormap_count = static_cast<int32_t>(r->colormap.size());
-      avr_frame_plan* fresh = nullptr;
-      abi_ok(avr_frame_plan_create_pieces(r->all_boxes.data(), r->owner.data(),
-                                          static_cast<int>(r->all_boxes.size()), r->n_ranks, r->rank,
-                                          group, &params, camera, r->piece_layout, r->band_rows,
-                                          &fresh));
-      if (r->n_ranks > 1 && r->tighten_exchange) {
-        // The exchange layout is tightened to the runs' per-row extents when the plan is made
-        // (25-50 % fewer bytes on the links from a camera's FIRST frame on; tens of microseconds
-        // of host geometry, avr_plan.cpp).  The decision depends on nothing but the renderer's
-        // settings, so every rank of the frame takes it alike.
-        const int status = avr_frame_plan_tighten(fresh, r->all_boxes.data(),
-                                                  static_cast<int>(r->all_boxes.size()));
-        if (status != AVR_OK) {
-          avr_frame_plan_destroy(fresh);
-          abi_ok(status);
-        }
-      }
-      if (r->plans.size() >= avr_renderer::kCachedPlans) {  // the least recently used one goes
-        size_t oldest = 0;
-        for (size_t i = 1; i < r->plans.size(); ++i) {
-          if (r->plans[i].last_used < r->plans[oldest].last_used) oldest = i;
-        }
-        // (a plan is host data only: every launch copied what it reads into its own descriptors)
-        avr_frame_plan_destroy(r->plans[oldest].plan);
-        r->plans.erase(r->plans.begin() + static_cast<std::ptrdiff_t>(oldest));
-      }
-      r->plans.push_back(avr_renderer::CachedPlan{key, fresh, 0});
-      cached = &r->plans.back();
-    }
-    cached->last_used = ++r->plan_clock;
-    r->plan = cached->plan;
-    r->have_plan = true;
-    const avr_frame_plan* plan = r->plan;
+    // ---- host plan (re-used while camera and parameters repeat; avr_renderer_prepare may have
+    // made it ahead of time on another thread) ---------------------------------------------------
+    const avr_frame_plan* plan = plan_for(r, *render, *camera, group_order, /*use=*/true);
     const avr_frame_plan_info& info = plan->info;
     const int64_t piece_pixels = info.piece_end - info.piece_begin;
 

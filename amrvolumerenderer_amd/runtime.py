@@ -748,6 +748,23 @@ class NativeRenderer:
                                                      C.byref(b), C.byref(n)))
         return c.value, m.value, b.value, n.value
 
+    def prepare(self, width: int, height: int, box_transparency: float, antialiasing: int,
+                camera: CameraParameters, use_visibility_graph: bool = True,
+                draw_bounds: bool = True, write_visibility_graph: bool = False,
+                group_order: Optional[Sequence[int]] = None) -> None:
+        """avr_renderer_prepare: makes and keeps the frame plan render() will want for these
+        arguments -- host geometry only.  May run on another thread while render() queues a frame
+        (ctypes releases the GIL for the call): see PlanAhead."""
+        rp = _capi.RenderParams(int(width), int(height), float(box_transparency),
+                                int(antialiasing), int(bool(use_visibility_graph)),
+                                int(bool(draw_bounds)), int(bool(write_visibility_graph)))
+        ccam = camera.to_c()
+        group = None
+        if group_order is not None:
+            group = (C.c_int32 * self.n_ranks)(*[int(g) for g in group_order])
+        _capi.check(_capi.lib().avr_renderer_prepare(self._handle, C.byref(rp), C.byref(ccam),
+                                                     group))
+
     def render(self, width: int, height: int, box_transparency: float, antialiasing: int,
                camera: CameraParameters, use_visibility_graph: bool = True,
                draw_bounds: bool = True, write_visibility_graph: bool = False,
@@ -793,3 +810,46 @@ class NativeRenderer:
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
             C.c_void_p(image.data_ptr()) if image is not None else None))
         return image, rgb8
+
+
+class PlanAhead:
+    """Plans the NEXT frame on a helper thread while the caller queues this one: for a camera
+    that never repeats the host's geometry of a new camera (visibility order, frame plan, tightened
+    exchange layout: ~0.1 ms for 176 boxes at N = 8) otherwise adds to every frame's queueing, and
+    a rank of eight has 0.15 ms per frame.  submit() the arguments of the render() call that will
+    follow the next one; render() finds the plan (or, if the helper is not through, waits for it
+    and goes on).  Results never depend on it."""
+
+    def __init__(self, native: "NativeRenderer"):
+        import queue
+        import threading
+        self._native = native
+        self._jobs = queue.SimpleQueue()
+        self._error = None
+        self._thread = threading.Thread(target=self._run, name="avr-plan-ahead", daemon=True)
+        self._thread.start()
+
+    def _run(self) -> None:
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            try:
+                self._native.prepare(*job[0], **job[1])
+            except Exception as error:  # noqa: BLE001 -- handed to the submitting thread
+                self._error = error
+
+    def submit(self, *args, **kwargs) -> None:
+        if self._error is not None:
+            error, self._error = self._error, None
+            raise error
+        self._jobs.put((args, kwargs))
+
+    def close(self) -> None:
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            error, self._error = self._error, None
+            raise error

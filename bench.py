@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="avr_renderer_set_overlap: -1 measured by the driver (default), 0 back to "
                          "back, 1 side by side, 2 paired (A/B only)")
+    ap.add_argument("--no-plan-ahead", action="store_true",
+                    help="--fly-through at N > 1: make every frame plan on the thread that queues "
+                         "the frames instead of one frame ahead on a helper thread")
     ap.add_argument("--no-self-check", action="store_true",
                     help="experiment builds only (tools/ab_*.sh variants that change results)")
     ap.add_argument("--check-collectives", action="store_true",
@@ -389,10 +392,28 @@ def main():
     if args.fly_through and renderer.native is not None:
         renderer.native.set_tighten(True)   # forgets the plans the sample counting left behind
 
+    # A scripted fly-through knows its next camera: for N > 1 the plan of frame f + 1 is made on a
+    # helper thread while frame f is queued (avr_renderer_prepare; at N = 1 a plan costs the host
+    # 15 us of a 1 ms frame and nobody needs it).  --no-plan-ahead: every plan on the frames' thread.
+    ahead = None
+    if (args.fly_through and world > 1 and renderer.native is not None
+            and not args.no_plan_ahead):
+        from amrvolumerenderer_amd.runtime import PlanAhead
+        ahead = PlanAhead(renderer.native)
+
+    def plan_next(camera):
+        ahead.submit(rparams.width, rparams.height, rparams.box_transparency,
+                     rparams.antialiasing, camera, rparams.use_visibility_graph,
+                     rparams.draw_bounds, rparams.write_visibility_graph)
+
     def step(i, timed=False):
         if args.fly_through and not timed:
             fly_view[0] += 1
+            if ahead is not None:
+                plan_next(scenes.orbit_camera(fly_view[0] + 1, FLY_VIEWS))
             return renderer.render(rparams, scenes.orbit_camera(fly_view[0], FLY_VIEWS))
+        if ahead is not None and i + 1 < len(cameras):
+            plan_next(cameras[i + 1])
         return renderer.render(rparams, cameras[i % len(cameras)])
 
     # Untimed setup (optional): pick the march occupancy cap for this workload
@@ -473,6 +494,9 @@ def main():
     elapsed = time.monotonic() - t0
     if world > 1:
         dist.barrier()
+    planned_ahead = ahead is not None
+    if ahead is not None:
+        ahead.close()
 
     t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:
@@ -583,7 +607,10 @@ def main():
                                   (round(sum(frame_samples) / len(frame_samples))
                                    if args.fly_through else frame_samples)),
             "camera": ("fly-through: every frame a camera the driver has never seen (0.1 degree "
-                       "of orbit per frame; plan cache useless)" if args.fly_through else
+                       "of orbit per frame; plan cache useless"
+                       + ("; each frame's plan made one frame ahead on a helper thread, "
+                          "avr_renderer_prepare)" if planned_ahead else ")")
+                       if args.fly_through else
                        f"orbit of {len(cameras)} views (plans cached)" if args.orbit else
                        "static (the frame plan is made once)"),
             # frames rendered before the W warm-up steps, all untimed: the sample count of every

@@ -573,6 +573,16 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
 int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
                         const avr_camera *camera, const int32_t *group_order, void *input_stream,
                         uint64_t *samples_out, int want_image, uint8_t *rgb8_out, float *image_out);
+/* Plans a frame ahead of time: makes the frame plan of (render, camera, group_order) -- visibility
+ * order (VolumeRenderer.cpp:1235-1241), global layer order and exchange layout
+ * (DirectSendBase.cpp:400-446), for N > 1 tightened to the runs' per-row extents -- and keeps it
+ * with the renderer's plans, where avr_renderer_render finds it.  Host geometry only (0.1 ms for
+ * 176 boxes at N = 8, which is most of what a rank's 0.15 ms frame leaves the host): a caller whose
+ * camera never repeats (a scripted fly-through) calls it for frame f + 1 on ANOTHER thread while
+ * frame f is being queued.  Safe beside avr_renderer_render / avr_renderer_synchronize of the same
+ * renderer; not beside its setters.  Calling it is never required and never changes results. */
+int avr_renderer_prepare(avr_renderer *renderer, const avr_render_params *render,
+                         const avr_camera *camera, const int32_t *group_order);
 int avr_renderer_synchronize(avr_renderer *renderer);
 /* which: 0 classify, 1 march, 2 exchange / fold / gather / tail (hipStream_t as void*). */
 void *avr_renderer_stream(avr_renderer *renderer, int which);

@@ -671,6 +671,13 @@ class FrameDriver {
     check(avr_renderer_render(renderer_, &params, &camera, group_order, nullptr, samples_out,
                               want_image ? 1 : 0, rgb8_out, image_out));
   }
+  // Plans a frame ahead of time (host geometry only; avr_renderer_prepare): for a camera path
+  // that never repeats, call it for frame f + 1 on another thread -- std::async -- while frame f
+  // is being queued by render().
+  void prepare(const avr_render_params& params, const avr_camera& camera,
+               const int32_t* group_order = nullptr) {
+    check(avr_renderer_prepare(renderer_, &params, &camera, group_order));
+  }
   void synchronize() { check(avr_renderer_synchronize(renderer_)); }
 
  private:

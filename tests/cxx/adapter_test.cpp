@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -345,10 +346,19 @@ int main(int argc, char** argv) {
             avr_camera elsewhere = camera;
             elsewhere.eye[0] = camera.eye[0] - 0.9f;
             elsewhere.eye[1] = camera.eye[1] + 0.4f;
+            auto away = [&](int frame) { return (frame % 3 == 1) && frame + 1 < frames; };
             for (int frame = 0; frame < frames; ++frame) {
-              const bool away = (frame % 3 == 1) && frame + 1 < frames;
-              driver.render(render, away ? elsewhere : camera, r == 0 ? bytes.data() : nullptr, true,
-                            r == 0 ? image.data() : nullptr);
+              // the next frame's plan is made on another thread while this frame is queued
+              // (avr_renderer_prepare): it must be the plan render() would have made itself
+              std::future<void> planned;
+              if (frame + 1 < frames) {
+                const avr_camera next = away(frame + 1) ? elsewhere : camera;
+                planned = std::async(std::launch::async,
+                                     [&driver, &render, next] { driver.prepare(render, next); });
+              }
+              driver.render(render, away(frame) ? elsewhere : camera,
+                            r == 0 ? bytes.data() : nullptr, true, r == 0 ? image.data() : nullptr);
+              if (planned.valid()) planned.get();
             }
             driver.synchronize();
           } catch (const std::exception& e) {

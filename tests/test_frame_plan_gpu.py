@@ -367,6 +367,65 @@ def test_corun_tuning_never_changes_results(O, ctx):
                      "timed_windows": 0}
 
 
+def test_plans_made_ahead_on_another_thread_change_nothing(ctx):
+    """avr_renderer_prepare / runtime.PlanAhead: the frame plans of a camera path made one (and
+    several) frames ahead on a helper thread, while the frames are queued -- more cameras than the
+    driver keeps plans (32), so plans are evicted under the frames' feet.  One rank: every frame
+    equals the one a renderer planning on its own thread delivers.  A rank of four (played alone:
+    its frames hold nothing defined, its plans do): every frame's plan, tightened exchange layout
+    included, is the one made without the helper."""
+    from amrvolumerenderer_amd.renderer import build_scene_on_device
+    cams = [scenes.orbit_camera(v, 90) for v in range(90)]
+    args = (160, 120, 0.9, 1)
+    kw = dict(use_visibility_graph=True, draw_bounds=False)
+
+    def frames(n_ranks, lookahead):
+        spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+        scenes.assign_owners(spec, n_ranks, "level_pairs")
+        all_boxes, local = build_scene_on_device(ctx, spec, 0)
+        merged, mine = [], iter(local)
+        for b in all_boxes:
+            merged.append(next(mine) if b.owner == 0 else b)
+        r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, 0,
+                                   n_ranks, runtime.Comm.solo(0, n_ranks) if n_ranks > 1 else None)
+        ahead = runtime.PlanAhead(r) if lookahead else None
+        out, plans = [], []
+        for i, cam in enumerate(cams):
+            if ahead is not None:   # the first frame asks for the next `lookahead`, later ones for one more
+                for j in ([i + lookahead] if i else range(1, lookahead + 1)):
+                    if j < len(cams):
+                        ahead.submit(*args, cams[j], **kw)
+            out.append(r.render(*args, cam, want_image=True, **kw))
+            info = r.plan_info()
+            plans.append((info.n_runs_total, info.n_local_runs, info.send_floats, info.recv_floats,
+                          info.piece_begin, info.piece_end))
+        if ahead is not None:
+            ahead.close()
+        r.synchronize()
+        torch.cuda.synchronize()
+        out = [(img.clone(), rgb.clone()) for img, rgb in out]
+        # preparing what is already there, and on the frames' own thread, is fine too
+        r.prepare(*args, cams[-1], **kw)
+        r.prepare(*args, cams[0], **kw)
+        with pytest.raises(Exception):
+            r.prepare(0, 120, 0.9, 1, cams[0], **kw)
+        r.close()
+        return out, plans
+
+    want, want_plans = frames(1, 0)
+    assert len({p for p in want_plans}) >= 1 and bool((want[0][0][..., 3] > 0).any())
+    for lookahead in (1, 3):
+        got, got_plans = frames(1, lookahead)
+        assert got_plans == want_plans
+        for f, ((img, rgb), (w_img, w_rgb)) in enumerate(zip(got, want)):
+            assert torch.equal(img.view(torch.int32), w_img.view(torch.int32)), (lookahead, f)
+            assert torch.equal(rgb, w_rgb), (lookahead, f)
+    _, want_plans = frames(4, 0)
+    assert len(set(want_plans)) > 10 and all(p[2] > 0 for p in want_plans)
+    for lookahead in (1, 3):
+        assert frames(4, lookahead)[1] == want_plans, lookahead
+
+
 def _simulated_frame(O, ctx, spec, cam, W, H, transparency, n_ranks, tighten, cells=None, bands=0):
     """The N-rank frame with the ranks played one after the other on this GPU: per rank its frame
     plan (tightened or not), classify + march into the send buffer, the all-to-all by hand, the

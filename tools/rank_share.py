@@ -57,6 +57,8 @@ ap.add_argument("--fly-through", action="store_true",
                 help="every frame a camera the driver has never seen (0.1 degree of orbit per "
                      "frame): visibility order, frame plan, tightened exchange layout and per-box "
                      "prologue are made per frame")
+ap.add_argument("--no-plan-ahead", action="store_true",
+                help="--fly-through: make every plan on the frames' own thread")
 ap.add_argument("--overlap", type=int, default=-1, help="avr_renderer_set_overlap")
 ap.add_argument("--classify-share", type=int, default=-1, help="avr_renderer_set_classify_share")
 ap.add_argument("--worker", type=int, nargs=2, metavar=("N_RANKS", "RANK"), default=None,
@@ -121,13 +123,27 @@ def measure_share(n_ranks, rank):
     samples = int(counter.item())
     # clocks and allocator pools settle, and the driver finishes measuring how the rank's two
     # kernels share the GPU (bounded at 3 s)
+    # a scripted fly-through knows its next camera: its plan is made one frame ahead on a helper
+    # thread (avr_renderer_prepare) unless --no-plan-ahead -- also while the driver's search runs
+    # (with the host as the limit every candidate would read the same)
+    ahead = None
+    if args.fly_through and n_ranks > 1 and not args.no_plan_ahead:
+        ahead = runtime.PlanAhead(r)
+    upcoming = [next_cam()]
+
+    def frame():
+        this_cam, upcoming[0] = upcoming[0], next_cam()
+        if ahead is not None:
+            ahead.submit(args.size, args.size, args.transparency, 1, upcoming[0], **kw)
+        r.render(args.size, args.size, args.transparency, 1, this_cam, **kw)
+
     begin = time.perf_counter()
     warm = 0
     while True:
         elapsed = time.perf_counter() - begin
         if warm >= 30 and elapsed >= 0.5 and (elapsed >= 3.0 or r.corun_state()["settled"]):
             break
-        r.render(args.size, args.size, args.transparency, 1, next_cam(), **kw)
+        frame()
         warm += 1
     r.synchronize()
     torch.cuda.synchronize()
@@ -135,8 +151,10 @@ def measure_share(n_ranks, rank):
     r.host_profile(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.frames):
-        r.render(args.size, args.size, args.transparency, 1, next_cam(), **kw)
+        frame()
     host = (time.perf_counter() - t0) / args.frames
+    if ahead is not None:
+        ahead.close()
     r.synchronize()
     torch.cuda.synchronize()
     share = (time.perf_counter() - t0) / args.frames
