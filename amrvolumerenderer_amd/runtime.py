@@ -662,6 +662,13 @@ class NativeRenderer:
                                                   device=self.device) for w in range(3)]
 
     def close(self) -> None:
+        helper = getattr(self, "_plan_ahead", None)
+        if helper is not None:   # no plan may be in the making when the renderer goes
+            self._plan_ahead = None
+            try:
+                helper.close()
+            except Exception:  # noqa: BLE001 -- its error belongs to whoever submitted the job
+                pass
         if getattr(self, "_handle", None):
             _capi.lib().avr_renderer_destroy(self._handle)
             self._handle = None
@@ -824,6 +831,7 @@ class PlanAhead:
         import queue
         import threading
         self._native = native
+        native._plan_ahead = self   # NativeRenderer.close() closes the helper first
         self._jobs = queue.SimpleQueue()
         self._error = None
         self._thread = threading.Thread(target=self._run, name="avr-plan-ahead", daemon=True)
@@ -850,6 +858,8 @@ class PlanAhead:
             self._jobs.put(None)
             self._thread.join()
             self._thread = None
+            if getattr(self._native, "_plan_ahead", None) is self:
+                self._native._plan_ahead = None
         if self._error is not None:
             error, self._error = self._error, None
             raise error

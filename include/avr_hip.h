@@ -580,7 +580,8 @@ int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
  * 176 boxes at N = 8, which is most of what a rank's 0.15 ms frame leaves the host): a caller whose
  * camera never repeats (a scripted fly-through) calls it for frame f + 1 on ANOTHER thread while
  * frame f is being queued.  Safe beside avr_renderer_render / avr_renderer_synchronize of the same
- * renderer; not beside its setters.  Calling it is never required and never changes results. */
+ * renderer; not beside its setters or avr_renderer_destroy.  Calling it is never required and never
+ * changes results. */
 int avr_renderer_prepare(avr_renderer *renderer, const avr_render_params *render,
                          const avr_camera *camera, const int32_t *group_order);
 int avr_renderer_synchronize(avr_renderer *renderer);
