@@ -167,3 +167,34 @@ def test_tightened_plans_agree_between_ranks(avr_lib, n_ranks, policy):
                         plans[0].send_block(0, 0)
     finally:
         scenes.assign_owners(spec, 1, "morton")
+
+
+def test_plans_made_on_several_threads_equal_the_serial_ones(avr_lib):
+    """avr_frame_plan_create / avr_frame_plan_tighten keep their scratch per thread: plans made
+    concurrently on four threads (what avr_renderer_prepare relies on beside a frame's own
+    planning) have the layout of the plans made one after the other."""
+    from concurrent.futures import ThreadPoolExecutor
+    spec = scenes.make_amr_scene(32, 3, 8, "smooth")
+    n_ranks = 4
+    scenes.assign_owners(spec, n_ranks, "level_pairs")
+    meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+    params = make_params(640, 480, spec.scalar_range, 0.8, 0.02, spec.bounds)
+    jobs = [(scenes.orbit_camera(v, 48), v % n_ranks) for v in range(48)]
+
+    def layout(job):
+        cam, rank = job
+        plan = FramePlan(meta, params, cam, rank, n_ranks, piece_layout=1, band_rows=8)
+        plan.tighten()
+        out = (plan.n_runs_total, plan.n_local_runs, plan.send_floats, plan.recv_floats,
+               tuple(plan.send_splits), tuple(plan.recv_splits), tuple(plan.group_order))
+        plan.close()
+        return out
+
+    try:
+        serial = [layout(job) for job in jobs]
+        assert len(set(serial)) > 24 and all(entry[2] > 0 for entry in serial)
+        for _ in range(3):
+            with ThreadPoolExecutor(max_workers=4) as pool:
+                assert list(pool.map(layout, jobs)) == serial
+    finally:
+        scenes.assign_owners(spec, 1, "morton")
