@@ -202,6 +202,7 @@ SIGNATURES = {
     "avr_comm_create": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "avr_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "avr_comm_create_solo": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "avr_comm_create_solo_rccl": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "avr_comm_destroy": (None, [_vp]),
     "avr_comm_rank": (C.c_int, [_vp]),
     "avr_comm_size": (C.c_int, [_vp]),

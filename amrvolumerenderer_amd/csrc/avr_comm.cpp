@@ -179,6 +179,7 @@ struct avr_comm {
   std::shared_ptr<avr::LocalWorld> local;         // in-process flavour
   std::unique_ptr<avr::SharedWorld> shared;       // cross-process flavour (one GPU, shared memory)
   bool solo = false;                              // one rank of N played alone (timing studies)
+  int solo_percent = 100;                         // ... share of every peer's block it moves through RCCL
 };
 
 namespace {
@@ -277,6 +278,26 @@ int avr_comm_create_solo(int rank, int n_ranks, avr_comm** out_comm) {
   });
 }
 
+int avr_comm_create_solo_rccl(int device_id, int rank, int n_ranks, int percent, avr_comm** out_comm) {
+  return guarded([&]() -> int {
+    require(out_comm != nullptr && n_ranks >= 1 && rank >= 0 && rank < n_ranks && percent >= 1 &&
+                percent <= 100, "invalid argument");
+    *out_comm = nullptr;
+    avr::hip_ok(hipSetDevice(device_id), "hipSetDevice");
+    ncclUniqueId unique;
+    avr::nccl_ok(avr::rccl().get_unique_id(&unique), "ncclGetUniqueId");
+    auto comm = std::make_unique<avr_comm>();
+    comm->rank = rank;
+    comm->n_ranks = n_ranks;
+    comm->device = device_id;
+    comm->solo = true;
+    comm->solo_percent = percent;
+    avr::nccl_ok(avr::rccl().comm_init_rank(&comm->nccl, 1, unique, 0), "ncclCommInitRank");
+    *out_comm = comm.release();
+    return AVR_OK;
+  });
+}
+
 int avr_comm_create_shared(const char* name, int rank, int n_ranks, size_t capacity_bytes,
                            avr_comm** out_comm) {
   return guarded([&]() -> int {
@@ -349,6 +370,29 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
         avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(me)], send + send_at[static_cast<size_t>(me)],
                                    static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
                     "hipMemcpyAsync(exchange)");
+      }
+      if (comm->nccl != nullptr) {
+        // ... and the blocks for the peers go through RCCL to THIS rank (a one-rank communicator):
+        // the grouped send / receive round of the real frame -- its launch on the host, its
+        // kernel beside the paint kernels, its bytes through HBM -- with the links left out.
+        // Block s is sent and received with the smaller of its two sizes -- or the given share
+        // of it: on the real node the seven blocks travel over seven links at once, here one
+        // after the other over one connection (timing only: what lands in the receive buffer is
+        // this rank's own data).
+        const avr::Rccl& api = avr::rccl();
+        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        for (int s = 0; s < n; ++s) {
+          if (s == me) continue;
+          const int64_t count = std::min(plan->send_splits[static_cast<size_t>(s)],
+                                         plan->recv_splits[static_cast<size_t>(s)]) *
+                                comm->solo_percent / 100;
+          if (count <= 0) continue;
+          avr::nccl_ok(api.send(send + send_at[static_cast<size_t>(s)], static_cast<size_t>(count), ncclFloat, 0,
+                                comm->nccl, stream), "ncclSend");
+          avr::nccl_ok(api.recv(recv + recv_at[static_cast<size_t>(s)], static_cast<size_t>(count), ncclFloat, 0,
+                                comm->nccl, stream), "ncclRecv");
+        }
+        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
       }
       return AVR_OK;
     }
@@ -609,6 +653,35 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
         avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
                                    static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                    hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+      }
+      if (comm->nccl != nullptr && my_end > my_begin) {
+        // through RCCL to this rank itself (timing only, as avr_exchange): the root receives a
+        // piece from every other rank, the others send theirs
+        const avr::Rccl& api = avr::rccl();
+        const size_t bytes = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
+        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        if (me != root) {
+          // (no destination buffer off the root: the piece's first half lands on its second --
+          // the piece has been handed over by then, and a solo rank's pixels mean nothing)
+          const size_t half = bytes / 2;
+          if (half > 0) {
+            char* target = static_cast<char*>(const_cast<void*>(piece)) + half;
+            avr::nccl_ok(api.send(piece, half, ncclUint8, 0, comm->nccl, stream), "ncclSend");
+            avr::nccl_ok(api.recv(target, half, ncclUint8, 0, comm->nccl, stream), "ncclRecv");
+          }
+        } else {
+          for (int s = 0; s < n; ++s) {
+            if (s == me) continue;
+            int64_t b = 0, e = 0;
+            piece_range(s, &b, &e);
+            const size_t count = std::min(bytes, static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel));
+            if (count == 0) continue;
+            avr::nccl_ok(api.send(piece, count, ncclUint8, 0, comm->nccl, stream), "ncclSend");
+            avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, count, ncclUint8, 0, comm->nccl, stream),
+                         "ncclRecv");
+          }
+        }
+        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
       }
       return AVR_OK;
     }

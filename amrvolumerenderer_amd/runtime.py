@@ -587,6 +587,19 @@ class Comm:
         return self
 
     @classmethod
+    def solo_rccl(cls, device_index: int, rank: int, n_ranks: int, percent: int = 100) -> "Comm":
+        """avr_comm_create_solo_rccl: as solo(), the rank's collectives played through a one-rank
+        RCCL communicator to itself (timing studies: RCCL's kernels beside the paint kernels)."""
+        self = cls.__new__(cls)
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        handle = C.c_void_p()
+        _capi.check(_capi.lib().avr_comm_create_solo_rccl(int(device_index), self.rank,
+                                                          self.n_ranks, int(percent),
+                                                          C.byref(handle)))
+        self._handle = handle
+        return self
+
+    @classmethod
     def shared(cls, name: str, rank: int, n_ranks: int, capacity_bytes: int = 256 << 20) -> "Comm":
         """avr_comm_create_shared: rank processes sharing ONE GPU meet in a POSIX shared-memory
         segment (collective).  Rehearsal of the multi-process flow, not a performance path."""

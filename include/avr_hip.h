@@ -440,6 +440,15 @@ int avr_comm_create_local(int n_ranks, avr_comm **out_comms /* [n_ranks] */);
  * tools/rank_share.py): only the block a rank keeps for itself moves, the peers' blocks of the
  * receive buffer keep whatever they held.  Frames rendered this way are not images. */
 int avr_comm_create_solo(int rank, int n_ranks, avr_comm **out_comm);
+/* The same, with the rank's collectives played through RCCL to ITSELF (a one-rank communicator
+ * made here): avr_exchange sends and receives every peer's block -- the smaller of its two sizes
+ * -- as one grouped ncclSend / ncclRecv round, avr_gather likewise.  What a one-GPU box can show
+ * of the real round: its launch on the host, its kernel beside the paint kernels, its bytes
+ * through HBM; not the links.  percent (1..100): the share of every peer's block avr_exchange
+ * moves -- on the node the N - 1 blocks travel over N - 1 links at once, here one after the other
+ * over one connection, so 100 overstates how long the round's kernel runs.  Timing only. */
+int avr_comm_create_solo_rccl(int device_id, int rank, int n_ranks, int percent,
+                              avr_comm **out_comm);
 /* Rehearsal of the N-rank frame across PROCESSES that share one GPU (RCCL refuses two ranks on
  * one device): the ranks meet in the POSIX shared-memory segment `name` ("/something"; whoever
  * comes first creates it, rank 0 removes the name when it is destroyed), capacity_bytes of staging

@@ -57,6 +57,11 @@ ap.add_argument("--fly-through", action="store_true",
                 help="every frame a camera the driver has never seen (0.1 degree of orbit per "
                      "frame): visibility order, frame plan, tightened exchange layout and per-box "
                      "prologue are made per frame")
+ap.add_argument("--through-rccl", type=int, default=0, metavar="PERCENT",
+                help="play every rank's exchange and gather through a one-rank RCCL communicator "
+                     "to the rank itself instead of moving only its own block: this share of "
+                     "every peer's block (100 = all of it, one block after the other over ONE "
+                     "connection where the node has N - 1 links)")
 ap.add_argument("--no-plan-ahead", action="store_true",
                 help="--fly-through: make every plan on the frames' own thread")
 ap.add_argument("--overlap", type=int, default=-1, help="avr_renderer_set_overlap")
@@ -99,7 +104,12 @@ def measure_share(n_ranks, rank):
                                        C.c_void_p(b.data_ptr())))
         ctx.synchronize()
         L.avr_frame_plan_destroy(plan1)
-    comm = runtime.Comm.solo(rank, n_ranks) if n_ranks > 1 else None
+    comm = None
+    if n_ranks > 1:
+        # --through-rccl: the rank's exchange and gather go through a one-rank RCCL communicator to
+        # the rank itself (RCCL's launch, kernel and bytes beside the paint kernels; not the links)
+        comm = (runtime.Comm.solo_rccl(0, rank, n_ranks, args.through_rccl) if args.through_rccl
+                else runtime.Comm.solo(rank, n_ranks))
     r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, rank,
                                n_ranks, comm)
     r.set_options(args.march_occupancy, False)
@@ -222,6 +232,7 @@ def child(extra):
 print(f"{args.config}, {args.size}^2, ownership {args.ownership}, "
       f"{'contiguous pieces' if args.contiguous_pieces else 'row-band pieces'}, "
       f"{'no RCCL in the share processes' if args.no_rccl else 'live one-rank RCCL communicator in every share process'}"
+      f"{f', EXCHANGE ({args.through_rccl} % of every block) AND GATHER THROUGH RCCL (to the rank itself)' if args.through_rccl else ''}"
       f"{', FLY-THROUGH (a new camera every frame)' if args.fly_through else ''}",
       flush=True)
 summary = []
