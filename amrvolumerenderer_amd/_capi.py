@@ -164,6 +164,7 @@ SIGNATURES = {
     "avr_classify_plan": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_fold_plan_own": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "avr_visibility_graph_create": (C.c_int, [C.POINTER(Box), C.POINTER(C.c_int32), C.c_int,
                                                C.c_int, C.POINTER(_vp)]),
     "avr_visibility_graph_destroy": (None, [_vp]),
@@ -207,6 +208,7 @@ SIGNATURES = {
     "avr_comm_rank": (C.c_int, [_vp]),
     "avr_comm_size": (C.c_int, [_vp]),
     "avr_exchange": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_exchange_peers": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_gather": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "avr_renderer_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(Box), _ip,
                                        C.c_int, C.POINTER(ScalarTransform), C.POINTER(C.c_double),

@@ -925,6 +925,11 @@ int avr_march_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_pla
 
 int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
                   float* out_piece, uint8_t* out_rgb8) {
+  return avr_fold_plan_own(ctx, plan, recv_buffer, nullptr, out_piece, out_rgb8);
+}
+
+int avr_fold_plan_own(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
+                      const float* own_send_buffer, float* out_piece, uint8_t* out_rgb8) {
   return guarded([&]() -> int {
     bind_device(ctx);
     require(plan != nullptr, "null argument");
@@ -953,6 +958,26 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
     launch.recv = recv_buffer;
     launch.out_piece = out_piece;
     launch.out_rgb8 = out_rgb8;
+    if (own_send_buffer != nullptr) {
+      // the rank's block for itself: where the receive layout has it and where the march put it
+      const int me = plan->info.rank;
+      int64_t send_at = 0, recv_at = 0;
+      for (int s = 0; s < me; ++s) {
+        send_at += plan->send_splits[static_cast<size_t>(s)];
+        recv_at += plan->recv_splits[static_cast<size_t>(s)];
+      }
+      const int64_t own = plan->recv_splits[static_cast<size_t>(me)];
+      if (plan->send_splits[static_cast<size_t>(me)] != own) {
+        throw std::runtime_error(
+            "frame plan: a rank's block for itself differs between send and receive layout");
+      }
+      launch.own_begin = recv_at;
+      launch.own_end = recv_at + own;
+      // (two allocations: the distance is taken between addresses, not between pointers)
+      launch.own_delta = (reinterpret_cast<intptr_t>(own_send_buffer + send_at) -
+                          reinterpret_cast<intptr_t>(recv_buffer + recv_at)) /
+                         static_cast<intptr_t>(sizeof(float));
+    }
     return avr::launch_fold_plan(launch, ctx->stream);
   });
 }

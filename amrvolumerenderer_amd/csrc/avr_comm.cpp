@@ -348,8 +348,28 @@ void avr_comm_destroy(avr_comm* comm) {
 int avr_comm_rank(const avr_comm* comm) { return comm ? comm->rank : -1; }
 int avr_comm_size(const avr_comm* comm) { return comm ? comm->n_ranks : -1; }
 
+namespace {
+int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
+             float* recv, bool move_own);
+}
+
 int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
                  float* recv) {
+  return exchange(ctx, plan, comm, send, recv, /*move_own=*/true);
+}
+
+int avr_exchange_peers(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm,
+                       const float* send, float* recv) {
+  return exchange(ctx, plan, comm, send, recv, /*move_own=*/false);
+}
+
+}  // extern "C"
+
+namespace {
+// move_own: whether the rank's block for itself is copied from the send to the receive buffer
+// (avr_fold_plan_own reads it where it is)
+int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
+             float* recv, bool move_own) {
   return guarded([&]() -> int {
     check_plan(comm, plan);
     hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
@@ -366,7 +386,7 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
     }
     if (comm->solo) {  // only the block the rank keeps for itself moves
       const int64_t own = plan->send_splits[static_cast<size_t>(me)];
-      if (own > 0) {
+      if (own > 0 && move_own) {
         avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(me)], send + send_at[static_cast<size_t>(me)],
                                    static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
                     "hipMemcpyAsync(exchange)");
@@ -425,7 +445,7 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
           if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
             throw std::runtime_error("exchange: the ranks' frame plans disagree on a block size");
           }
-          if (bytes == 0) continue;
+          if (bytes == 0 || (s == me && !move_own)) continue;
           avr::hip_ok(hipMemcpy(recv + recv_at[static_cast<size_t>(s)],
                                 world.region(s) + world.header()->offsets[s][me],
                                 static_cast<size_t>(bytes), hipMemcpyHostToDevice),
@@ -459,7 +479,7 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
           if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
             throw std::runtime_error("exchange: the ranks' frame plans disagree on a block size");
           }
-          if (bytes == 0) continue;
+          if (bytes == 0 || (s == me && !move_own)) continue;
           avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(s)],
                                      world.base[static_cast<size_t>(s)] +
                                          world.offsets[static_cast<size_t>(s)][static_cast<size_t>(me)],
@@ -480,7 +500,7 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
     if (n == 1) {
       // a one-rank communicator only exists to exercise this path where a single GPU is all
       // there is: the block for itself goes through ncclSend / ncclRecv like any other
-      if (own > 0) {
+      if (own > 0 && move_own) {
         avr::nccl_ok(api.group_start(), "ncclGroupStart");
         avr::nccl_ok(api.send(send, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclSend");
         avr::nccl_ok(api.recv(recv, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclRecv");
@@ -488,7 +508,7 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
       }
       return AVR_OK;
     }
-    if (own > 0) {
+    if (own > 0 && move_own) {
       avr::hip_ok(hipMemcpyAsync(recv + recv_at[static_cast<size_t>(me)], send + send_at[static_cast<size_t>(me)],
                                  static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
                   "hipMemcpyAsync(exchange)");
@@ -511,6 +531,9 @@ int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, c
     return AVR_OK;
   });
 }
+}  // namespace
+
+extern "C" {
 
 int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_order,
                         int64_t n_pixels, int bytes_per_pixel, const void* image, void* slices) {

@@ -282,6 +282,10 @@ struct FoldLaunch {
   const float* recv;
   float* out_piece;
   uint8_t* out_rgb8;                   // may be null
+  // Blocks whose offset in the receive layout lies in [own_begin, own_end) -- the rank's own runs
+  // -- are read own_delta floats away from there: from the send buffer the march stored them in
+  // (avr_fold_plan_own).  own_begin == own_end: everything from recv.
+  int64_t own_begin = 0, own_end = 0, own_delta = 0;
 };
 int launch_fold_plan(const FoldLaunch& launch, void* stream);
 int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,

@@ -1048,7 +1048,8 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
     const RunSpanDev* __restrict__ spans, const float* __restrict__ recv,
     float* __restrict__ out_piece,
     uint8_t* __restrict__ out_rgb8, const int first_row, const int chunks_per_row,
-    const PieceMapDev pieces, const int piece) {
+    const PieceMapDev pieces, const int piece, const int64_t own_begin, const int64_t own_end,
+    const int64_t own_delta) {
   __shared__ FoldEntry list[256];
   __shared__ int wave_count[4];
   const int tid = static_cast<int>(threadIdx.x);
@@ -1087,6 +1088,9 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
           entry.base = block.offset + (static_cast<int64_t>(block_row - block.first_row) *
                                            (rect.x1 - rect.x0 + 1) - rect.x0) * 5;
         }
+        // a block of the rank's own runs may still lie where the march stored it (FoldLaunch):
+        // the same floats, own_delta away from where the receive layout has them
+        if (block.offset >= own_begin && block.offset < own_end) entry.base += own_delta;
       }
     }
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(touches);
@@ -1374,7 +1378,8 @@ int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
                      static_cast<hipStream_t>(stream_v), L.width, L.piece_begin, L.piece_end,
                      L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, L.recv,
                      L.out_piece, L.out_rgb8,
-                     first_row, chunks_per_row, L.pieces, L.piece);
+                     first_row, chunks_per_row, L.pieces, L.piece, L.own_begin, L.own_end,
+                     L.own_delta);
   return check_launch("fold_plan_kernel");
 }
 

@@ -945,13 +945,19 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(2);
     // ---- stream X: exchange, fold, gather, frame tail ------------------------------------------
     hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[volume], 0), "hipStreamWaitEvent");
+    // (the rank's block for itself is not copied into the receive buffer: the fold reads it
+    // where the march stored it -- the send buffer lives until composed_event -- which is one
+    // kernel and one gap less on this stream, the busiest of a rank of eight's frame)
     const float* received = send;
+    const float* own = nullptr;
     if (many) {
-      abi_ok(avr_exchange(r->compose, plan, r->comm, send, recv));
+      abi_ok(avr_exchange_peers(r->compose, plan, r->comm, send, recv));
       received = recv;
+      own = send;
     }
     lap(3);
-    abi_ok(avr_fold_plan(r->compose, plan, received, piece, overlay_piece ? nullptr : piece_rgb8));
+    abi_ok(avr_fold_plan_own(r->compose, plan, received, own, piece,
+                             overlay_piece ? nullptr : piece_rgb8));
     if (overlay_piece && piece_pixels > 0) {
       abi_ok(avr_bbox_overlay_piece(r->compose, plan, r->tight_min, r->tight_max, camera, piece,
                                     piece_rgb8));

@@ -335,13 +335,19 @@ class Context:
         return out
 
     def fold_plan(self, plan, recv: torch.Tensor, want_rgb8: bool = False,
-                  sync_streams: bool = True, want_piece: bool = True):
+                  sync_streams: bool = True, want_piece: bool = True,
+                  own_send: Optional[torch.Tensor] = None):
         """avr_fold_plan: receiver-side fold of this rank's piece.  Returns
         (piece [piece_len, 5] or None, rgb8 [piece_len, 3] or None).  sync_streams=False: the
-        caller already runs on this context's stream."""
+        caller already runs on this context's stream.  own_send (avr_fold_plan_own): the rank's
+        send buffer, from which the blocks of its own runs are read instead of from recv."""
         if not (want_piece or want_rgb8):
             raise ValueError("nothing to produce")
         self._check_tensor(recv, torch.float32, "recv")
+        if own_send is not None:
+            self._check_tensor(own_send, torch.float32, "own_send")
+            if own_send.numel() < plan.send_floats:
+                raise ValueError("send buffer is too small")
         if recv.numel() < plan.recv_floats:
             raise ValueError("receive buffer is too small")
         n = plan.piece_end - plan.piece_begin
@@ -349,8 +355,9 @@ class Context:
         rgb8 = self.empty(max(n, 0), 3, dtype=torch.uint8) if want_rgb8 else None
         if sync_streams:
             self.join()
-        _capi.check(_capi.lib().avr_fold_plan(
+        _capi.check(_capi.lib().avr_fold_plan_own(
             self._handle, plan._handle, C.c_void_p(recv.data_ptr()),
+            C.c_void_p(own_send.data_ptr()) if own_send is not None else None,
             C.c_void_p(piece.data_ptr()) if piece is not None else None,
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None))
         if sync_streams:

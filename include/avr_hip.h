@@ -369,6 +369,13 @@ int avr_march_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_pla
  * may then be NULL when only the bytes are wanted (20 of the 23 bytes stored per pixel). */
 int avr_fold_plan(avr_context *ctx, const avr_frame_plan *plan, const float *recv_buffer,
                   float *out_piece, uint8_t *out_rgb8);
+/* The same fold with the blocks of the rank's OWN runs read where the march stored them -- in
+ * own_send_buffer, the rank's send buffer (its block for itself has the same layout there as in
+ * the receive buffer) -- instead of from recv_buffer: with avr_exchange_peers a rank's data for
+ * itself is never copied (one kernel and one gap less on the compositing stream of every frame,
+ * which at N = 8 has five kernels to run in 0.15 ms).  own_send_buffer NULL: avr_fold_plan. */
+int avr_fold_plan_own(avr_context *ctx, const avr_frame_plan *plan, const float *recv_buffer,
+                      const float *own_send_buffer, float *out_piece, uint8_t *out_rgb8);
 
 /* ---- image algebra ----------------------------------------------------------------------- */
 
@@ -469,6 +476,11 @@ int avr_comm_size(const avr_comm *comm);
  * context's stream. */
 int avr_exchange(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm, const float *send,
                  float *recv);
+/* avr_exchange without the copy of the rank's block for itself: recv holds the peers' blocks
+ * only, the rank's own stay in send (avr_fold_plan_own reads them there; send must then live until
+ * that fold has run). */
+int avr_exchange_peers(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm,
+                       const float *send, float *recv);
 /* Classic direct send of ONE image per rank -- DirectSendBase::compose(localImage, sendGroup,
  * recvGroup, comm) for a plain (not layered) image, DirectSend/Base/DirectSendBase.cpp:76-177,
  * 257-281: every rank's image (n_pixels * bytes_per_pixel bytes, device) is cut into the n pieces of

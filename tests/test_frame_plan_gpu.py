@@ -68,6 +68,21 @@ def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency, scene
         ctx.synchronize()
         got[plan.piece_begin:plan.piece_end] = piece.cpu().numpy()
         got8[plan.piece_begin:plan.piece_end] = rgb8.cpu().numpy()
+        # avr_fold_plan_own: the rank's block for itself read from its send buffer instead (the
+        # receive buffer holds poison there, as after avr_exchange_peers)
+        poisoned = np.array(recv, dtype=np.float32, copy=True)
+        begin = sum(plan.recv_splits[:plan.rank])
+        poisoned[begin:begin + plan.recv_splits[plan.rank]] = np.nan
+        dev2 = torch.from_numpy(np.ascontiguousarray(poisoned)).to(ctx.device)
+        own = torch.from_numpy(np.ascontiguousarray(sends[plan.rank])).to(ctx.device)
+        if dev2.numel() == 0:
+            dev2 = torch.zeros(1, device=ctx.device)
+        if own.numel() == 0:
+            own = torch.zeros(1, device=ctx.device)
+        piece2, rgb82 = ctx.fold_plan(plan, dev2, want_rgb8=True, own_send=own)
+        ctx.synchronize()
+        assert torch.equal(piece2.view(torch.int32), piece.view(torch.int32)), plan.rank
+        assert torch.equal(rgb82, rgb8), plan.rank
     assert_bit_equal(got, want, f"{n_ranks} ranks {policy}")
     assert np.array_equal(got8, O.quantize_rgb8(want, W, H)[::-1].reshape(-1, 3))
 
