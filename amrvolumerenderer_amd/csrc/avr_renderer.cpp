@@ -271,6 +271,7 @@ int validate(const avr_render_params& p) {
 
 hipEvent_t make_event(bool timing) {
   hipEvent_t event = nullptr;
+  // (hipEventReleaseToDevice on the timing events was measured and changes nothing)
   hip_ok(hipEventCreateWithFlags(&event, timing ? hipEventDefault : avr::ordering_event_flags()),
          "hipEventCreate");
   return event;

@@ -269,6 +269,24 @@ int main() {
     expect(even, "paired windows have an even number of frames");
     expect(doubled, "the finalists are timed over double windows");
   }
+  {  // the safe side of the cliff: a finalist with a smaller reserve within 0.5 % of the best is
+     // held instead (26 KiB read 0.997 in its window and runs 1.05; 24 KiB reads 1.000)
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    auto model = [](int c) {
+      if (c == 13) return 0.997f;
+      return one_rank(c);
+    };
+    const Run run = play(t, model, 4000);
+    expect(t.settled() && run.candidate == 12,
+           "the smaller of two reserves within 0.5 % is held, got " + std::to_string(run.candidate));
+    // ... but not a reserve that is really slower
+    CoRunTuner u;
+    u.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    const Run other = play(u, [](int c) { return c == 13 ? 0.97f : one_rank(c); }, 4000);
+    expect(u.settled() && other.candidate == 13,
+           "a reserve that is 3 % faster is held, got " + std::to_string(other.candidate));
+  }
   if (failures == 0) std::printf("ok\n");
   return failures == 0 ? 0 : 1;
 }
