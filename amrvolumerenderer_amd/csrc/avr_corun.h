@@ -41,7 +41,10 @@ struct CoRunTuner {
                                                // 0.2 ms frames of an N = 8 share need ~40 for a
                                                // period good to a per cent, 1 ms frames 8
   static constexpr int kHoldFrames = 360;      // frames between re-timings of the held candidate
-  static constexpr float kDrift = 1.10f;       // held candidate this much slower: search again
+  static constexpr float kDrift = 1.05f;       // held candidate this much slower, twice in a row:
+                                               // search again (the reserve one step past the best
+                                               // one is 6 % slower: a window that flattered it once
+                                               // must not keep the driver there)
 
   // kSearch: (back to back, then) reserves 0, 4, 8 ... KiB; kRefine: the two reserves either
   // side of the best one; kVerify: back to back and the best reserve once more; kHold: the
@@ -63,8 +66,6 @@ struct CoRunTuner {
   // gone on with if it wins by more than that.
   static constexpr float kPairedMargin = 1.02f;
   int verify[3] = {0, 0, 0}, n_verify = 0, verify_at = 0;  // kVerify: candidates re-timed in turn
-  float verify_ms[3] = {0.0f, 0.0f, 0.0f};                 // ... and what their windows read
-  static constexpr float kSafeSide = 1.005f;  // a smaller reserve this close to the best is preferred
   int refined = 0, repeated = 0;
   bool drift_suspected = false;  // kHold: the last window read slow
   long windows = 0;
@@ -272,30 +273,11 @@ struct CoRunTuner {
         }
       }
     } else if (phase == kVerify) {
-      verify_ms[verify_at] = period_ms;
       if (++verify_at < n_verify) {
         candidate = verify[verify_at];
       } else {
         phase = kHold;
         candidate = best;  // of the re-timed windows (best_ms was reset before them)
-        // Behind the best reserve lies a cliff (one step more and the classify pass is the
-        // bottleneck: config-4 0.985 -> 1.05-1.10 ms), before it a gentle slope (1.00-1.01): a
-        // finalist of the same layout with a SMALLER reserve that read within 0.5 % of the best
-        // is held instead -- a window that flatters the reserve on the cliff's edge must not
-        // decide (seen: 26 KiB held at 1.05 ms where 24 KiB runs 0.98).
-        for (int i = 0; i < n_verify; ++i) {
-          const int c = verify[i];
-          if (c < 0 || candidate < 0 || is_paired(c) != is_paired(candidate)) continue;
-          if (reserve_index(c) < reserve_index(candidate) && verify_ms[i] <= best_ms * kSafeSide) {
-            candidate = c;
-          }
-        }
-        if (candidate != best) {
-          for (int i = 0; i < n_verify; ++i) {
-            if (verify[i] == candidate) best_ms = verify_ms[i];
-          }
-          best = candidate;
-        }
       }
     }
     interrupt();

@@ -286,6 +286,7 @@ struct FoldLaunch {
   // -- are read own_delta floats away from there: from the send buffer the march stored them in
   // (avr_fold_plan_own).  own_begin == own_end: everything from recv.
   int64_t own_begin = 0, own_end = 0, own_delta = 0;
+  int max_workgroups = 0;              // grid cap (0: the default, 2048)
 };
 int launch_fold_plan(const FoldLaunch& launch, void* stream);
 int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,

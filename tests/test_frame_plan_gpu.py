@@ -354,7 +354,7 @@ def test_corun_tuning_never_changes_results(O, ctx):
             assert state["timed_windows"] >= 4
         elif share < 0:
             # (a whole search is 29 windows; the 0.1 ms frames of this small scene are noisy enough
-            # for the held candidate to read 10 % off now and then, which starts a new search)
+            # for the held candidate to read 5 % off twice now and then, which starts a new search)
             assert state["timed_windows"] >= 4
             assert state["settled"] or state["timed_windows"] > 29
             assert 0 <= state["lds_reserve_bytes"] <= 57344
