@@ -242,6 +242,7 @@ struct avr_context {
   uint32_t cu_mask_pattern = 0;                // non-zero: own stream restricted to these CUs
   int march_workgroups_per_cu = 0;             // 0 = uncapped
   uint32_t classify_lds_pad = 0;               // avr_context_set_classify_lds_reserve
+  bool classify_stream_stores = false;         // context_set_classify_stream_stores
   uint64_t* march_counters = nullptr;          // diagnostics (avr_context_set_march_counters)
 };
 
@@ -326,6 +327,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   launch.n_boxes = n_boxes;
   launch.n_classify_tiles = plan.classify_tile_begin.back();
   launch.classify_lds_pad = ctx->classify_lds_pad;
+  launch.classify_stream_stores = ctx->classify_stream_stores ? 1 : 0;
   launch.classified = scene->classified_slot(slot, plan.classified_bytes, ctx->stream);
 
   if ((phases & kClassify) && scene->cache_classification) {
@@ -439,6 +441,9 @@ namespace avr {
 void* context_stream(avr_context* ctx) {
   bind_device(ctx);
   return ctx->stream;
+}
+void context_set_classify_stream_stores(avr_context* ctx, bool stream) {
+  ctx->classify_stream_stores = stream;
 }
 void context_set_lean_descriptors(avr_context* ctx, bool lean) { ctx->staging.set_lean(lean); }
 }  // namespace avr

@@ -253,6 +253,8 @@ struct RenderLaunch {
   uint32_t n_classify_tiles;
   uint32_t classify_lds_pad;  // bytes of LDS each classify workgroup claims beyond its own
                               // (0 = none): caps its occupancy beside the march
+  int classify_stream_stores;  // the classified bricklets are written through to memory as a
+                               // stream (their reader is a frame away) instead of left in L2
   const MarchItemDev* items_dev;  // n_items entries (multiple of kXcds)
   uint32_t n_items;
   int only_mode;                        // the IndexMode shared by every box, or -1
@@ -370,6 +372,8 @@ void* context_stream(avr_context* ctx);
 // leaves no packet at all on the stream (by default its event is still recorded, which is what
 // keeps the host a few batches ahead of the GPU at most).
 void context_set_lean_descriptors(avr_context* ctx, bool lean);
+// Whether the context's classify passes stream their bricklets to memory (RenderLaunch).
+void context_set_classify_stream_stores(avr_context* ctx, bool stream);
 
 // Flags of the events that only ORDER work between this library's streams on ONE device (a
 // frame's classified volume -> its march -> its fold; the descriptor ring's slots): recorded

@@ -713,7 +713,8 @@ constexpr int kStreamingLoad = 2;
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
-    const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified) {
+    const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
+    const int stream_stores) {
   __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
 
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
@@ -848,7 +849,15 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     // kernel of every queue.  One box, fixed reserve: plain 0.9705 / 0.967 ms per frame, nt
     // 0.9686 / 0.9632, sc0 sc1 0.9638 / 0.9624, sc0 sc1 nt 0.9597 / 0.9584.  (The march's 20-byte
     // layer stores want the opposite: nt 0.973 against 0.967, sc0 sc1 nt 1.079.)
-    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(target), "v"(v) : "memory");
+    // -- when the march that reads them is a frame away (side by side: the next frame's classify
+    // pass runs beside this frame's march).  Where a frame's march follows its classify pass on
+    // the same stream (back to back, paired: the ranks of eight), the bricklets it gathers first
+    // are still in L2 if they were stored plainly: a rank of eight 0.143 ms plain, 0.149 streamed.
+    if (stream_stores != 0) {  // (wave-uniform)
+      asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(target), "v"(v) : "memory");
+    } else {
+      *target = v;
+    }
   }
 }
 
@@ -1271,10 +1280,12 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   const size_t pad = L.classify_lds_pad;  // occupancy cap beside the march (avr_renderer)
   if (simple) {
     hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
-                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
+                       L.classify_stream_stores);
   } else {
     hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
-                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified);
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
+                       L.classify_stream_stores);
   }
   return check_launch("classify_kernel");
 }

@@ -862,6 +862,13 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // (the first frame after a drain classifies alone: no march to leave room for)
     abi_ok(avr_context_set_classify_lds_reserve(classify_ctx,
                                                 (overlap && !r->pipeline_idle) ? reserve : 0));
+    // Side by side the march that reads this frame's bricklets starts a frame later: they are
+    // streamed to memory.  Back to back and paired it follows at once: they stay in L2.
+    {
+      static const char* forced = std::getenv("AVR_CLASSIFY_STREAM");  // A/B only
+      const bool stream = forced != nullptr ? std::atoi(forced) != 0 : (overlap && !paired);
+      avr::context_set_classify_stream_stores(classify_ctx, stream);
+    }
     r->last_overlap = overlap;
     r->last_paired = paired;
     r->last_reserve = reserve;
