@@ -241,14 +241,18 @@ struct CoRunTuner {
       }
     }
     if (phase == kRefine) {
-      // the neighbours of the best one inside its layout (the centre may move once)
+      // the neighbours of the best one inside its layout (the centre may move), and a second
+      // window for ITS neighbours of the coarse pass: one window of 8 frames is good to 1.5 %,
+      // and the true best reserve had lost to its neighbour by one unlucky window now and then
+      // (24 KiB read 1.010 once, 20 KiB was held: 1.002 ms against 0.993)
       int next = -1;
-      while (refined < 2 && next < 0) {
+      while (refined < 4 && next < 0) {
         const bool paired = is_paired(best_beside);
         const int step = paired ? kPairedCoarse / 2 : 1;
         const int lo = paired ? std::max(first, kPairedBase) : std::max(first, 0);
         const int hi = paired ? last : std::min(last, kLastCandidate);
-        const int probe = best_beside + (refined == 0 ? -step : step);
+        static constexpr int kOffsets[4] = {-1, 1, -2, 2};
+        const int probe = best_beside + kOffsets[refined] * step;
         ++refined;
         if (probe >= lo && probe <= hi && hi > lo) next = probe;
       }

@@ -850,7 +850,8 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     // 0.9686 / 0.9632, sc0 sc1 0.9638 / 0.9624, sc0 sc1 nt 0.9597 / 0.9584.  (The march's 20-byte
     // layer stores want the opposite: nt 0.973 against 0.967, sc0 sc1 nt 1.079.)
     // -- when the march that reads them is a frame away (side by side: the next frame's classify
-    // pass runs beside this frame's march).  Where a frame's march follows its classify pass on
+    // pass runs beside this frame's march) and the volume is more than the memory-side cache
+    // holds (avr_capi.cpp).  Where a frame's march follows its classify pass on
     // the same stream (back to back, paired: the ranks of eight), the bricklets it gathers first
     // are still in L2 if they were stored plainly: a rank of eight 0.143 ms plain, 0.149 streamed.
     if (stream_stores != 0) {  // (wave-uniform)

@@ -95,7 +95,7 @@ int main() {
     expect(run.candidate == 12 || run.candidate == 13, "one rank holds 24-26 KiB, got " +
                                                             std::to_string(run.candidate));
     // (20 windows of 8 timed frames, each after 8 frames of settling, + the event lag)
-    expect(run.frames < 400, "one rank settles within 400 frames, took " + std::to_string(run.frames));
+    expect(run.frames < 440, "one rank settles within 440 frames, took " + std::to_string(run.frames));
     int back_to_back = 0;
     for (int c : run.tried) back_to_back += (c == CoRunTuner::kBackToBack) ? 1 : 0;
     expect(run.tried.front() == 0 && back_to_back == 1 &&
@@ -149,7 +149,7 @@ int main() {
     CoRunTuner t;
     t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
     Run run = play(t, [](int c) { return 35.0f * one_rank(c); }, 5000);
-    expect(t.settled() && run.frames < 180, "35 ms frames settle within 180 frames, took " +
+    expect(t.settled() && run.frames < 200, "35 ms frames settle within 200 frames, took " +
                                                 std::to_string(run.frames));
     const int held = run.candidate;
     run = play(t, [](int c) { return 35.0f * one_rank(c); }, 2 * CoRunTuner::kHoldFrames + 40, 2, 0,
@@ -216,7 +216,7 @@ int main() {
     const Run run = play(t, model, 4000);
     expect(t.settled() && (run.candidate == 12 || run.candidate == 13),
            "one rank stays side by side at 24-26 KiB, got " + std::to_string(run.candidate));
-    expect(run.frames < 560, "one rank settles within 560 frames with the paired layout in the "
+    expect(run.frames < 600, "one rank settles within 600 frames with the paired layout in the "
                              "search, took " + std::to_string(run.frames));
   }
   {  // the caller asked for the paired layout only: its reserves alone are searched
@@ -285,6 +285,20 @@ int main() {
     expect(t.settled() && t.candidate != 13,
            "two slow windows in a row send the driver back to the search, holds " +
                std::to_string(t.candidate));
+  }
+  {  // one unlucky window must not eliminate the best reserve: 24 KiB reads 1.010 in the coarse
+     // pass (its neighbour 20 KiB 0.995), is timed again as a neighbour of the best, and wins
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    int calls_of_12 = 0;
+    auto model = [&calls_of_12](int c) {
+      if (c == 12) return (calls_of_12++ == 0) ? 1.010f : 0.985f;
+      if (c == 10) return 0.995f;
+      return one_rank(c) + 0.01f;
+    };
+    const Run run = play(t, model, 4000);
+    expect(t.settled() && run.candidate == 12,
+           "the best reserve survives one unlucky window, got " + std::to_string(run.candidate));
   }
   if (failures == 0) std::printf("ok\n");
   return failures == 0 ? 0 : 1;
