@@ -539,10 +539,11 @@ class HipDirectSend {
     float* send = send_.reserve(static_cast<std::size_t>(info.send_floats) + 1, &allocations_);
     float* recv = recv_.reserve(static_cast<std::size_t>(info.recv_floats) + 1, &allocations_);
     check(avr_pack_layers(context_.get(), plan, pointers.data(), local_count, send));
-    check(avr_exchange(context_.get(), plan, comm_->get(), send, recv));
+    // (the rank's block for itself is not copied: the fold reads it from the send buffer)
+    check(avr_exchange_peers(context_.get(), plan, comm_->get(), send, recv));
     const std::size_t piece_pixels = static_cast<std::size_t>(info.piece_end - info.piece_begin);
     float* piece = piece_.reserve(piece_pixels * 5 + 1, &allocations_);
-    check(avr_fold_plan(context_.get(), plan, recv, piece, nullptr));
+    check(avr_fold_plan_own(context_.get(), plan, recv, send, piece, nullptr));
     // the result image: this rank's pixel range, created like the reference's empty layer
     auto result = localImage->createEmptyLayer(static_cast<int>(info.piece_begin),
                                                static_cast<int>(info.piece_end));
