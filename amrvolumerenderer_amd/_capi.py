@@ -165,6 +165,7 @@ SIGNATURES = {
     "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_own": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "avr_fold_plan_image": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_visibility_graph_create": (C.c_int, [C.POINTER(Box), C.POINTER(C.c_int32), C.c_int,
                                                C.c_int, C.POINTER(_vp)]),
     "avr_visibility_graph_destroy": (None, [_vp]),

@@ -937,11 +937,29 @@ int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* rec
   return avr_fold_plan_own(ctx, plan, recv_buffer, nullptr, out_piece, out_rgb8);
 }
 
+namespace {
+int fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
+              const float* own_send_buffer, float* out_piece, uint8_t* out_rgb8, bool to_image);
+}
+
 int avr_fold_plan_own(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
                       const float* own_send_buffer, float* out_piece, uint8_t* out_rgb8) {
+  return fold_plan(ctx, plan, recv_buffer, own_send_buffer, out_piece, out_rgb8, false);
+}
+
+int avr_fold_plan_image(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
+                        float* out_piece, uint8_t* out_rgb8_image) {
+  return fold_plan(ctx, plan, recv_buffer, nullptr, out_piece, out_rgb8_image, true);
+}
+
+namespace {
+int fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
+              const float* own_send_buffer, float* out_piece, uint8_t* out_rgb8, bool to_image) {
   return guarded([&]() -> int {
     bind_device(ctx);
     require(plan != nullptr, "null argument");
+    require(!to_image || (plan->info.n_ranks == 1 && out_rgb8 != nullptr),
+            "avr_fold_plan_image is for one rank's whole image");
     // (a rank whose piece is empty -- more ranks than pixels, or row bands on a short image --
     // has nothing to fold and may pass empty buffers)
     if (plan->info.piece_end <= plan->info.piece_begin) return AVR_OK;
@@ -972,6 +990,7 @@ int avr_fold_plan_own(avr_context* ctx, const avr_frame_plan* plan, const float*
     // A rank of several folds its piece on the stream that also carries the exchange and the
     // gather, five kernels per frame: there it should be through quickly.
     launch.max_workgroups = plan->info.n_ranks == 1 ? 256 : 0;
+    launch.flip_height = to_image ? plan->params.height : 0;
     if (own_send_buffer != nullptr) {
       // the rank's block for itself: where the receive layout has it and where the march put it
       const int me = plan->info.rank;
@@ -995,6 +1014,7 @@ int avr_fold_plan_own(avr_context* ctx, const avr_frame_plan* plan, const float*
     return avr::launch_fold_plan(launch, ctx->stream);
   });
 }
+}  // namespace
 
 int avr_visibility_graph_create(const avr_box* all_boxes, const int32_t* owner, int n_boxes,
                                 int n_ranks, avr_visibility_graph** out_graph) {

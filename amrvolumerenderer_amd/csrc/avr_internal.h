@@ -289,6 +289,7 @@ struct FoldLaunch {
   // (avr_fold_plan_own).  own_begin == own_end: everything from recv.
   int64_t own_begin = 0, own_end = 0, own_delta = 0;
   int max_workgroups = 0;              // grid cap (0: the default, 2048)
+  int flip_height = 0;                 // > 0: out_rgb8 is the whole image, rows top-down (one rank)
 };
 int launch_fold_plan(const FoldLaunch& launch, void* stream);
 int launch_fold_runs(const float* const* slices_dev, int n_slices, float* out, int64_t n,

@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
     float* __restrict__ out_piece,
     uint8_t* __restrict__ out_rgb8, const int first_row, const int chunks_per_row,
     const PieceMapDev pieces, const int piece, const int64_t own_begin, const int64_t own_end,
-    const int64_t own_delta, const int n_segments) {
+    const int64_t own_delta, const int n_segments, const int flip_height) {
   __shared__ FoldEntry list[256];
   __shared__ int wave_count[4];
   const int tid = static_cast<int>(threadIdx.x);
@@ -1150,7 +1150,12 @@ __global__ __launch_bounds__(256) void fold_plan_kernel(
     d[4] = acc.d;
   }
   if (out_rgb8 != nullptr) {
-    uint8_t* b = out_rgb8 + q * 3;
+    // flip_height > 0 (one rank, the piece is the image): the bytes go straight to the output
+    // file's rows, top-down (SavePPM.cpp:25) -- avr_assemble_rows' flip in the same pass
+    const int64_t at = (flip_height > 0)
+                           ? static_cast<int64_t>(flip_height - 1 - row) * width + px
+                           : q;
+    uint8_t* b = out_rgb8 + at * 3;
     b[0] = static_cast<uint8_t>(component_as_byte(acc.r));
     b[1] = static_cast<uint8_t>(component_as_byte(acc.g));
     b[2] = static_cast<uint8_t>(component_as_byte(acc.b));
@@ -1412,7 +1417,7 @@ int launch_fold_plan(const FoldLaunch& L, void* stream_v) {
                      L.n_runs, L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, L.recv,
                      L.out_piece, L.out_rgb8,
                      first_row, chunks_per_row, L.pieces, L.piece, L.own_begin, L.own_end,
-                     L.own_delta, static_cast<int>(blocks));
+                     L.own_delta, static_cast<int>(blocks), L.flip_height);
   return check_launch("fold_plan_kernel");
 }
 

@@ -964,8 +964,14 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       own = send;
     }
     lap(3);
-    abi_ok(avr_fold_plan_own(r->compose, plan, received, own, piece,
-                             overlay_piece ? nullptr : piece_rgb8));
+    // (one rank without antialiasing or wireframe: the fold writes the output file's rows itself)
+    const bool fold_to_image = !many && early_rgb8 && !overlay_piece && is_root;
+    if (fold_to_image) {
+      abi_ok(avr_fold_plan_image(r->compose, plan, received, piece, rgb8_out));
+    } else {
+      abi_ok(avr_fold_plan_own(r->compose, plan, received, own, piece,
+                               overlay_piece ? nullptr : piece_rgb8));
+    }
     if (overlay_piece && piece_pixels > 0) {
       abi_ok(avr_bbox_overlay_piece(r->compose, plan, r->tight_min, r->tight_max, camera, piece,
                                     piece_rgb8));
@@ -980,7 +986,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         full = gathered_rgb8;
         abi_ok(avr_gather(r->compose, plan, r->comm, piece_rgb8, 3, full, 0));
       }
-      if (is_root) abi_ok(avr_assemble_rows(r->compose, plan, full, 3, 1, rgb8_out));
+      if (is_root && !fold_to_image) abi_ok(avr_assemble_rows(r->compose, plan, full, 3, 1, rgb8_out));
       if (gather_image) {
         if (many) {
           float* gathered = is_root ? (banded ? gathered_image : image_out) : nullptr;

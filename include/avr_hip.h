@@ -376,6 +376,11 @@ int avr_fold_plan(avr_context *ctx, const avr_frame_plan *plan, const float *rec
  * which at N = 8 has five kernels to run in 0.15 ms).  own_send_buffer NULL: avr_fold_plan. */
 int avr_fold_plan_own(avr_context *ctx, const avr_frame_plan *plan, const float *recv_buffer,
                       const float *own_send_buffer, float *out_piece, uint8_t *out_rgb8);
+/* One rank (the piece is the image): the fold with its bytes written as the output file's rows,
+ * top-down (SavePPM.cpp:25) -- avr_fold_plan + avr_assemble_rows(flip) in one pass over the
+ * pixels.  out_rgb8_image: width * height * 3 bytes; out_piece as avr_fold_plan (may be NULL). */
+int avr_fold_plan_image(avr_context *ctx, const avr_frame_plan *plan, const float *recv_buffer,
+                        float *out_piece, uint8_t *out_rgb8_image);
 
 /* ---- image algebra ----------------------------------------------------------------------- */
 
