@@ -364,6 +364,20 @@ class Context:
             self.publish()
         return piece, rgb8
 
+    def fold_plan_image(self, plan, recv: torch.Tensor) -> torch.Tensor:
+        """avr_fold_plan_image (one rank): the fold with its bytes written as the output file's
+        rows, top-down.  Returns rgb8 [height, width, 3]."""
+        self._check_tensor(recv, torch.float32, "recv")
+        if recv.numel() < plan.recv_floats:
+            raise ValueError("receive buffer is too small")
+        rgb8 = self.empty(plan.height, plan.width, 3, dtype=torch.uint8)
+        self.join()
+        _capi.check(_capi.lib().avr_fold_plan_image(self._handle, plan._handle,
+                                                    C.c_void_p(recv.data_ptr()), None,
+                                                    C.c_void_p(rgb8.data_ptr())))
+        self.publish()
+        return rgb8
+
     def downsample(self, src: torch.Tensor, target_w: int, target_h: int, block: int
                    ) -> torch.Tensor:
         self._check_tensor(src, torch.float32, "src")

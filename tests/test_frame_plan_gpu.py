@@ -85,6 +85,17 @@ def test_render_and_fold_plan(O, ctx, n_ranks, policy, size, transparency, scene
         assert torch.equal(rgb82, rgb8), plan.rank
     assert_bit_equal(got, want, f"{n_ranks} ranks {policy}")
     assert np.array_equal(got8, O.quantize_rgb8(want, W, H)[::-1].reshape(-1, 3))
+    if n_ranks == 1:
+        # avr_fold_plan_image: the same bytes as the output file's rows (top-down), in one pass;
+        # and it is for one rank only
+        dev = torch.from_numpy(np.ascontiguousarray(recvs[0])).to(ctx.device)
+        image8 = ctx.fold_plan_image(plans[0], dev)
+        ctx.synchronize()
+        assert np.array_equal(image8.cpu().numpy(), O.quantize_rgb8(want, W, H))
+    else:
+        with pytest.raises(Exception):
+            ctx.fold_plan_image(plans[0], torch.zeros(max(plans[0].recv_floats, 1),
+                                                     device=ctx.device))
 
 
 @pytest.mark.parametrize("antialiasing,draw_bounds", [(1, False), (4, False), (1, True), (4, True)])
