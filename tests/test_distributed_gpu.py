@@ -370,3 +370,43 @@ def test_bench_multi_rank_flow_on_one_gpu(n_ranks):
     assert line["config"]["self_checks"] == {"native_collectives_equal_torch_distributed": True}
     assert line["config"]["exchange"]["layout"].startswith("per-row extents")
     assert line["value"] > 0 and line["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("percent", [100, 25])
+def test_one_rank_of_four_played_through_rccl(percent):
+    """avr_comm_create_solo_rccl (timing studies, tools/rank_share.py --through-rccl): a rank of
+    four played alone with its grouped send / receive round and its gather going through a one-rank
+    RCCL communicator to the rank itself.  The frames are not images; they must run, pipelined, and
+    plan what the plain solo communicator plans."""
+    import torch
+    from amrvolumerenderer_amd import runtime, scenes
+    from amrvolumerenderer_amd.renderer import build_scene_on_device
+    ctx = runtime.Context(0)
+    n_ranks = 4
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    scenes.assign_owners(spec, n_ranks, "level_pairs")
+    cams = [scenes.orbit_camera(v, 12) for v in range(12)]
+    plans = {}
+    for rank, flavour in ((1, "solo"), (1, "rccl"), (0, "rccl")):
+        all_boxes, local = build_scene_on_device(ctx, spec, rank)
+        merged, mine = [], iter(local)
+        for b in all_boxes:
+            merged.append(next(mine) if b.owner == rank else b)
+        comm = (runtime.Comm.solo(rank, n_ranks) if flavour == "solo"
+                else runtime.Comm.solo_rccl(0, rank, n_ranks, percent))
+        r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, rank,
+                                   n_ranks, comm)
+        seen = []
+        for i in range(36):   # back to back
+            r.render(160, 120, 0.9, 1, cams[i % len(cams)], draw_bounds=False, want_image=(i % 5 == 0))
+            info = r.plan_info()
+            seen.append((info.send_floats, info.recv_floats, info.n_runs_total))
+        r.synchronize()
+        torch.cuda.synchronize()
+        plans[(rank, flavour)] = seen
+        r.close()
+    assert plans[(1, "solo")] == plans[(1, "rccl")]
+    assert all(s > 0 for s, _, _ in plans[(0, "rccl")])
+    with pytest.raises(Exception):
+        runtime.Comm.solo_rccl(0, 0, 4, 0)
