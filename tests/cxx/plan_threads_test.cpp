@@ -35,8 +35,11 @@ int main() {
   std::vector<int64_t> serial(48), threaded(48);
   auto job = [&](int v, int64_t* out) {
     avr_camera cam{};
-    cam.eye[0] = 0.5f + 2.0f * std::cos(0.13f * v); cam.eye[1] = 0.6f; cam.eye[2] = 0.5f + 2.0f * std::sin(0.13f * v);
-    cam.look_at[0] = cam.look_at[1] = cam.look_at[2] = 0.5f; cam.up[1] = 1.0f;
+    // (every third camera looks from INSIDE the volume: boxes behind the eye, corners that project
+    // far outside any integer range)
+    const float radius = (v % 3 == 2) ? 0.12f : 2.0f;
+    cam.eye[0] = 0.5f + radius * std::cos(0.13f * v); cam.eye[1] = 0.6f; cam.eye[2] = 0.5f + radius * std::sin(0.13f * v);
+    cam.look_at[0] = cam.look_at[1] = cam.look_at[2] = (v % 3 == 2) ? 0.9f : 0.5f; cam.up[1] = 1.0f;
     cam.fov_y_degrees = 45.0f; cam.near_plane = 0.1f; cam.far_plane = 100.0f;
     avr_frame_plan plan;
     avr::build_frame_plan(boxes.data(), owner.data(), n, 4, v % 4, nullptr, params, cam, 1, 8, &plan);
