@@ -17,5 +17,7 @@ def test_plans_made_concurrently_are_race_free():
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
     out = subprocess.run([os.path.join(CXX, "plan_threads_test")], capture_output=True, text=True,
                          timeout=300, env=env)
+    if "unexpected memory mapping" in (out.stderr or ""):   # ThreadSanitizer against this kernel's ASLR
+        pytest.skip("ThreadSanitizer cannot map its shadow memory here")
     assert out.returncode == 0, (out.stdout + out.stderr)[-4000:]
     assert out.stdout.startswith("ok"), out.stdout
