@@ -172,7 +172,8 @@ struct CoRunTuner {
     }
     repeated = 0;
     if (phase == kHold) {
-      if (period_ms > best_ms * kDrift) {
+      // (a rank of several shares its period with the other ranks' exchange: twice the margin)
+      if (period_ms > best_ms * (start_beside ? kDrift : 2.0f * kDrift - 1.0f)) {
         // one slow window (a hiccup of the exchange, another process on the node) is not a
         // drift: the candidate is timed once more right away, and only a second slow window
         // starts a new search (whose ~30 candidates include much slower ones)
