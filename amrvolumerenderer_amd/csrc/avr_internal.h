@@ -254,7 +254,7 @@ struct RenderLaunch {
   uint32_t classify_lds_pad;  // bytes of LDS each classify workgroup claims beyond its own
                               // (0 = none): caps its occupancy beside the march
   int classify_stream_stores;  // the classified bricklets are written through to memory as a
-                               // stream (their reader is a frame away) instead of left in L2
+                               // stream (their reader is a frame away) instead of stored plainly
   const MarchItemDev* items_dev;  // n_items entries (multiple of kXcds)
   uint32_t n_items;
   int only_mode;                        // the IndexMode shared by every box, or -1

@@ -853,7 +853,9 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     // pass runs beside this frame's march) and the volume is more than the memory-side cache
     // holds (avr_capi.cpp).  Where a frame's march follows its classify pass on
     // the same stream (back to back, paired: the ranks of eight), the bricklets it gathers first
-    // are still in L2 if they were stored plainly: a rank of eight 0.143 ms plain, 0.149 streamed.
+    // are still in the caches if they were stored plainly: a rank of eight 0.143 ms plain, 0.149
+    // streamed (the march's L2 hit rate is 63.4 % either way, tools/share_cache_pmc.sh: what helps
+    // sits below L2, in the memory-side cache, or is the write traffic itself).
     if (stream_stores != 0) {  // (wave-uniform)
       asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(target), "v"(v) : "memory");
     } else {

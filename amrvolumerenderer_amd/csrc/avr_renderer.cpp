@@ -863,7 +863,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     abi_ok(avr_context_set_classify_lds_reserve(classify_ctx,
                                                 (overlap && !r->pipeline_idle) ? reserve : 0));
     // Side by side the march that reads this frame's bricklets starts a frame later: they are
-    // streamed to memory.  Back to back and paired it follows at once: they stay in L2.
+    // streamed to memory.  Back to back and paired it follows at once: they are stored plainly
+    // (a rank of eight 0.143 against 0.149 ms).
     {
       static const char* forced = std::getenv("AVR_CLASSIFY_STREAM");  // A/B only
       const bool stream = forced != nullptr ? std::atoi(forced) != 0 : (overlap && !paired);
