@@ -127,6 +127,8 @@ struct LocalWorld {
 // then one data region per rank.  Blocks travel device -> the sender's region -> device.
 struct SharedHeader {
   static constexpr int kMaxRanks = 64;
+  static constexpr uint32_t kMagic = 0x41565253u;  // "AVRS": rank 0 has initialised the segment
+  std::atomic<uint32_t> magic;
   std::atomic<uint32_t> arrived;
   std::atomic<uint32_t> generation;
   int64_t offsets[kMaxRanks][kMaxRanks];  // [source][peer]: byte offset inside the source's region
@@ -313,22 +315,64 @@ int avr_comm_create_shared(const char* name, int rank, int n_ranks, size_t capac
     world->owner = rank == 0;
     const size_t head = (sizeof(avr::SharedHeader) + 4095) / 4096 * 4096;
     world->mapped_bytes = head + world->capacity * static_cast<size_t>(n_ranks);
-    // whoever comes first creates the segment; a new segment is all zeros (the barrier's state)
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) throw std::runtime_error(std::string("shm_open(") + name + ") failed");
-    if (ftruncate(fd, static_cast<off_t>(world->mapped_bytes)) != 0) {
-      (void)close(fd);
-      throw std::runtime_error("ftruncate of the shared segment failed");
+    // Rank 0 creates the segment afresh (a name left behind by a crashed job is removed first, and
+    // O_EXCL makes sure nobody else's is adopted), sizes it -- a new segment is all zeros: the
+    // barrier's state -- and publishes the magic word last; the others open WITHOUT creating,
+    // retrying until the name exists, has its size and carries the magic.  The name is removed
+    // right after the attach barrier below, so a rank that fails later leaks nothing in /dev/shm.
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    auto pause = [&](const char* what) {
+      if (std::chrono::steady_clock::now() > give_up) {
+        throw std::runtime_error(std::string("shared communicator: ") + what + " within 120 s");
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    };
+    int fd = -1;
+    if (rank == 0) {
+      (void)shm_unlink(name);
+      fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0) throw std::runtime_error(std::string("shm_open(") + name + ") failed");
+      if (ftruncate(fd, static_cast<off_t>(world->mapped_bytes)) != 0) {
+        (void)close(fd);
+        (void)shm_unlink(name);
+        throw std::runtime_error("ftruncate of the shared segment failed");
+      }
+    } else {
+      for (;;) {
+        fd = shm_open(name, O_RDWR, 0600);
+        if (fd >= 0) {
+          struct stat st {};
+          if (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) == world->mapped_bytes) break;
+          (void)close(fd);
+          fd = -1;
+        }
+        pause("rank 0 did not create the segment");
+      }
     }
     void* mapping = mmap(nullptr, world->mapped_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     (void)close(fd);
-    if (mapping == MAP_FAILED) throw std::runtime_error("mmap of the shared segment failed");
+    if (mapping == MAP_FAILED) {
+      if (rank == 0) (void)shm_unlink(name);
+      throw std::runtime_error("mmap of the shared segment failed");
+    }
     world->mapping = mapping;
     auto comm = std::make_unique<avr_comm>();
     comm->rank = rank;
     comm->n_ranks = n_ranks;
     comm->shared = std::move(world);
+    avr::SharedHeader* header = comm->shared->header();
+    if (rank == 0) {
+      header->magic.store(avr::SharedHeader::kMagic, std::memory_order_release);
+    } else {
+      while (header->magic.load(std::memory_order_acquire) != avr::SharedHeader::kMagic) {
+        pause("rank 0 did not initialise the segment");
+      }
+    }
     comm->shared->barrier();  // everybody is attached before anybody communicates
+    if (rank == 0) {          // ... and nobody needs the name any more
+      (void)shm_unlink(name);
+      comm->shared->owner = false;
+    }
     *out_comm = comm.release();
     return AVR_OK;
   });

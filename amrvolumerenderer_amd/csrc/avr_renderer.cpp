@@ -156,6 +156,16 @@ struct avr_renderer {
   // plan be made at a time (the visibility graph keeps state between calls).
   std::mutex plans_mutex, making_mutex;
 
+  // Changes what plans are made from (scalar range, exchange layout, piece layout): waits for a
+  // plan in the making on another thread (avr_renderer_prepare), so that no plan built from the
+  // old settings enters the cache after it was cleared.
+  template <typename Change>
+  void change_plan_inputs(Change&& change) {
+    std::lock_guard<std::mutex> making(making_mutex);
+    change();
+    forget_plans();
+  }
+
   void forget_plans() {
     std::lock_guard<std::mutex> lock(plans_mutex);
     for (CachedPlan& entry : plans) avr_frame_plan_destroy(entry.plan);
@@ -233,6 +243,7 @@ struct avr_renderer {
     for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
     if (pair_b != nullptr) abi_ok(avr_context_synchronize(pair_b));
     pipeline_idle = true;
+    paired_previous = nullptr;  // nothing is in flight: nothing to order the next classify pass after
     tuner.drained();
   }
 };
@@ -473,9 +484,10 @@ int avr_renderer_set_options(avr_renderer* r, int march_workgroups_per_cu, int c
 int avr_renderer_set_scalar_range(avr_renderer* r, const float scalar_range[2]) {
   return guarded([&]() -> int {
     require(r != nullptr && scalar_range != nullptr, "null argument");
-    r->scalar_range[0] = scalar_range[0];
-    r->scalar_range[1] = scalar_range[1];
-    r->forget_plans();  // the plans carry the paint parameters
+    r->change_plan_inputs([&] {  // the plans carry the paint parameters
+      r->scalar_range[0] = scalar_range[0];
+      r->scalar_range[1] = scalar_range[1];
+    });
     return AVR_OK;
   });
 }
@@ -513,8 +525,7 @@ int avr_renderer_corun_state(const avr_renderer* r, int* overlap_out, int* reser
 int avr_renderer_set_tighten(avr_renderer* r, int enabled) {
   return guarded([&]() -> int {
     require(r != nullptr, "null renderer");
-    r->tighten_exchange = enabled != 0;
-    r->forget_plans();  // the next frame plans afresh
+    r->change_plan_inputs([&] { r->tighten_exchange = enabled != 0; });  // the next frame plans afresh
     return AVR_OK;
   });
 }
@@ -527,9 +538,10 @@ int avr_renderer_set_piece_layout(avr_renderer* r, int piece_layout, int band_ro
     require(piece_layout == AVR_PIECES_CONTIGUOUS ||
                 (band_rows >= 1 && (band_rows & (band_rows - 1)) == 0),
             "band_rows must be a power of two");
-    r->piece_layout = piece_layout;
-    r->band_rows = (piece_layout == AVR_PIECES_ROW_BANDS) ? band_rows : 1;
-    r->forget_plans();
+    r->change_plan_inputs([&] {
+      r->piece_layout = piece_layout;
+      r->band_rows = (piece_layout == AVR_PIECES_ROW_BANDS) ? band_rows : 1;
+    });
     return AVR_OK;
   });
 }
@@ -906,7 +918,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
     hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[volume];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
-    r->paired_previous = paired ? classified : nullptr;
+    // (what the NEXT frame waits on must outlive this frame's timing events, which
+    // avr_renderer_set_timing destroys: always the volume's own ordering event)
+    if (paired && r->timing) {
+      hip_ok(hipEventRecord(r->classified_event[volume], stream_c), "hipEventRecord");
+    }
+    r->paired_previous = paired ? r->classified_event[volume] : nullptr;
 
     lap(1);
     // ---- stream M: march into send buffer `slot` ------------------------------------------------

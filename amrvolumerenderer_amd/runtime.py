@@ -817,8 +817,9 @@ class NativeRenderer:
         # (a camera and parameters that repeat are converted once: per frame the Python layer costs
         # the host what matters beside a rank's 0.17 ms frame)
         key = (width, height, box_transparency, antialiasing, use_visibility_graph, draw_bounds,
-               write_visibility_graph, camera.eye, camera.look_at, camera.up, camera.fov_y_degrees,
-               camera.near_plane, camera.far_plane)
+               write_visibility_graph, tuple(map(float, camera.eye)),
+               tuple(map(float, camera.look_at)), tuple(map(float, camera.up)),
+               float(camera.fov_y_degrees), float(camera.near_plane), float(camera.far_plane))
         if getattr(self, "_converted_key", None) != key:
             self._converted = (
                 _capi.RenderParams(int(width), int(height), float(box_transparency),

@@ -393,6 +393,43 @@ def test_corun_tuning_never_changes_results(O, ctx):
                      "timed_windows": 0}
 
 
+def test_timing_toggled_under_the_paired_layout(ctx):
+    """What bench.py does around its timed region, under the layout ranks of four and eight settle
+    on: timing on, frames, timing off (which destroys the frames' timing events), frames again.
+    The paired layout orders every classify pass after the previous frame's: that hand-over must
+    not go through an event the toggle destroyed (round 3 advisor finding)."""
+    spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+    local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in
+             zip(cells, spec.boxes)]
+    p = RenderParameters(160, 120, 0.9, 1)
+    cam = scenes.default_camera()
+    renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+    native = renderer.native
+    assert native is not None
+    native.set_overlap(0)
+    want = renderer.render(p, cam, want_image=True)
+    renderer.synchronize()
+    native.set_overlap(2)
+    native.set_classify_share(8192)
+    got = []
+    for cycle in range(3):
+        native.set_timing(True)
+        got += [renderer.render(p, cam, want_image=True) for _ in range(7)]
+        renderer.synchronize()
+        _, _, busy_ms, frames = native.timings()
+        assert frames == 7 and busy_ms > 0.0
+        native.set_timing(False)
+        got += [renderer.render(p, cam, want_image=True) for _ in range(5)]   # no drain before them
+    renderer.synchronize()
+    torch.cuda.synchronize()
+    assert native.corun_state()["classify"].startswith("before its march, the frames alternating")
+    for image, rgb8 in got:
+        assert torch.equal(image.view(torch.int32), want[0].view(torch.int32))
+        assert torch.equal(rgb8, want[1])
+
+
 def test_plans_made_ahead_on_another_thread_change_nothing(ctx):
     """avr_renderer_prepare / runtime.PlanAhead: the frame plans of a camera path made one (and
     several) frames ahead on a helper thread, while the frames are queued -- more cameras than the
