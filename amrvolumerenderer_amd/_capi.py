@@ -239,7 +239,22 @@ SIGNATURES = {
     "avr_renderer_set_timing": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_timings": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "avr_set_frame_timeout_ms": (C.c_int, [C.c_int]),
+    "avr_comm_set_control": (C.c_int, [_vp, _vp, _vp]),
+    "avr_comm_control_allgather": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "avr_comm_control_rounds": (C.c_long, [_vp]),
+    "avr_frame_plan_agree": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "avr_renderer_set_plan_check": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_corun_coordination": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_corun_history": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_corun_history": (C.c_int, [_vp, C.POINTER(C.c_int16), C.c_int,
+                                             C.POINTER(C.c_int)]),
+    "avr_renderer_failure": (C.c_char_p, [_vp]),
 }
+
+CONTROL_MAX_BYTES = 2048
+# int (*avr_control_allgather_fn)(void *user, const void *mine, void *all, int bytes_per_rank)
+CONTROL_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
 
 _lib = None
 

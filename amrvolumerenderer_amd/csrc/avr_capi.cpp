@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <exception>
@@ -40,21 +42,58 @@ void hip_check(hipError_t err, const char* what) {
   }
 }
 
+}  // namespace
+
+// Every host wait on device work has a deadline (AVR_FRAME_TIMEOUT_MS, default 30 s; 0 = none): the
+// frame of a rank of several contains collectives, and a peer that died, or whose calls differ from
+// this rank's, would otherwise leave the wait -- and the job -- hanging.  The reference's exchange
+// either completes or errors (MPI_Waitany / MPI_Waitall, DirectSendBase.cpp:206-220, 277); so does
+// this one: the wait throws, the C ABI call returns AVR_ERR_RUNTIME naming what did not finish.
+namespace {
+std::atomic<int> g_timeout_override{-1};
+}
+void set_frame_timeout_ms(int ms) { g_timeout_override.store(ms < 0 ? -1 : ms); }
+int frame_timeout_ms() {
+  const int forced = g_timeout_override.load(std::memory_order_relaxed);
+  if (forced >= 0) return forced;
+  static const int value = [] {
+    const char* text = std::getenv("AVR_FRAME_TIMEOUT_MS");
+    if (text == nullptr || text[0] == '\0') return 30000;
+    const long parsed = std::strtol(text, nullptr, 10);
+    return static_cast<int>(std::min<long>(std::max<long>(parsed, 0), 3600000));
+  }();
+  return value;
+}
+
 // Host waits poll the event instead of blocking in hipEventSynchronize / hipStreamSynchronize:
 // a blocking wait that outlasts the runtime's spin phase sleeps on an interrupt, and waking from
 // it was measured to take milliseconds on this platform -- by then a pipelined renderer's queue
 // has run dry (5-7 ms stalls every few frames at 1.3 ms per frame, tools/host_stalls.py).
-void wait_event(hipEvent_t event, const char* what) {
+void wait_event_deadline(void* event_v, const char* what) {
+  hipEvent_t event = static_cast<hipEvent_t>(event_v);
+  const int limit_ms = frame_timeout_ms();
+  std::chrono::steady_clock::time_point deadline{};
   for (unsigned spins = 0;; ++spins) {
     const hipError_t status = hipEventQuery(event);
     if (status == hipSuccess) return;
     if (status != hipErrorNotReady) hip_check(status, what);
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
     if (spins > 64) std::this_thread::yield();
+    if (limit_ms > 0 && (spins & 255u) == 255u) {
+      const auto now = std::chrono::steady_clock::now();
+      if (deadline == std::chrono::steady_clock::time_point{}) {
+        deadline = now + std::chrono::milliseconds(limit_ms);
+      } else if (now > deadline) {
+        throw DeadlineExceeded(std::string(what) + " did not finish within " +
+                               std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
+      }
+    }
   }
 }
 
 // Waits until everything queued on `stream` so far has finished.
-void wait_stream(hipStream_t stream, const char* what) {
+void wait_stream_deadline(void* stream_v, const char* what) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
   hipEvent_t event = nullptr;
   hip_check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
   const hipError_t recorded = hipEventRecord(event, stream);
@@ -63,13 +102,20 @@ void wait_stream(hipStream_t stream, const char* what) {
     hip_check(recorded, what);
   }
   try {
-    wait_event(event, what);
+    wait_event_deadline(event, what);
+  } catch (const DeadlineExceeded&) {
+    throw;  // the event is still pending on a stream that does not move: it is leaked, not destroyed
   } catch (...) {
     (void)hipEventDestroy(event);
     throw;
   }
   (void)hipEventDestroy(event);
 }
+
+namespace {
+
+void wait_event(hipEvent_t event, const char* what) { wait_event_deadline(event, what); }
+void wait_stream(hipStream_t stream, const char* what) { wait_stream_deadline(stream, what); }
 
 // Per-call descriptors (box table, transfer-function tables, run tables, ...) travel to the
 // device in ONE asynchronous copy per call: they are packed into a pinned host block and copied
@@ -457,6 +503,11 @@ extern "C" {
 const char* avr_last_error(void) { return avr::g_last_error.c_str(); }
 
 int avr_abi_version(void) { return 1; }
+
+int avr_set_frame_timeout_ms(int milliseconds) {
+  avr::set_frame_timeout_ms(milliseconds);
+  return AVR_OK;
+}
 
 int avr_context_create(int device_id, avr_context** out_ctx) {
   return guarded([&]() -> int {

@@ -107,7 +107,10 @@ struct LocalWorld {
   std::vector<const char*> base;              // send buffer / piece
   std::vector<std::vector<int64_t>> offsets;  // byte offset of the block for each peer
   std::vector<std::vector<int64_t>> sizes;    // byte size of the block for each peer
+  std::vector<std::vector<unsigned char>> control;  // avr_comm_control_allgather
 
+  // Every rank arrives, or the wait gives up (AVR_FRAME_TIMEOUT_MS): a rank thread that died must
+  // not leave its peers waiting.
   void barrier() {
     std::unique_lock<std::mutex> lock(mutex);
     const uint64_t mine = generation;
@@ -115,8 +118,15 @@ struct LocalWorld {
       waiting = 0;
       ++generation;
       arrived.notify_all();
-    } else {
+      return;
+    }
+    const int limit_ms = frame_timeout_ms();
+    if (limit_ms <= 0) {
       arrived.wait(lock, [&] { return generation != mine; });
+    } else if (!arrived.wait_for(lock, std::chrono::milliseconds(limit_ms),
+                                 [&] { return generation != mine; })) {
+      throw DeadlineExceeded("local communicator: a peer did not arrive within " +
+                             std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
     }
   }
 };
@@ -133,6 +143,7 @@ struct SharedHeader {
   std::atomic<uint32_t> generation;
   int64_t offsets[kMaxRanks][kMaxRanks];  // [source][peer]: byte offset inside the source's region
   int64_t sizes[kMaxRanks][kMaxRanks];
+  unsigned char control[kMaxRanks][AVR_CONTROL_MAX_BYTES];  // avr_comm_control_allgather
 };
 
 struct SharedWorld {
@@ -152,7 +163,8 @@ struct SharedWorld {
     if (owner) (void)shm_unlink(name.c_str());
   }
   // Every rank arrives, or the wait gives up: a rehearsal must not hang a GPU box.
-  void barrier() {
+  void barrier(int limit_ms = -1) {
+    if (limit_ms < 0) limit_ms = frame_timeout_ms();
     SharedHeader* h = header();
     const uint32_t mine = h->generation.load(std::memory_order_acquire);
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == static_cast<uint32_t>(n_ranks)) {
@@ -160,11 +172,12 @@ struct SharedWorld {
       h->generation.fetch_add(1, std::memory_order_release);
       return;
     }
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(limit_ms);
     for (unsigned spins = 0; h->generation.load(std::memory_order_acquire) == mine; ++spins) {
       if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(20));
-      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() > deadline) {
-        throw std::runtime_error("shared communicator: a peer did not arrive within 120 s");
+      if (limit_ms > 0 && (spins & 255u) == 255u && std::chrono::steady_clock::now() > deadline) {
+        throw DeadlineExceeded("shared communicator: a peer did not arrive within " +
+                               std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
       }
     }
   }
@@ -182,6 +195,15 @@ struct avr_comm {
   std::unique_ptr<avr::SharedWorld> shared;       // cross-process flavour (one GPU, shared memory)
   bool solo = false;                              // one rank of N played alone (timing studies)
   int solo_percent = 100;                         // ... share of every peer's block it moves through RCCL
+  // control plane (avr_comm_control_allgather): the caller's own (MPI_Allgather in the reference's
+  // host, gloo in bench.py), or -- RCCL flavour without one -- a tiny grouped round in band
+  avr_control_allgather_fn control_fn = nullptr;
+  void* control_user = nullptr;
+  void* control_dev = nullptr;     // (n_ranks + 1) slots of AVR_CONTROL_MAX_BYTES: mine, then everybody's
+  void* control_host = nullptr;    // pinned twin, device-mapped
+  void* control_host_mapped = nullptr;
+  hipEvent_t control_done = nullptr;
+  long control_rounds = 0;         // calls so far (diagnostics, tests)
 };
 
 namespace {
@@ -257,6 +279,7 @@ int avr_comm_create_local(int n_ranks, avr_comm** out_comms) {
     world->base.assign(static_cast<size_t>(n_ranks), nullptr);
     world->offsets.resize(static_cast<size_t>(n_ranks));
     world->sizes.resize(static_cast<size_t>(n_ranks));
+    world->control.resize(static_cast<size_t>(n_ranks));
     for (int r = 0; r < n_ranks; ++r) {
       auto* comm = new avr_comm();
       comm->rank = r;
@@ -368,8 +391,8 @@ int avr_comm_create_shared(const char* name, int rank, int n_ranks, size_t capac
         pause("rank 0 did not initialise the segment");
       }
     }
-    comm->shared->barrier();  // everybody is attached before anybody communicates
-    if (rank == 0) {          // ... and nobody needs the name any more
+    comm->shared->barrier(120000);  // everybody is attached before anybody communicates
+    if (rank == 0) {                // ... and nobody needs the name any more
       (void)shm_unlink(name);
       comm->shared->owner = false;
     }
@@ -380,6 +403,9 @@ int avr_comm_create_shared(const char* name, int rank, int n_ranks, size_t capac
 
 void avr_comm_destroy(avr_comm* comm) {
   if (comm == nullptr) return;
+  if (comm->control_done != nullptr) (void)hipEventDestroy(comm->control_done);
+  if (comm->control_dev != nullptr) (void)hipFree(comm->control_dev);
+  if (comm->control_host != nullptr) (void)hipHostFree(comm->control_host);
   if (comm->nccl != nullptr) {
     try {
       (void)avr::rccl().comm_destroy(comm->nccl);
@@ -387,6 +413,181 @@ void avr_comm_destroy(avr_comm* comm) {
     }
   }
   delete comm;
+}
+
+int avr_comm_set_control(avr_comm* comm, avr_control_allgather_fn allgather, void* user) {
+  return guarded([&]() -> int {
+    require(comm != nullptr, "null communicator");
+    comm->control_fn = allgather;
+    comm->control_user = user;
+    return AVR_OK;
+  });
+}
+
+long avr_comm_control_rounds(const avr_comm* comm) { return comm ? comm->control_rounds : -1; }
+
+int avr_comm_control_allgather(avr_comm* comm, avr_context* ctx, const void* mine, void* all,
+                               int bytes) {
+  return guarded([&]() -> int {
+    require(comm != nullptr && mine != nullptr && all != nullptr, "null argument");
+    require(bytes > 0 && bytes <= AVR_CONTROL_MAX_BYTES && bytes % 4 == 0,
+            "bytes must be a multiple of 4 in (0, AVR_CONTROL_MAX_BYTES]");
+    const int n = comm->n_ranks, me = comm->rank;
+    const size_t each = static_cast<size_t>(bytes);
+    char* out = static_cast<char*>(all);
+    ++comm->control_rounds;
+    if (comm->control_fn != nullptr) {  // the caller's control plane
+      if (comm->control_fn(comm->control_user, mine, all, bytes) != 0) {
+        throw std::runtime_error("control plane: the caller's allgather failed");
+      }
+      return AVR_OK;
+    }
+    if (comm->solo) {  // alone: every peer "says" what this rank says
+      for (int s = 0; s < n; ++s) std::memcpy(out + static_cast<size_t>(s) * each, mine, each);
+      return AVR_OK;
+    }
+    if (comm->shared) {
+      avr::SharedWorld& world = *comm->shared;
+      std::memcpy(world.header()->control[me], mine, each);
+      world.barrier();
+      for (int s = 0; s < n; ++s) {
+        std::memcpy(out + static_cast<size_t>(s) * each, world.header()->control[s], each);
+      }
+      world.barrier();  // everybody has read: the slots may be rewritten
+      return AVR_OK;
+    }
+    if (comm->local) {
+      avr::LocalWorld& world = *comm->local;
+      {
+        std::lock_guard<std::mutex> lock(world.mutex);
+        world.control[static_cast<size_t>(me)].assign(static_cast<const unsigned char*>(mine),
+                                                      static_cast<const unsigned char*>(mine) + each);
+      }
+      world.barrier();
+      for (int s = 0; s < n; ++s) {
+        if (world.control[static_cast<size_t>(s)].size() != each) {
+          throw std::runtime_error("control plane: the ranks' calls differ (message sizes)");
+        }
+        std::memcpy(out + static_cast<size_t>(s) * each, world.control[static_cast<size_t>(s)].data(), each);
+      }
+      world.barrier();
+      return AVR_OK;
+    }
+    // RCCL, in band: my slot to every peer, every peer's slot to me -- one grouped round of tiny
+    // messages over the connections the frame's exchange uses anyway (no ring / tree is set up),
+    // on the context's stream, behind whatever the frames before have queued there.  Every rank
+    // calls this at the same point of the same frame, so the rounds meet in order.
+    require(ctx != nullptr, "the in-band control plane needs a context (its stream)");
+    hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
+    const size_t slot = AVR_CONTROL_MAX_BYTES;
+    if (comm->control_dev == nullptr) {
+      const size_t total = slot * static_cast<size_t>(n + 1);
+      avr::hip_ok(hipMalloc(&comm->control_dev, total), "hipMalloc(control)");
+      avr::hip_ok(hipHostMalloc(&comm->control_host, total, hipHostMallocMapped), "hipHostMalloc(control)");
+      avr::hip_ok(hipHostGetDevicePointer(&comm->control_host_mapped, comm->control_host, 0),
+                  "hipHostGetDevicePointer(control)");
+      avr::hip_ok(hipEventCreateWithFlags(&comm->control_done, hipEventDisableTiming), "hipEventCreate");
+    }
+    char* dev = static_cast<char*>(comm->control_dev);
+    char* host = static_cast<char*>(comm->control_host);
+    char* mapped = static_cast<char*>(comm->control_host_mapped);
+    // slot 0: mine; slots 1 .. n: everybody's (mine copied there on the host, below)
+    std::memcpy(host, mine, each);
+    if (avr::launch_upload(mapped, dev, each, stream) != AVR_OK) throw std::runtime_error(avr_last_error());
+    const avr::Rccl& api = avr::rccl();
+    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    for (int s = 0; s < n; ++s) {
+      if (s == me && n > 1) continue;  // (a one-rank communicator talks to itself on purpose)
+      avr::nccl_ok(api.send(dev, each, ncclChar, s, comm->nccl, stream), "ncclSend(control)");
+      avr::nccl_ok(api.recv(dev + slot * static_cast<size_t>(s + 1), each, ncclChar, s, comm->nccl, stream),
+                   "ncclRecv(control)");
+    }
+    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    if (avr::launch_upload(dev + slot, mapped + slot, slot * static_cast<size_t>(n), stream) != AVR_OK) {
+      throw std::runtime_error(avr_last_error());
+    }
+    avr::hip_ok(hipEventRecord(comm->control_done, stream), "hipEventRecord(control)");
+    avr::wait_event_deadline(comm->control_done,
+                             "control plane: the in-band round (a peer is missing, or the ranks' "
+                             "calls differ)");
+    for (int s = 0; s < n; ++s) {
+      std::memcpy(out + static_cast<size_t>(s) * each, host + slot * static_cast<size_t>(s + 1), each);
+    }
+    if (n > 1) std::memcpy(out + static_cast<size_t>(me) * each, mine, each);
+    return AVR_OK;
+  });
+}
+
+int avr_frame_plan_agree(const avr_frame_plan* plan, avr_comm* comm, avr_context* ctx,
+                         uint64_t settings_digest) {
+  return guarded([&]() -> int {
+    check_plan(comm, plan);
+    const int n = comm->n_ranks;
+    const size_t un = static_cast<size_t>(n);
+    const int bytes = static_cast<int>(8 + 16 * un);
+    require(bytes <= AVR_CONTROL_MAX_BYTES, "too many ranks for the plan agreement check");
+    if (plan->send_splits.size() != un || plan->recv_splits.size() != un) {
+      throw std::runtime_error("frame plan: split tables do not match the rank count");
+    }
+    // FNV-1a over everything of the plan that is the same on every rank by construction
+    uint64_t digest = 0xcbf29ce484222325ull;
+    auto mix = [&](const void* data, size_t size) {
+      const unsigned char* p = static_cast<const unsigned char*>(data);
+      for (size_t i = 0; i < size; ++i) {
+        digest ^= p[i];
+        digest *= 0x100000001b3ull;
+      }
+    };
+    auto mix_value = [&](auto value) { mix(&value, sizeof(value)); };
+    mix_value(settings_digest);
+    mix_value(plan->info.n_ranks);
+    mix_value(plan->info.n_runs_total);
+    mix_value(plan->info.n_pixels);
+    mix_value(plan->pieces.layout);
+    mix_value(plan->pieces.band_rows);
+    mix_value(plan->pieces.n_pieces);
+    mix_value(plan->pieces.width);
+    mix_value(plan->pieces.height);
+    mix_value(plan->pieces.piece_size);
+    mix_value(static_cast<int32_t>(plan->tightened ? 1 : 0));
+    mix(plan->group_order.data(), plan->group_order.size() * sizeof(int32_t));
+    mix(plan->piece_of_rank.data(), plan->piece_of_rank.size() * sizeof(int32_t));
+    mix(plan->layer_box.data(), plan->layer_box.size() * sizeof(int32_t));
+    for (const avr_run_info& run : plan->runs) {
+      mix_value(run.owner);
+      mix_value(run.local_run);
+      mix_value(run.first_layer);
+      mix_value(run.n_layers);
+      mix(run.rect, sizeof(run.rect));
+    }
+    std::vector<int64_t> mine(1 + 2 * un), all((1 + 2 * un) * un);
+    std::memcpy(&mine[0], &digest, 8);
+    std::copy(plan->send_splits.begin(), plan->send_splits.end(), mine.begin() + 1);
+    std::copy(plan->recv_splits.begin(), plan->recv_splits.end(), mine.begin() + 1 + n);
+    const int status = avr_comm_control_allgather(comm, ctx, mine.data(), all.data(), bytes);
+    if (status != AVR_OK) return status;
+    if (comm->solo) return AVR_OK;  // (alone: nobody to agree with)
+    const size_t row = 1 + 2 * un;
+    for (size_t a = 1; a < un; ++a) {  // every rank scans the same matrix: the same verdict everywhere
+      if (all[a * row] != all[0]) {
+        throw std::runtime_error("frame plan: rank " + std::to_string(a) + "'s plan differs from rank 0's "
+                                 "(image, pieces, group order, runs or settings): the ranks were not "
+                                 "given the same frame");
+      }
+    }
+    for (size_t a = 0; a < un; ++a) {
+      for (size_t b = 0; b < un; ++b) {
+        const int64_t sends = all[a * row + 1 + b], expects = all[b * row + 1 + un + a];
+        if (sends != expects) {
+          throw std::runtime_error("frame plan: rank " + std::to_string(a) + " sends " +
+                                   std::to_string(sends) + " floats to rank " + std::to_string(b) +
+                                   ", which expects " + std::to_string(expects) +
+                                   ": the exchange would never complete");
+        }
+      }
+    }
+    return AVR_OK;
+  });
 }
 
 int avr_comm_rank(const avr_comm* comm) { return comm ? comm->rank : -1; }

@@ -69,6 +69,21 @@ struct CoRunTuner {
   int refined = 0, repeated = 0;
   bool drift_suspected = false;  // kHold: the last window read slow
   long windows = 0;
+  // Ranks of several search as ONE system (round 4): every frame is a collective, so a rank that
+  // walks through its candidates alone stalls all the others and reads their candidates' periods
+  // as its own.  Coordinated, every rank holds the same candidate in the same frames -- the state
+  // machine below is a pure function of the frame count and of the reported periods -- and the
+  // period reported for a window is the MAXIMUM over the ranks (one small allgather on the
+  // communicator's control plane per window, avr_comm_control_allgather), taken by all ranks at
+  // the same frame: kReportLag frames after the window's last one, when each rank's own events
+  // have long happened (host-side back-pressure keeps at most three frames in flight).  What
+  // happens to ONE rank only (its pipeline drained because a buffer grew) must not move its
+  // state: it voids the rank's window, and a window void on any rank is timed again by all.
+  bool coordinated = false;
+  bool window_void = false;
+  int frames_since_close = 0;
+  static constexpr int kReportLag = 3;
+  static constexpr float kHoldMs = 500.0f;  // coordinated: the held candidate is re-timed this often
   // the window in progress
   int frames_at_candidate = 0;  // since the candidate was chosen (or an interruption)
   bool open = false, closing = false;
@@ -114,9 +129,39 @@ struct CoRunTuner {
   void interrupt() {  // the pipeline drained or the candidate changed: the window is void
     frames_at_candidate = 0;
     open = closing = false;
+    window_void = false;
+    frames_since_close = 0;
   }
   void drained() {  // a window whose last frame was already queued stays valid
+    if (coordinated) {  // (the frame counts are the ranks' common clock: only the window suffers)
+      if (open) window_void = true;
+      return;
+    }
     if (!closing) interrupt();
+  }
+  void set_coordinated(bool on) {
+    if (on == coordinated) return;
+    coordinated = on;
+    restart();
+  }
+  // frames the held candidate runs before it is timed again
+  int hold_frames() const {
+    if (!coordinated || last_period_ms <= 0.0f) return kHoldFrames;
+    const float frames = kHoldMs / last_period_ms;
+    return static_cast<int>(std::min(std::max(frames, static_cast<float>(kHoldFrames)), 20000.0f));
+  }
+  // coordinated: whether the closed window's period is to be agreed on in this frame
+  bool report_due() {
+    if (!coordinated || !closing) return false;
+    return ++frames_since_close >= kReportLag;
+  }
+  // coordinated: some rank's window was void -- the same candidate is timed again, by all
+  void retime() {
+    const int start = (phase == kHold) ? hold_frames() : std::max(kSettleFrames, frames_per_window());
+    open = closing = false;
+    window_void = false;
+    frames_since_close = 0;
+    frames_at_candidate = std::max(0, start - std::max(kSettleFrames, frames_per_window()));
   }
   // Once per frame, after its march has been queued, while no window is waiting for its end
   // event: what to record on the march stream now.
@@ -129,7 +174,7 @@ struct CoRunTuner {
     // harmless while every candidate was side by side and is not beside the paired layout, which
     // settles at once): as many frames are let pass as the window then times.
     const int start =
-        (phase == kHold) ? kHoldFrames : std::max(kSettleFrames, frames_per_window());
+        (phase == kHold) ? hold_frames() : std::max(kSettleFrames, frames_per_window());
     if (!open && frames_at_candidate >= start) {
       open = true;
       // paired, the window's two events must lie on the same one of the two streams (whose
@@ -182,7 +227,7 @@ struct CoRunTuner {
         } else {
           drift_suspected = true;
           interrupt();
-          frames_at_candidate = kHoldFrames - std::max(kSettleFrames, frames_per_window());
+          frames_at_candidate = hold_frames() - std::max(kSettleFrames, frames_per_window());
         }
       } else {
         drift_suspected = false;

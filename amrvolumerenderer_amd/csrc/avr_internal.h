@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -367,6 +368,17 @@ bool visibility_order(avr_visibility_graph* graph, const avr_camera& camera, flo
                       const char* dot_prefix, int32_t* rank_order, int* n_splits);
 
 void set_error(const std::string& message);
+// Deadline (ms) of every host wait on device work, AVR_FRAME_TIMEOUT_MS (default 30000; 0: none):
+// a frame of several ranks contains collectives, and a peer that died or whose calls differ must
+// end in an error on this rank, not in a hang (DirectSendBase.cpp:206-220, 277 completes or errors).
+int frame_timeout_ms();
+void set_frame_timeout_ms(int ms);  // < 0: back to the environment's value
+struct DeadlineExceeded : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+// Polling host waits (hipEvent_t / hipStream_t) that throw DeadlineExceeded naming `what`.
+void wait_event_deadline(void* hip_event, const char* what);
+void wait_stream_deadline(void* hip_stream, const char* what);
 // The context's HIP stream (hipStream_t; created on first use) with its device made current.
 void* context_stream(avr_context* ctx);
 // The context's owner bounds the frames in flight itself: a descriptor batch that repeats then

@@ -37,6 +37,9 @@ struct avr_frame_plan {
   // host prologue of this frame's local boxes, filled by the first device call that needs it
   // (avr_classify_plan) and re-used by the next (avr_march_plan)
   avr::FramePlan prologue;
+  // the settings epoch of the frame driver under which the ranks agreed on this plan
+  // (avr_frame_plan_agree; 0 = not yet)
+  mutable uint64_t agreed_epoch = 0;
 };
 
 namespace avr {

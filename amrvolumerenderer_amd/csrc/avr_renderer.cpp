@@ -49,6 +49,8 @@ void abi_ok(int status) {
   if (status == AVR_OK) return;
   const std::string message = avr_last_error();
   if (status == AVR_ERR_INVALID_ARGUMENT) throw std::invalid_argument(message);
+  // (a wait inside a nested C ABI call that ran into the deadline: the renderer fails for good)
+  if (message.find("AVR_FRAME_TIMEOUT_MS") != std::string::npos) throw avr::DeadlineExceeded(message);
   throw std::runtime_error(message);
 }
 
@@ -138,6 +140,17 @@ struct avr_renderer {
   int overlap_classify = -1;  // -1: default (1 for one rank, 0 otherwise); see avr_renderer_set_overlap
   int host_backpressure = -1;  // -1: default (ranks of several); see avr_renderer_set_host_backpressure
   hipEvent_t paired_previous = nullptr;  // paired layout: the previous frame's classify pass finished
+  // Ranks of several (round 4): a new plan is agreed on over the control plane before anything of
+  // its first frame is queued (avr_frame_plan_agree), the co-run search is one search of all ranks
+  // (CoRunTuner::coordinated), and every host wait has a deadline after which the renderer is
+  // failed for good -- the frame either completes or errors (DirectSendBase.cpp:206-220, 277).
+  int plan_check = 1;          // avr_renderer_set_plan_check
+  int coordinate = -1;         // avr_renderer_set_corun_coordination: -1 = ranks of several
+  uint64_t settings_epoch = 1; // bumped by every setter the ranks must agree on
+  std::string failed;          // non-empty: what did not finish; every later call returns it
+  const char* stage = "idle";  // what the frame being queued was doing (error messages)
+  std::vector<int16_t> history;  // candidate of every frame (avr_renderer_set_corun_history)
+  size_t history_capacity = 0;
 
   // Frame plans by (render parameters, camera, group order), most recently used kept: a camera
   // that comes back (an orbit) finds its plan -- and, for N > 1, its tightened exchange layout.
@@ -203,6 +216,13 @@ struct avr_renderer {
 
   ~avr_renderer() {
     (void)hipSetDevice(device);
+    if (!failed.empty()) {
+      // A stream of this renderer does not move (a collective whose peer never came): waiting for
+      // it, or freeing device memory (which waits for the device), would hang the caller too.
+      // Everything is leaked; the process is expected to report the error and exit.
+      forget_plans();
+      return;
+    }
     for (avr_context* ctx : {classify, march, compose, pair_b}) {
       if (ctx != nullptr) (void)avr_context_synchronize(ctx);
     }
@@ -239,9 +259,35 @@ struct avr_renderer {
 
   hipStream_t stream_of(avr_context* ctx) { return static_cast<hipStream_t>(avr::context_stream(ctx)); }
 
+  // What the ranks must have set alike (mixed into the plan agreement's digest).
+  uint64_t settings_digest() const {
+    uint64_t digest = 0xcbf29ce484222325ull;
+    for (int64_t value : {static_cast<int64_t>(overlap_classify), static_cast<int64_t>(share_fixed),
+                          static_cast<int64_t>(cache_classification), static_cast<int64_t>(tighten_exchange),
+                          static_cast<int64_t>(coordinate), static_cast<int64_t>(plan_check)}) {
+      digest = (digest ^ static_cast<uint64_t>(value)) * 0x100000001b3ull;
+    }
+    return digest;
+  }
+
+  std::string describe() const {
+    char text[256];
+    std::snprintf(text, sizeof text,
+                  "rank %d of %d, frame %u, stage: %s; co-run: %s, LDS reserve %d, %s after %ld windows",
+                  rank, n_ranks, frame, stage,
+                  last_paired ? "paired" : last_overlap ? "side by side" : "back to back", last_reserve,
+                  tuner.settled() ? "settled" : "searching", tuner.windows);
+    return text;
+  }
+
   void drain_all() {
-    for (avr_context* ctx : {classify, march, compose}) abi_ok(avr_context_synchronize(ctx));
-    if (pair_b != nullptr) abi_ok(avr_context_synchronize(pair_b));
+    // (waits with the deadline, stream by stream, so that an error names the one that is stuck)
+    const std::pair<avr_context*, const char*> streams[] = {
+        {classify, "the classify stream"}, {march, "the march stream"},
+        {compose, "the compositing stream (exchange, fold, gather)"}, {pair_b, "the second march stream"}};
+    for (const auto& entry : streams) {
+      if (entry.first != nullptr) avr::wait_stream_deadline(stream_of(entry.first), entry.second);
+    }
     pipeline_idle = true;
     paired_previous = nullptr;  // nothing is in flight: nothing to order the next classify pass after
     tuner.drained();
@@ -267,6 +313,23 @@ int guarded(F&& body) {
     avr::set_error("unknown failure");
     return AVR_ERR_RUNTIME;
   }
+}
+
+// A call on a renderer: refused once the renderer has failed; a wait that runs into the deadline
+// fails it (the message says which stream of which rank in which frame, and how the co-run search
+// stood) -- the caller reports it and exits, and its peers run into their own deadlines.
+template <typename F>
+int guarded_renderer(avr_renderer* r, F&& body) {
+  return guarded([&]() -> int {
+    if (r == nullptr) throw std::invalid_argument("null renderer");
+    if (!r->failed.empty()) throw std::runtime_error(r->failed);
+    try {
+      return body();
+    } catch (const avr::DeadlineExceeded& e) {
+      r->failed = std::string(e.what()) + " [" + r->describe() + "]";
+      throw std::runtime_error(r->failed);
+    }
+  });
 }
 
 // validateRenderParameters (VolumeRenderer.cpp:562-579); returns sqrt(antialiasing)
@@ -476,6 +539,7 @@ int avr_renderer_set_options(avr_renderer* r, int march_workgroups_per_cu, int c
             "march_workgroups_per_cu must be in [-1, 8]");
     r->march_cap = march_workgroups_per_cu;
     r->cache_classification = cache_classification != 0;
+    ++r->settings_epoch;
     abi_ok(avr_scene_set_classification_cache(r->scene, r->cache_classification ? 1 : 0));
     return AVR_OK;
   });
@@ -505,13 +569,14 @@ int avr_renderer_set_classify_share(avr_renderer* r, int bytes) {
     require(bytes >= -1 && bytes <= AVR_CLASSIFY_LDS_RESERVE_MAX,
             "bytes must be -1 or in [0, AVR_CLASSIFY_LDS_RESERVE_MAX]");
     r->share_fixed = bytes;
+    ++r->settings_epoch;
     return AVR_OK;
   });
 }
 
 int avr_renderer_corun_state(const avr_renderer* r, int* overlap_out, int* reserve_bytes_out,
                              int* settled_out, long* windows_out) {
-  return guarded([&]() -> int {
+  return guarded([&]() -> int {  // (still answered by a failed renderer: the caller reports it)
     require(r != nullptr, "null renderer");
     const CoRunTuner& t = r->tuner;
     if (overlap_out != nullptr) *overlap_out = r->last_paired ? 2 : r->last_overlap ? 1 : 0;
@@ -547,8 +612,7 @@ int avr_renderer_set_piece_layout(avr_renderer* r, int piece_layout, int band_ro
 }
 
 int avr_renderer_set_host_backpressure(avr_renderer* r, int mode) {
-  return guarded([&]() -> int {
-    require(r != nullptr, "null renderer");
+  return guarded_renderer(r, [&]() -> int {
     require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
     r->drain_all();
     r->host_backpressure = mode;
@@ -557,12 +621,57 @@ int avr_renderer_set_host_backpressure(avr_renderer* r, int mode) {
 }
 
 int avr_renderer_set_overlap(avr_renderer* r, int overlap_classify) {
-  return guarded([&]() -> int {
-    require(r != nullptr, "null renderer");
+  return guarded_renderer(r, [&]() -> int {
     r->drain_all();
     r->overlap_classify = overlap_classify;
+    ++r->settings_epoch;
     return AVR_OK;
   });
+}
+
+int avr_renderer_set_plan_check(avr_renderer* r, int mode) {
+  return guarded_renderer(r, [&]() -> int {
+    require(mode == 0 || mode == 1, "mode must be 0 or 1");
+    r->plan_check = mode;
+    ++r->settings_epoch;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_set_corun_coordination(avr_renderer* r, int mode) {
+  return guarded_renderer(r, [&]() -> int {
+    require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
+    r->drain_all();
+    r->coordinate = mode;
+    ++r->settings_epoch;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_set_corun_history(avr_renderer* r, int frames) {
+  return guarded_renderer(r, [&]() -> int {
+    require(frames >= 0, "frames must not be negative");
+    r->history.clear();
+    r->history_capacity = static_cast<size_t>(frames);
+    r->history.reserve(r->history_capacity);
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_corun_history(const avr_renderer* r, int16_t* candidates_out, int capacity,
+                               int* frames_out) {
+  return guarded([&]() -> int {
+    require(r != nullptr && frames_out != nullptr && capacity >= 0 &&
+                (capacity == 0 || candidates_out != nullptr), "invalid argument");
+    *frames_out = static_cast<int>(r->history.size());
+    const size_t n = std::min(r->history.size(), static_cast<size_t>(capacity));
+    std::copy(r->history.begin(), r->history.begin() + static_cast<std::ptrdiff_t>(n), candidates_out);
+    return AVR_OK;
+  });
+}
+
+const char* avr_renderer_failure(const avr_renderer* r) {
+  return (r == nullptr || r->failed.empty()) ? nullptr : r->failed.c_str();
 }
 
 int avr_renderer_reference_sample_distance(const avr_renderer* r, float* out) {
@@ -584,9 +693,10 @@ void* avr_renderer_stream(avr_renderer* r, int which) {
 }
 
 int avr_renderer_synchronize(avr_renderer* r) {
-  return guarded([&]() -> int {
-    require(r != nullptr, "null renderer");
+  return guarded_renderer(r, [&]() -> int {
+    r->stage = "synchronize";
     r->drain_all();
+    r->stage = "idle";
     return AVR_OK;
   });
 }
@@ -613,8 +723,7 @@ int avr_renderer_host_profile(avr_renderer* r, double seconds_out[6], long* fram
 }
 
 int avr_renderer_set_timing(avr_renderer* r, int enabled) {
-  return guarded([&]() -> int {
-    require(r != nullptr, "null renderer");
+  return guarded_renderer(r, [&]() -> int {
     hip_ok(hipSetDevice(r->device), "hipSetDevice");
     r->drain_all();
     r->clear_timing();
@@ -629,8 +738,8 @@ int avr_renderer_set_timing(avr_renderer* r, int enabled) {
 
 int avr_renderer_timings(avr_renderer* r, double* classify_ms, double* march_ms, double* busy_ms,
                          int* frames) {
-  return guarded([&]() -> int {
-    require(r != nullptr && classify_ms != nullptr && march_ms != nullptr && busy_ms != nullptr &&
+  return guarded_renderer(r, [&]() -> int {
+    require(classify_ms != nullptr && march_ms != nullptr && busy_ms != nullptr &&
                 frames != nullptr, "null argument");
     hip_ok(hipSetDevice(r->device), "hipSetDevice");
     r->drain_all();
@@ -683,8 +792,8 @@ int avr_renderer_prepare(avr_renderer* r, const avr_render_params* render, const
 int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const avr_camera* camera,
                         const int32_t* group_order, void* input_stream, uint64_t* samples_out,
                         int want_image, uint8_t* rgb8_out, float* image_out) {
-  return guarded([&]() -> int {
-    require(r != nullptr && render != nullptr && camera != nullptr, "null argument");
+  return guarded_renderer(r, [&]() -> int {
+    require(render != nullptr && camera != nullptr, "null argument");
     const int root = validate(*render);
     hip_ok(hipSetDevice(r->device), "hipSetDevice");
     const bool is_root = r->rank == 0;
@@ -702,71 +811,27 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     };
     // ---- host plan (re-used while camera and parameters repeat; avr_renderer_prepare may have
     // made it ahead of time on another thread) ---------------------------------------------------
+    r->stage = "frame plan";
     const avr_frame_plan* plan = plan_for(r, *render, *camera, group_order, /*use=*/true);
     const avr_frame_plan_info& info = plan->info;
     const int64_t piece_pixels = info.piece_end - info.piece_begin;
+    const bool many = r->n_ranks > 1;
+    // ---- a NEW plan of a rank of several is agreed on before anything of its first frame is
+    // queued: a grouped ncclSend / ncclRecv round whose two sides disagree on a block size never
+    // ends (the reference would notice in the metadata message of every transfer,
+    // Common/Image.cpp:62-90).  Once per plan (and again after a setting changed), never per frame;
+    // on disagreement EVERY rank returns the error here (avr_frame_plan_agree).
+    if (many && r->plan_check != 0 && plan->agreed_epoch != r->settings_epoch) {
+      r->stage = "plan agreement (control plane)";
+      abi_ok(avr_frame_plan_agree(plan, r->comm, r->compose, r->settings_digest()));
+      plan->agreed_epoch = r->settings_epoch;
+    }
 
     // Round 1's march (8 workgroups per CU) gained from being capped at 5 beside the classify
     // pass; the present one is admitted 6 per CU by its register budget and runs best uncapped
     // (config-4 frame: uncapped 1.06-1.07 ms, cap 5 1.09-1.11 ms).
     const int cap = (r->march_cap < 0) ? 0 : r->march_cap;
 
-    // One rank: the classify pass of the next frame runs beside the march of this one (HBM-bound
-    // beside issue-bound).  A rank's share of an N-rank frame is two SHORT kernels whose time is
-    // their slowest workgroups': side by side each stretched the other (N = 8, slowest rank:
-    // 77 us + 151 us alone, 0.26 + 0.27 ms overlapped), so there they run back to back on the
-    // march stream and only the exchange / fold / gather of the previous frame overlaps them.
-    // Which of the two, and how many classify workgroups a CU admits beside the march, is measured
-    // on the running pipeline (CoRunTuner) unless the caller fixed it: avr_renderer_set_overlap,
-    // avr_renderer_set_classify_share.  (A cached classification leaves nothing to tune.)
-    CoRunTuner& tuner = r->tuner;
-    {
-      // overlap_classify: -1 everything, 0 back to back, 1 side by side, 2 paired
-      int first = CoRunTuner::kBackToBack, last = CoRunTuner::kLastPaired;
-      if (r->cache_classification) {  // no classify pass to place
-        first = last = (r->overlap_classify == 0) ? CoRunTuner::kBackToBack : 0;
-      } else if (r->overlap_classify == 0) {
-        last = first;
-      } else if (r->overlap_classify == 2) {
-        first = CoRunTuner::kPairedBase;
-        if (r->share_fixed >= 0) last = first;  // the caller's reserve, kept outside the scale
-      } else {
-        if (r->overlap_classify > 0) {
-          first = 0;
-          last = CoRunTuner::kLastCandidate;
-        }
-        if (r->share_fixed >= 0) {
-          // one side-by-side candidate: the caller's reserve (kept outside the candidate scale)
-          last = (first == CoRunTuner::kBackToBack) ? 0 : first;
-        }
-      }
-      tuner.restrict_to(first, last, r->n_ranks == 1);
-    }
-    const bool overlap = tuner.candidate != CoRunTuner::kBackToBack;
-    const bool paired = CoRunTuner::is_paired(tuner.candidate);
-    const int reserve = !overlap ? 0
-                        : (r->share_fixed >= 0)
-                            ? r->share_fixed
-                            : CoRunTuner::reserve_index(tuner.candidate) * CoRunTuner::kReserveStep;
-    // (One stream per kernel kind.  Letting the odd frames take a second march or classify stream
-    // -- the frames are independent, so march(f+1) need not queue behind march(f) and its wait /
-    // record / copy packets could be worked off early -- was measured in round 3 and is worse by
-    // half: with a FOURTH concurrently active queue everything stalls, a 5 us descriptor copy
-    // takes 40-50 us, the frame of a rank of eight goes from 0.187 to 0.26-0.33 ms and the one-rank
-    // frame from 0.98 to 1.25-1.42 ms.  profiles/r3_experiments/.)
-    // Paired layout (avr_corun.h): this frame's classify pass and march back to back on ONE
-    // stream, the even frames on stream M, the odd ones on stream B -- with stream X three active
-    // queues, the number this GPU runs side by side without penalty.
-    avr_context* march_ctx = r->march;
-    if (paired && (r->frame & 1u)) {
-      if (r->pair_b == nullptr) abi_ok(avr_context_create_with_priority(r->device, 1, &r->pair_b));
-      march_ctx = r->pair_b;
-    }
-    avr_context* classify_ctx = paired ? march_ctx : overlap ? r->classify : r->march;
-    abi_ok(avr_context_set_march_occupancy(march_ctx, cap));
-    hipStream_t stream_c = r->stream_of(classify_ctx);
-    hipStream_t stream_m = r->stream_of(march_ctx);
-    hipStream_t stream_x = r->stream_of(r->compose);
     // Send buffers alternate; the classified volumes rotate through three, so that the classify
     // stream may run a whole frame ahead of the march: with two, classify(f+1) and march(f) both
     // had to wait for the later of classify(f) and march(f-1) and started in lockstep, a launch
@@ -792,7 +857,6 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // bottom-up image into the file's top-down rows).
     const bool banded = info.piece_layout == AVR_PIECES_ROW_BANDS;
     const int64_t n_pixels = info.n_pixels;
-    const bool many = r->n_ranks > 1;
     auto bytes_of = [](int64_t count, int each) {
       return static_cast<size_t>(std::max<int64_t>(count, 1)) * static_cast<size_t>(each);
     };
@@ -832,23 +896,112 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // copies of a repeating camera skipped as well, a rank of eight went from 0.187 to 0.164 ms);
     // at most three frames are then in flight.  One rank's 1 ms frames hide those packets and lose
     // 1-2 % to the shorter queue (measured), so there the streams wait.
-    // avr_renderer_set_host_backpressure.
+    // avr_renderer_set_host_backpressure.  (The waits have the deadline of
+    // avr_set_frame_timeout_ms: the exchange of the frame three back involves every peer.)
     const bool host_side = (r->host_backpressure < 0) ? many : (r->host_backpressure != 0);
+    if (host_side) {
+      if (r->marched_pending[volume]) {
+        r->stage = "back-pressure: the march of the frame three before";
+        avr::wait_event_deadline(r->marched_event[volume], "the march of the frame three before this one");
+      }
+      if (r->composed_pending[slot]) {
+        r->stage = "back-pressure: the exchange and fold of the frame three before";
+        avr::wait_event_deadline(r->composed_event[slot],
+                                 "the exchange / fold of the frame three before this one (compositing "
+                                 "stream: a peer's blocks have not arrived)");
+      }
+    }
+
+    // One rank: the classify pass of the next frame runs beside the march of this one (HBM-bound
+    // beside issue-bound).  A rank's share of an N-rank frame is two SHORT kernels whose time is
+    // their slowest workgroups': side by side each stretched the other (N = 8, slowest rank:
+    // 77 us + 151 us alone, 0.26 + 0.27 ms overlapped), so there they run back to back on the
+    // march stream and only the exchange / fold / gather of the previous frame overlaps them.
+    // Which of the two, and how many classify workgroups a CU admits beside the march, is measured
+    // on the running pipeline (CoRunTuner) unless the caller fixed it: avr_renderer_set_overlap,
+    // avr_renderer_set_classify_share.  (A cached classification leaves nothing to tune.)
+    CoRunTuner& tuner = r->tuner;
+    {
+      // overlap_classify: -1 everything, 0 back to back, 1 side by side, 2 paired
+      int first = CoRunTuner::kBackToBack, last = CoRunTuner::kLastPaired;
+      if (r->cache_classification) {  // no classify pass to place
+        first = last = (r->overlap_classify == 0) ? CoRunTuner::kBackToBack : 0;
+      } else if (r->overlap_classify == 0) {
+        last = first;
+      } else if (r->overlap_classify == 2) {
+        first = CoRunTuner::kPairedBase;
+        if (r->share_fixed >= 0) last = first;  // the caller's reserve, kept outside the scale
+      } else {
+        if (r->overlap_classify > 0) {
+          first = 0;
+          last = CoRunTuner::kLastCandidate;
+        }
+        if (r->share_fixed >= 0) {
+          // one side-by-side candidate: the caller's reserve (kept outside the candidate scale)
+          last = (first == CoRunTuner::kBackToBack) ? 0 : first;
+        }
+      }
+      tuner.restrict_to(first, last, r->n_ranks == 1);
+      // ranks of several search together (avr_corun.h): the same candidate in the same frames,
+      // every window's period the maximum over the ranks
+      tuner.set_coordinated(many && r->comm != nullptr && r->coordinate != 0);
+    }
+    if (tuner.tuning() && tuner.report_due()) {
+      // The window closed kReportLag frames ago (the back-pressure above has seen its last march
+      // through); all ranks are at this frame.  A rank whose window was void (its pipeline had
+      // drained: a buffer grew) says so, and then everybody times the candidate again.
+      r->stage = "co-run window agreement (control plane)";
+      avr::wait_event_deadline(r->window_end, "the march that closes the co-run window");
+      float mine = -1.0f;
+      if (!tuner.window_void) {
+        float elapsed_ms = 0.0f;
+        hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end), "hipEventElapsedTime");
+        mine = elapsed_ms / static_cast<float>(tuner.window_length);
+      }
+      std::vector<float> periods(static_cast<size_t>(r->n_ranks), 0.0f);
+      abi_ok(avr_comm_control_allgather(r->comm, r->compose, &mine, periods.data(), 4));
+      float agreed = 0.0f;
+      bool any_void = false;
+      for (float period : periods) {
+        any_void = any_void || !(period >= 0.0f);
+        agreed = std::max(agreed, period);
+      }
+      if (any_void) {
+        tuner.retime();
+      } else {
+        tuner.report(agreed);
+      }
+    }
+    const bool overlap = tuner.candidate != CoRunTuner::kBackToBack;
+    const bool paired = CoRunTuner::is_paired(tuner.candidate);
+    const int reserve = !overlap ? 0
+                        : (r->share_fixed >= 0)
+                            ? r->share_fixed
+                            : CoRunTuner::reserve_index(tuner.candidate) * CoRunTuner::kReserveStep;
+    // (One stream per kernel kind.  Letting the odd frames take a second march or classify stream
+    // -- the frames are independent, so march(f+1) need not queue behind march(f) and its wait /
+    // record / copy packets could be worked off early -- was measured in round 3 and is worse by
+    // half: with a FOURTH concurrently active queue everything stalls, a 5 us descriptor copy
+    // takes 40-50 us, the frame of a rank of eight goes from 0.187 to 0.26-0.33 ms and the one-rank
+    // frame from 0.98 to 1.25-1.42 ms.  profiles/r3_experiments/.)
+    // Paired layout (avr_corun.h): this frame's classify pass and march back to back on ONE
+    // stream, the even frames on stream M, the odd ones on stream B -- with stream X three active
+    // queues, the number this GPU runs side by side without penalty.
+    avr_context* march_ctx = r->march;
+    if (paired && (r->frame & 1u)) {
+      if (r->pair_b == nullptr) abi_ok(avr_context_create_with_priority(r->device, 1, &r->pair_b));
+      march_ctx = r->pair_b;
+    }
+    avr_context* classify_ctx = paired ? march_ctx : overlap ? r->classify : r->march;
+    abi_ok(avr_context_set_march_occupancy(march_ctx, cap));
+    hipStream_t stream_c = r->stream_of(classify_ctx);
+    hipStream_t stream_m = r->stream_of(march_ctx);
+    hipStream_t stream_x = r->stream_of(r->compose);
     for (avr_context* ctx : {r->classify, r->march, r->compose, r->pair_b}) {
       if (ctx != nullptr) avr::context_set_lean_descriptors(ctx, host_side);
     }
-    auto host_wait = [&](hipEvent_t event) {
-      for (unsigned spins = 0;; ++spins) {
-        const hipError_t status = hipEventQuery(event);
-        if (status == hipSuccess) return;
-        if (status != hipErrorNotReady) hip_ok(status, "hipEventQuery");
-        (void)hipGetLastError();
-        if (spins > 64) std::this_thread::yield();
-      }
-    };
-    if (host_side) {
-      if (r->marched_pending[volume]) host_wait(r->marched_event[volume]);
-      if (r->composed_pending[slot]) host_wait(r->composed_event[slot]);
+    if (r->history.size() < r->history_capacity) {
+      r->history.push_back(static_cast<int16_t>(tuner.candidate));
     }
     struct TimedGuard {  // the frame's four timing events, destroyed unless the frame keeps them
       FrameEvents events;
@@ -888,6 +1041,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     r->pipeline_idle = false;
 
     lap(0);
+    r->stage = "classify";
     // ---- stream C: classify pass of this frame into classified volume `slot` -------------------
     if (input_stream != nullptr) {  // the caller's cell data is produced on that stream
       hipStream_t producer = (input_stream == AVR_DEFAULT_STREAM)
@@ -926,6 +1080,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     r->paired_previous = paired ? r->classified_event[volume] : nullptr;
 
     lap(1);
+    r->stage = "march";
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
     if (overlap && !paired) {  // (paired: the march follows its classify pass on the same stream)
       hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
@@ -935,7 +1090,9 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // the tuner's window: the period of a few frames between two events after the march
     if (tuner.tuning()) {
       if (tuner.closing) {
-        if (hipEventQuery(r->window_end) == hipSuccess) {
+        if (tuner.coordinated) {
+          // (agreed on by all ranks kReportLag frames after the window, above)
+        } else if (hipEventQuery(r->window_end) == hipSuccess) {
           float elapsed_ms = 0.0f;
           hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end),
                  "hipEventElapsedTime");
@@ -969,6 +1126,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
 
     lap(2);
+    r->stage = "exchange";
     // ---- stream X: exchange, fold, gather, frame tail ------------------------------------------
     hip_ok(hipStreamWaitEvent(stream_x, r->marched_event[volume], 0), "hipStreamWaitEvent");
     // (the rank's block for itself is not copied into the receive buffer: the fold reads it
@@ -982,6 +1140,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       own = send;
     }
     lap(3);
+    r->stage = "fold";
     // (one rank without antialiasing or wireframe: the fold writes the output file's rows itself)
     const bool fold_to_image = !many && early_rgb8 && !overlay_piece && is_root;
     if (fold_to_image) {
@@ -998,6 +1157,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     r->composed_pending[slot] = true;
 
     lap(4);
+    r->stage = "gather and frame tail";
     if (early_rgb8) {
       uint8_t* full = piece_rgb8;
       if (many) {
@@ -1036,6 +1196,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     lap(5);
+    r->stage = "queued";
     ++r->host_frames;
     r->pipeline_idle = false;  // (a buffer that grew drained the streams in between)
     return AVR_OK;

@@ -159,6 +159,11 @@ class FrameRenderer:
             import torch.distributed as dist
             try:
                 comm = runtime.Comm.from_process_group(ctx.device_index, process_group)
+                if dist.get_backend(process_group) != "nccl":
+                    # the caller's host-side control plane (gloo; MPI in the reference's host)
+                    # carries the communicator's small agreements -- a new plan's check, the
+                    # co-run search's window decisions -- instead of tiny RCCL rounds in band
+                    comm.set_control(runtime.control_over_process_group(process_group))
             except Exception as error:   # e.g. RCCL not loadable: say so, keep the frame on the GPU
                 # NOT a CPU fallback: the same HIP kernels, with torch.distributed's RCCL
                 # collectives (all_to_all_single / gather) instead of the C++ driver's; every rank

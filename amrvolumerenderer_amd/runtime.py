@@ -646,6 +646,45 @@ class Comm:
 
         return cls(device_index, rank, world, broadcast)
 
+    def set_control(self, allgather_bytes) -> None:
+        """avr_comm_set_control: the caller's control plane for the small host-side agreements of
+        an N-rank frame (a new plan's agreement check, the co-run search's window decisions) --
+        `allgather_bytes(mine: bytes) -> list of n_ranks bytes objects`, e.g. over gloo
+        (control_over_process_group), MPI_Allgather in the reference's host.  None: back to the
+        communicator's own (RCCL flavour: a tiny grouped round in band)."""
+        if allgather_bytes is None:
+            _capi.check(_capi.lib().avr_comm_set_control(self._handle, None, None))
+            self._control = None
+            return
+        n = self.n_ranks
+
+        def trampoline(_user, mine, out, size):
+            try:
+                parts = allgather_bytes(C.string_at(mine, size))
+                if len(parts) != n or any(len(part) != size for part in parts):
+                    return 1
+                C.memmove(out, b"".join(parts), n * size)
+                return 0
+            except Exception:  # noqa: BLE001 -- no exception may cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        callback = _capi.CONTROL_ALLGATHER_FN(trampoline)
+        _capi.check(_capi.lib().avr_comm_set_control(self._handle, callback, None))
+        self._control = callback   # kept alive for as long as the communicator may call it
+
+    def control_allgather(self, mine: bytes, ctx: Optional["Context"] = None):
+        """avr_comm_control_allgather (collective, host-blocking): every rank's bytes."""
+        size = len(mine)
+        out = C.create_string_buffer(size * self.n_ranks)
+        _capi.check(_capi.lib().avr_comm_control_allgather(
+            self._handle, ctx._handle if ctx is not None else None, mine, out, size))
+        return [out.raw[i * size:(i + 1) * size] for i in range(self.n_ranks)]
+
+    def control_rounds(self) -> int:
+        return int(_capi.lib().avr_comm_control_rounds(self._handle))
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             _capi.lib().avr_comm_destroy(self._handle)
@@ -656,6 +695,27 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def control_over_process_group(group=None):
+    """A control plane for Comm.set_control over an initialised torch.distributed group (gloo in
+    bench.py): all_gather of a byte tensor on the CPU."""
+    import torch.distributed as dist
+
+    def allgather(mine: bytes):
+        world = dist.get_world_size(group)
+        local = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        return [bytes(part.numpy().tobytes()) for part in parts]
+
+    return allgather
+
+
+def set_frame_timeout_ms(milliseconds: int) -> None:
+    """avr_set_frame_timeout_ms: deadline of every host wait on device work (0: none, < 0: default
+    = AVR_FRAME_TIMEOUT_MS or 30 s)."""
+    _capi.check(_capi.lib().avr_set_frame_timeout_ms(int(milliseconds)))
 
 
 class NativeRenderer:
@@ -757,6 +817,34 @@ class NativeRenderer:
         return {"classify": layout.get(overlap.value, str(overlap.value)),
                 "lds_reserve_bytes": reserve.value, "settled": bool(settled.value),
                 "timed_windows": windows.value}
+
+    def set_plan_check(self, enabled: bool = True) -> None:
+        """avr_renderer_set_plan_check: whether a new plan of a rank of several is agreed on over
+        the control plane before its first frame is queued (default on)."""
+        _capi.check(_capi.lib().avr_renderer_set_plan_check(self._handle, int(bool(enabled))))
+
+    def set_corun_coordination(self, mode: int = -1) -> None:
+        """avr_renderer_set_corun_coordination: -1 default (ranks of several search as one
+        system), 0 every rank on its own (round 3's behaviour), 1 on."""
+        _capi.check(_capi.lib().avr_renderer_set_corun_coordination(self._handle, int(mode)))
+
+    def set_corun_history(self, frames: int) -> None:
+        """Record the co-run candidate of each of the next `frames` frames (diagnostics)."""
+        _capi.check(_capi.lib().avr_renderer_set_corun_history(self._handle, int(frames)))
+
+    def corun_history(self):
+        """The recorded candidates: -1 back to back, k side by side with reserve k * 2 KiB,
+        29 + k paired."""
+        n = C.c_int(0)
+        _capi.check(_capi.lib().avr_renderer_corun_history(self._handle, None, 0, C.byref(n)))
+        out = (C.c_int16 * max(n.value, 1))()
+        _capi.check(_capi.lib().avr_renderer_corun_history(self._handle, out, n.value, C.byref(n)))
+        return list(out[:n.value])
+
+    def failure(self) -> Optional[str]:
+        """avr_renderer_failure: what did not finish within the deadline, or None."""
+        text = _capi.lib().avr_renderer_failure(self._handle)
+        return text.decode("utf-8", "replace") if text else None
 
     def set_scalar_range(self, scalar_range) -> None:
         rng = (C.c_float * 2)(float(scalar_range[0]), float(scalar_range[1]))

@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--layout", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="avr_renderer_set_overlap: -1 measured by the driver (default), 0 back to "
                          "back, 1 side by side, 2 paired (A/B only)")
+    ap.add_argument("--no-coordination", action="store_true",
+                    help="N > 1, A/B only: every rank runs the co-run search on its own (round 3) "
+                         "instead of all ranks as one system (avr_renderer_set_corun_coordination)")
     ap.add_argument("--no-plan-ahead", action="store_true",
                     help="--fly-through at N > 1: make every frame plan on the thread that queues "
                          "the frames instead of one frame ahead on a helper thread")
@@ -257,6 +260,35 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, sys.argv[1:]))
+    state = {}
+    try:
+        run(args, state)
+    except BaseException as error:  # noqa: BLE001 -- reported, then the process ends at once
+        if isinstance(error, SystemExit) and error.code in (0, None):
+            raise
+        # A frame of several ranks either completes or errors (avr_set_frame_timeout_ms): say which
+        # rank failed where and how its co-run search stood, then leave WITHOUT the interpreter's
+        # shutdown -- a stream that does not move would hang torch's teardown (and with it the job,
+        # until the launcher's own limit); the launcher ends the other ranks.
+        import traceback
+        renderer = state.get("renderer")
+        native = getattr(renderer, "native", None) if renderer is not None else None
+        lines = [f"bench.py: rank {os.environ.get('RANK', '0')} of "
+                 f"{os.environ.get('WORLD_SIZE', '1')} failed: {type(error).__name__}: {error}"]
+        if native is not None:
+            try:
+                lines.append(f"  renderer: {native.failure() or 'not failed (the error came from elsewhere)'}")
+                lines.append(f"  corun_state: {native.corun_state()}")
+            except Exception as inner:  # noqa: BLE001
+                lines.append(f"  (no renderer state: {inner})")
+        print("\n".join(lines), file=sys.stderr, flush=True)
+        traceback.print_exc()
+        sys.stderr.flush()
+        code = error.code if isinstance(error, SystemExit) and isinstance(error.code, int) else 4
+        os._exit(code or 4)
+
+
+def run(args, state):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -318,6 +350,9 @@ def main():
                              march_workgroups_per_cu=args.march_occupancy,
                              stream_priorities=tuple(int(v) for v in args.priorities.split(",")),
                              cache_classification=args.cache_classification)
+    state["renderer"] = renderer
+    if renderer.native is not None and args.no_coordination:
+        renderer.native.set_corun_coordination(0)
     if renderer.native is not None and args.classify_share >= 0:
         renderer.native.set_classify_share(args.classify_share)
     if renderer.native is not None and args.layout >= 0:
@@ -572,6 +607,11 @@ def main():
     roofline["compulsory_frac"] = round(
         roofline["compulsory_bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
 
+    corun_ranks = [renderer.native.corun_state() if native else None]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, corun_ranks[0], group=group)
+        corun_ranks = gathered
     out = {
         "metric": f"Mray-samples/s ({width}x{height} render of {spec.n0}^3-base "
                   f"{spec.levels}-level AMR" + (f", antialiasing {args.antialiasing}"
@@ -597,7 +637,9 @@ def main():
                                   "Python pipeline with torch.distributed RCCL collectives -- the "
                                   f"C++ driver's communicator failed: {renderer.native_error}"),
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
-            "corun": renderer.native.corun_state() if native else None,
+            "corun": corun_ranks[0] if native else None,
+            # N > 1: what every rank's driver holds (searched as one system: the same on all)
+            "corun_ranks": corun_ranks if (native and world > 1) else None,
             "exchange": ({"rank0_send_mb": round(renderer.last_plan.send_floats * 4 / 1e6, 2),
                           "layout": "per-row extents of the runs (avr_frame_plan_tighten)"
                           if native else "run rectangles"} if world > 1 else None),

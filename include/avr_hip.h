@@ -95,6 +95,15 @@ const char *avr_last_error(void);
 /* ABI version of this header (bumped on incompatible change). */
 int avr_abi_version(void);
 
+/* Deadline, in milliseconds, of every host wait on device work inside this library (default: the
+ * environment's AVR_FRAME_TIMEOUT_MS, else 30000; 0 = wait forever; < 0 = back to the default).
+ * The frame of a rank of several contains collectives; the reference's exchange either completes
+ * or errors (MPI_Waitany / MPI_Waitall, DirectSend/Base/DirectSendBase.cpp:206-220, 277).  Here a
+ * wait that outlasts the deadline -- a peer that died, ranks whose calls differ -- makes the call
+ * return AVR_ERR_RUNTIME with avr_last_error() naming what did not finish (stream, frame); the
+ * renderer is then failed for good (every later call returns the error at once; destroy it). */
+int avr_set_frame_timeout_ms(int milliseconds);
+
 /* Creates a context bound to HIP device `device_id` with its own stream.  Replaces the
  * function-local static VolumePainter / DirectSendBase instances of
  * VolumeRenderer/VolumeRenderer.cpp:909-927 (one context per rank = per GPU). */
@@ -476,6 +485,37 @@ void avr_comm_destroy(avr_comm *comm);
 int avr_comm_rank(const avr_comm *comm);
 int avr_comm_size(const avr_comm *comm);
 
+/* Control plane of the communicator: a small host-side allgather among the ranks -- what the
+ * reference does with MPI_Allgather on MPI_COMM_WORLD for its layer counts and depth hints
+ * (DirectSend/Base/DirectSendBase.cpp:329-361).  Used for the agreement check of a new frame plan
+ * (avr_frame_plan_agree) and for the decisions of the frame driver's co-run search, which all
+ * ranks of a frame take together; never per frame.
+ * avr_comm_set_control hands over the caller's own (the reference's host: MPI_Allgather of
+ * bytes_per_rank bytes; bench.py: gloo): allgather(user, mine, all, bytes_per_rank) fills
+ * all[rank * bytes_per_rank ...] for every rank and returns 0.  Without one, the RCCL flavour runs
+ * a grouped round of tiny ncclSend / ncclRecv in band on the given context's stream (host-blocking,
+ * with the deadline of avr_set_frame_timeout_ms); the rehearsal flavours meet in their own memory. */
+#define AVR_CONTROL_MAX_BYTES 2048
+typedef int (*avr_control_allgather_fn)(void *user, const void *mine, void *all, int bytes_per_rank);
+int avr_comm_set_control(avr_comm *comm, avr_control_allgather_fn allgather, void *user);
+/* Collective, host-blocking: bytes (a multiple of 4, <= AVR_CONTROL_MAX_BYTES) of every rank into
+ * all[n_ranks * bytes].  ctx: the context whose stream carries the in-band round (RCCL flavour
+ * without a caller's control plane); may be NULL otherwise. */
+int avr_comm_control_allgather(avr_comm *comm, avr_context *ctx, const void *mine, void *all,
+                               int bytes);
+long avr_comm_control_rounds(const avr_comm *comm); /* control-plane calls so far (diagnostics) */
+/* Do the ranks' plans of one frame describe ONE exchange?  Collective over the control plane: every
+ * rank contributes a digest of the plan's replicated part (image, pieces, group order, runs, layer
+ * order) mixed with settings_digest (whatever else the caller requires to be equal on all ranks)
+ * and its send / receive block sizes; every rank then checks the whole matrix -- rank a's block
+ * for rank b must be what b expects from a -- and so every rank reaches the same verdict:
+ * AVR_OK, or AVR_ERR_RUNTIME (naming the first pair that disagrees) on ALL of them, before
+ * anything has been queued.  A grouped ncclSend / ncclRecv round whose two sides disagree on a
+ * size never ends; the reference finds out from the metadata message of every transfer
+ * (Common/Image.cpp:62-90).  The frame driver calls it once per new plan (avr_renderer_set_plan_check). */
+int avr_frame_plan_agree(const avr_frame_plan *plan, avr_comm *comm, avr_context *ctx,
+                         uint64_t settings_digest);
+
 /* The sparse all-to-all of one frame (layout: "frame plan" above): block for peer s of `send` goes
  * to rank s, `recv` receives the blocks of all ranks for this rank's piece.  Collective; on the
  * context's stream. */
@@ -582,6 +622,31 @@ int avr_renderer_set_tighten(avr_renderer *renderer, int enabled);
  * partition.  band_rows: a power of two.  The same on every rank.  Never changes results. */
 int avr_renderer_set_piece_layout(avr_renderer *renderer, int piece_layout, int band_rows);
 int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *out);
+/* Ranks of several, fail-fast and tuned as ONE system (round 4).
+ * avr_renderer_set_plan_check (default 1): the first frame of a NEW plan (and the first after one
+ *   of the setters the ranks must agree on) runs avr_frame_plan_agree over the communicator's
+ *   control plane before anything is queued; ranks whose plans or settings differ all get
+ *   AVR_ERR_RUNTIME there instead of hanging in the exchange.  0: no check (a caller whose camera
+ *   never repeats and who vouches for its ranks).
+ * avr_renderer_set_corun_coordination (default -1 = on for ranks of several): the co-run search
+ *   (avr_renderer_set_classify_share) holds the same candidate on every rank in the same frames
+ *   and decides on the MAXIMUM of the ranks' window periods (one 4-byte control-plane allgather
+ *   per window, three frames after the window's last); the held candidate is re-timed every
+ *   half second.  0: every rank searches on its own (round 3).  A run that wants no search at all
+ *   fixes layout and reserve: avr_renderer_set_overlap + avr_renderer_set_classify_share.
+ * avr_renderer_set_corun_history / avr_renderer_corun_history: the candidate of each of the next
+ *   `frames` frames (-1 back to back, k >= 0 side by side with reserve k * 2 KiB, 29 + k paired),
+ *   for tests and the multi-rank rehearsal.
+ * avr_renderer_failure: NULL, or what did not finish within the deadline of
+ *   avr_set_frame_timeout_ms (stream, rank, frame, stage, co-run state); the renderer is then
+ *   failed: every call returns AVR_ERR_RUNTIME with that message, avr_renderer_destroy releases
+ *   host memory only (device memory and streams of a hung GPU queue are left to process exit). */
+int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
+int avr_renderer_set_corun_coordination(avr_renderer *renderer, int mode);
+int avr_renderer_set_corun_history(avr_renderer *renderer, int frames);
+int avr_renderer_corun_history(const avr_renderer *renderer, int16_t *candidates_out, int capacity,
+                               int *frames_out);
+const char *avr_renderer_failure(const avr_renderer *renderer);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream: a HIP stream whose queued work
  * produces the cell data (or zeroes samples_out); the classify pass, and with it the march, is

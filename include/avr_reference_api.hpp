@@ -292,7 +292,11 @@ std::vector<float> compose_single_rank(Context& context, LayeredT& layers, int64
 //   void allgather_int(int value, int* out);                               // MPI_Allgather
 //   void allgatherv_float(const float* in, int n, float* out, const int* counts,
 //                         const int* displs);                              // MPI_Allgatherv
+//   void allgather_bytes(const void* mine, void* all, int bytes);          // MPI_Allgather, MPI_BYTE
 //   std::vector<int> group_ranks(GroupT group);   // ranks of the ordered group, MPI_Group_translate_ranks
+// allgather_bytes also becomes the communicator's own control plane (avr_comm_set_control): the
+// agreement check of every new frame plan and the decisions of the frame driver's co-run search
+// travel over it, so `control` must outlive the Communicator.
 class Communicator {
  public:
   Communicator() = default;
@@ -318,6 +322,22 @@ class Communicator {
                                                : failure);
     }
     check(avr_comm_create(device, id, control.rank(), control.size(), &comm_));
+    use_control(control);
+  }
+  // The small host-side agreements of an N-rank frame go through the caller's control plane.
+  template <class Control>
+  void use_control(Control& control) {
+    check(avr_comm_set_control(
+        comm_,
+        [](void* user, const void* mine, void* all, int bytes) -> int {
+          try {
+            static_cast<Control*>(user)->allgather_bytes(mine, all, bytes);
+            return 0;
+          } catch (...) {
+            return 1;
+          }
+        },
+        &control));
   }
   // n connected in-process communicators (one GPU, one host thread per rank): rehearsal only.
   static std::vector<std::unique_ptr<Communicator>> local(int n_ranks) {
@@ -512,6 +532,10 @@ class HipDirectSend {
     std::unique_ptr<avr_frame_plan, void (*)(avr_frame_plan*)> plan_guard(plan, avr_frame_plan_destroy);
     avr_frame_plan_info info{};
     check(avr_frame_plan_get_info(plan, &info));
+    // every rank built its plan from the same allgathered hints: checked before anything is
+    // queued, because an exchange whose two sides disagree on a block size never ends (the
+    // reference learns the sizes from a metadata message per transfer, Common/Image.cpp:62-90)
+    if (n_ranks > 1) check(avr_frame_plan_agree(plan, comm_->get(), context_.get(), 0));
     // the local layers in HBM (device-resident ones in place), then the owner-side run fold into
     // the send layout
     const std::size_t floats = static_cast<std::size_t>(width) * height * 5;
@@ -680,6 +704,9 @@ class FrameDriver {
     check(avr_renderer_prepare(renderer_, &params, &camera, group_order));
   }
   void synchronize() { check(avr_renderer_synchronize(renderer_)); }
+  // NULL, or what did not finish within the deadline (avr_set_frame_timeout_ms): the renderer is
+  // then failed for good -- report it (MPI_Abort in the reference's main, main.cpp:27-33) and exit.
+  const char* failure() const { return avr_renderer_failure(renderer_); }
 
  private:
   avr_renderer* renderer_ = nullptr;

@@ -13,6 +13,7 @@
 //     rehearsal communicator; `frames` frames are rendered back to back without synchronising.
 //   adapter_test compose_ranks layers.bin n_layers n_ranks W H hints.bin owners.bin group.bin out.bin
 //     Compositor::compose of a LayeredVolumeImage per rank (avr::HipDirectSend), threads as ranks.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -188,6 +189,17 @@ struct ThreadControl {
     std::copy(world->floats.begin(), world->floats.begin() + total, out);
     world->barrier();
   }
+  void allgather_bytes(const void* mine, void* all, int n_bytes) {
+    {
+      std::lock_guard<std::mutex> lock(world->mutex);
+      world->bytes.resize(static_cast<size_t>(world->n) * static_cast<size_t>(n_bytes));
+      std::memcpy(world->bytes.data() + static_cast<size_t>(my_rank) * static_cast<size_t>(n_bytes), mine,
+                  static_cast<size_t>(n_bytes));
+    }
+    world->barrier();
+    std::memcpy(all, world->bytes.data(), static_cast<size_t>(world->n) * static_cast<size_t>(n_bytes));
+    world->barrier();
+  }
   std::vector<int> group_ranks(const std::vector<int>& group) { return group; }
 };
 
@@ -333,6 +345,9 @@ int main(int argc, char** argv) {
       avr::DeviceBuffer<float> image(n_pixels * 5 + 1);
       avr::DeviceBuffer<unsigned char> bytes(n_pixels * 3 + 1);
       std::vector<std::string> errors(static_cast<size_t>(n_ranks));
+      // the co-run candidate every rank's driver held in every frame: ranks of several search as
+      // one system, so the rows must be equal (avr_renderer_set_corun_history)
+      std::vector<std::vector<int16_t>> held(static_cast<size_t>(n_ranks));
       std::vector<std::thread> threads;
       for (int r = 0; r < n_ranks; ++r) {
         threads.emplace_back([&, r] {
@@ -340,6 +355,7 @@ int main(int argc, char** argv) {
             avr::hip_ok(hipSetDevice(0), "hipSetDevice");
             avr::FrameDriver driver(0, r, n_ranks, n_ranks > 1 ? comms[static_cast<size_t>(r)].get() : nullptr,
                                     boxes, owner, transform, bmin, bmax);
+            avr::check(avr_renderer_set_corun_history(driver.get(), frames));
             // pipelined: no synchronisation between the frames.  Every third frame before the
             // last looks from elsewhere: the camera then comes back to a cached plan (whose
             // exchange layout the driver tightens on that second use).
@@ -361,6 +377,11 @@ int main(int argc, char** argv) {
               if (planned.valid()) planned.get();
             }
             driver.synchronize();
+            int recorded = 0;
+            held[static_cast<size_t>(r)].resize(static_cast<size_t>(frames));
+            avr::check(avr_renderer_corun_history(driver.get(), held[static_cast<size_t>(r)].data(), frames,
+                                                  &recorded));
+            if (recorded != frames) throw std::runtime_error("co-run history is incomplete");
           } catch (const std::exception& e) {
             errors[static_cast<size_t>(r)] = e.what();
           }
@@ -369,6 +390,18 @@ int main(int argc, char** argv) {
       for (std::thread& t : threads) t.join();
       for (const std::string& e : errors) {
         if (!e.empty()) throw std::runtime_error("rank failed: " + e);
+      }
+      for (int r = 1; r < n_ranks; ++r) {
+        if (held[static_cast<size_t>(r)] != held[0]) {
+          throw std::runtime_error("rank " + std::to_string(r) +
+                                   " held other co-run candidates than rank 0: the search is not coordinated");
+        }
+      }
+      {
+        std::vector<int16_t> distinct(held[0]);
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        std::printf("corun candidates held: %zu distinct over %d frames\n", distinct.size(), frames);
       }
       std::vector<float> host_image(n_pixels * 5);
       std::vector<unsigned char> host_bytes(n_pixels * 3);
@@ -418,6 +451,13 @@ int main(int argc, char** argv) {
             std::call_once(once, [&] { comms = avr::Communicator::local(n_ranks); });
             world.barrier();
             avr::HipDirectSend<standin::ThreadControl> compositor(control, 0, comms[static_cast<size_t>(r)].get());
+            // the agreement check of the compose's plan travels over the CALLER's control plane
+            // (MPI_Allgather in the reference's host), as with a communicator built from it
+            comms[static_cast<size_t>(r)]->use_control(control);
+            struct Unhook {
+              avr_comm* comm;
+              ~Unhook() { (void)avr_comm_set_control(comm, nullptr, nullptr); }
+            } unhook{comms[static_cast<size_t>(r)]->get()};
             // the caller holds an `Image*` (Compositor::compose's argument): the layered image is
             // found by dynamic_cast as in DirectSendBase.cpp:288-298.  Three frames: after the
             // first the pooled buffers have their size and nothing is allocated any more.

@@ -300,6 +300,82 @@ int main() {
     expect(t.settled() && run.candidate == 12,
            "the best reserve survives one unlucky window, got " + std::to_string(run.candidate));
   }
+  {  // ranks of several search as ONE system (round 4): eight tuners in lockstep -- the frame
+     // driver's protocol (avr_renderer.cpp) played on the CPU.  Each rank has its own curve (its
+     // own load), what is reported is the MAXIMUM over the ranks, agreed kReportLag frames after
+     // the window; a drain that hits ONE rank (a buffer grew) voids that rank's window and all
+     // ranks time the candidate again.  Every rank must hold the same candidate in EVERY frame and
+     // settle where the slowest rank's period is least.
+    const int n = 8;
+    std::vector<CoRunTuner> ranks(n);
+    for (CoRunTuner& t : ranks) {
+      t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastPaired, false);
+      t.set_coordinated(true);
+    }
+    auto local = [](int rank, int c) {  // rank r's own period under candidate c
+      const float load = 1.0f + 0.02f * static_cast<float>(rank);  // rank 7 is the slowest
+      if (!CoRunTuner::is_paired(c)) return load * (eighth(c) - 0.007f);
+      const float kib = 2.0f * static_cast<float>(CoRunTuner::reserve_index(c));
+      // the lightly loaded ranks would like a large reserve, the heavy ones a small one
+      const float best = 24.0f - 2.0f * static_cast<float>(rank);
+      return load * (0.145f + 0.0006f * std::fabs(kib - best));
+    };
+    bool lockstep = true;
+    int voided = 0, frames = 0;
+    long agreements = 0;
+    for (int frame = 1; frame <= 20000 && !ranks[0].settled(); ++frame, ++frames) {
+      // rank 3's pipeline drains now and then (only its own window suffers)
+      if (frame % 997 == 0) ranks[3].drained();
+      // --- top of the frame: the agreement, if due (the same frame on every rank)
+      int due = 0;
+      for (CoRunTuner& t : ranks) due += (t.tuning() && t.report_due()) ? 1 : 0;
+      lockstep = lockstep && (due == 0 || due == n);
+      if (due == n) {
+        ++agreements;
+        float agreed = 0.0f;
+        bool any_void = false;
+        for (int r = 0; r < n; ++r) {
+          if (ranks[r].window_void) any_void = true;
+          agreed = std::max(agreed, local(r, ranks[r].candidate));
+        }
+        if (any_void) ++voided;
+        for (CoRunTuner& t : ranks) {
+          if (any_void) {
+            t.retime();
+          } else {
+            t.report(agreed);
+          }
+        }
+      }
+      // --- the frame is queued with the candidate every rank now holds
+      for (int r = 1; r < n; ++r) lockstep = lockstep && ranks[r].candidate == ranks[0].candidate;
+      // --- after the march: window events
+      for (CoRunTuner& t : ranks) {
+        if (t.tuning() && !t.closing) (void)t.frame();
+      }
+    }
+    expect(lockstep, "coordinated: every rank holds the same candidate in every frame");
+    expect(ranks[0].settled(), "coordinated: the search settles");
+    expect(voided >= 1, "coordinated: a window void on one rank was timed again by all");
+    // the slowest rank (7: load 1.14, wants 10 KiB) decides: max over ranks is least near 10-14 KiB
+    const int held = ranks[0].candidate;
+    expect(CoRunTuner::is_paired(held) && CoRunTuner::reserve_index(held) >= 4 &&
+               CoRunTuner::reserve_index(held) <= 8,
+           "coordinated: settles where the MAXIMUM over the ranks is least, got " + std::to_string(held));
+    // the hold is re-timed by time, not by frames: 500 ms of 0.165 ms frames
+    expect(ranks[0].hold_frames() > 2500 && ranks[0].hold_frames() < 4000,
+           "coordinated: the held candidate is re-timed every half second, frames " +
+               std::to_string(ranks[0].hold_frames()));
+    (void)agreements;
+    (void)frames;
+  }
+  {  // uncoordinated, the same eight ranks -- each reading the period of whatever the OTHERS hold
+     // just then -- is what round 3 did; the coordinated flag off must leave that logic untouched
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, false);
+    expect(!t.coordinated && t.hold_frames() == CoRunTuner::kHoldFrames && !t.report_due(),
+           "one rank / uncoordinated: frame-count hold, no agreement frames");
+  }
   if (failures == 0) std::printf("ok\n");
   return failures == 0 ? 0 : 1;
 }

@@ -62,6 +62,9 @@ def test_adapter_single_rank_compose(O, avr_lib, tmp_path):
     (3, "round_robin", 1, 330),
     # more ranks than the image has pieces of whole rows, and as many ranks as a node has GPUs
     (5, "morton", 1, 3), (8, "round_robin", 1, 40), (8, "morton", 4, 3),
+    # eight ranks (a node's GPUs) through a good part of the co-run search: all eight drivers must
+    # hold the same candidate in every frame (the executable checks the recorded histories)
+    (8, "level_pairs", 1, 700),
     # the ownership bench.py uses for N > 1
     (4, "level_pairs", 1, 3), (8, "level_pairs", 1, 3)])
 def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, policy,
@@ -87,9 +90,13 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
             fh.write(struct.pack("<6d", *b.min_corner, *b.max_corner))
             fh.write(struct.pack("<4i", c.shape[2], c.shape[1], c.shape[0], b.owner))
             fh.write(np.ascontiguousarray(c, dtype="<f8").tobytes())
-    subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
-                    str(transparency), str(antialiasing), str(frames), str(tmp_path / "image.bin"),
-                    str(tmp_path / "rgb8.bin")], check=True, timeout=180)
+    done = subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
+                           str(transparency), str(antialiasing), str(frames),
+                           str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin")], check=True,
+                          timeout=300, stdout=subprocess.PIPE, text=True)
+    if frames >= 330 and n_ranks > 1:   # the search moved, and it moved on every rank alike
+        distinct = int(done.stdout.split("corun candidates held:")[1].split()[0])
+        assert distinct >= 5, done.stdout
     want, _, _ = O.compose_layered(layers, hints, owners, local_indices(owners, n_ranks), n_ranks)
     if root > 1:
         want = O.downsample(want, W, H, root).reshape(-1, 5)

@@ -239,6 +239,12 @@ def test_native_rccl_exchange_and_gather_with_one_rank(O):
     info = _capi.FramePlanInfo()
     _capi.check(L.avr_frame_plan_get_info(plan, C.byref(info)))
     assert info.n_runs_total == 1 and info.send_floats == W * H * 5 == info.recv_floats
+    # the communicator's in-band control plane (no caller's allgather installed): a grouped round
+    # of tiny ncclSend / ncclRecv on the context's stream -- here to the rank itself
+    word = bytes(range(16))
+    assert comm.control_allgather(word, ctx) == [word]
+    _capi.check(L.avr_frame_plan_agree(plan, comm._handle, ctx._handle, 7))
+    assert comm.control_rounds() == 2
     dev = [torch.from_numpy(np.ascontiguousarray(l)).to(ctx.device) for l in layers]
     pointers = (C.c_void_p * n_layers)(*[t.data_ptr() for t in dev])
     with torch.cuda.stream(ctx.stream):
@@ -340,6 +346,169 @@ def test_native_driver_across_processes(tmp_path, world, policy, antialiasing):
              nprocs=world, join=True)
     flags = out.read_text().split()
     assert len(flags) == 6 and all(f == "1" for f in flags), flags
+
+
+def _failfast_worker(rank, world, port, name, mode, out_dir):
+    """A rank process of the fail-fast rehearsal (test_ranks_fail_fast_...)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amrvolumerenderer_amd import _capi, runtime, scenes
+        from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+        from helpers import device_box
+
+        runtime.set_frame_timeout_ms(3000)
+        spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+        scenes.assign_owners(spec, world, "level_pairs")
+        ctx = runtime.Context(0)
+        cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+        meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+        local = [device_box(ctx, cells[i], spec.boxes[i].min_corner, spec.boxes[i].max_corner,
+                            spec.boxes[i].level, rank)
+                 for i in scenes.local_box_indices(spec, rank)]
+        comm = runtime.Comm.shared(name, rank, world, 64 << 20)
+        renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
+                                 rank, world, dist.group.WORLD, comm=comm)
+        p = RenderParameters(W, H, 0.85, 1)
+        good = scenes.default_camera()
+        for _ in range(3):   # the ranks agree: frames run
+            renderer.render(p, good)
+        renderer.synchronize()
+        rounds_before = comm.control_rounds()
+        begin = time.monotonic()
+        error = ""
+        try:
+            if mode == "different_plan":
+                # rank 1 is handed another camera: its plan describes another exchange
+                renderer.render(p, scenes.orbit_camera(5) if rank == 1 else good)
+                renderer.synchronize()
+            elif rank != 1:   # "missing_rank": rank 1 simply stops rendering
+                for _ in range(6):
+                    renderer.render(p, good)
+                renderer.synchronize()
+        except _capi.AvrError as failure:
+            error = str(failure)
+        elapsed = time.monotonic() - begin
+        failed = renderer.native.failure() or ""
+        later = ""
+        if error:
+            try:   # a failed renderer refuses further frames at once
+                renderer.render(p, good)
+            except _capi.AvrError as failure:
+                later = str(failure)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+            fh.write("\n".join([error.replace("\n", " "), f"{elapsed:.3f}", failed.replace("\n", " "),
+                                later.replace("\n", " "),
+                                str(comm.control_rounds() - rounds_before)]))
+        dist.barrier()
+        renderer.native.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["different_plan", "missing_rank"])
+def test_ranks_fail_fast_instead_of_hanging(tmp_path, mode):
+    """The N-rank frame completes or errors (DirectSendBase.cpp:206-220, 277), three rank
+    processes over the shared-memory rehearsal communicator:
+    * one rank is handed a deliberately different plan (another camera): the agreement check of a
+      new plan (avr_frame_plan_agree, one control-plane allgather) makes EVERY rank return an
+      error before anything of that frame is queued -- no hang, no deadline needed;
+    * one rank stops rendering: its peers' waits run into AVR_FRAME_TIMEOUT_MS (3 s here) and
+      return an error naming rank, frame, stage and co-run state; the renderer is failed for good."""
+    world = 3
+    name = f"/avr_failfast_{os.getpid()}_{mode}"
+    mp.spawn(_failfast_worker, args=(world, _free_port(), name, mode, str(tmp_path)),
+             nprocs=world, join=True)
+    for rank in range(world):
+        error, elapsed, failed, later, rounds = (tmp_path / f"rank{rank}.txt").read_text().split("\n")
+        if mode == "different_plan":
+            assert "frame plan: rank 1's plan differs from rank 0's" in error, (rank, error)
+            assert float(elapsed) < 2.0 and failed == "" and int(rounds) == 1
+        elif rank == 1:
+            assert error == ""
+        else:
+            assert "AVR_FRAME_TIMEOUT_MS" in error and f"rank {rank} of 3" in error, (rank, error)
+            assert "stage:" in error and "co-run:" in error
+            assert 2.5 < float(elapsed) < 12.0, elapsed
+            assert failed == error and later == error
+
+
+def _lockstep_worker(rank, world, port, name, frames, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import json
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from amrvolumerenderer_amd import runtime, scenes
+        from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+        from helpers import device_box
+
+        spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+        scenes.assign_owners(spec, world, "level_pairs")
+        ctx = runtime.Context(0)
+        cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+        meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+        local = [device_box(ctx, cells[i], spec.boxes[i].min_corner, spec.boxes[i].max_corner,
+                            spec.boxes[i].level, rank)
+                 for i in scenes.local_box_indices(spec, rank)]
+        comm = runtime.Comm.shared(name, rank, world, 64 << 20)
+        renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
+                                 rank, world, dist.group.WORLD, comm=comm)
+        native = renderer.native
+        native.set_corun_history(frames)
+        p = RenderParameters(W, H, 0.85, 1)
+        cam = scenes.default_camera()
+        first = None
+        for f in range(frames):
+            if rank == 2 and f in (57, 131):
+                native.synchronize()   # ONE rank's pipeline drains: only its window is void
+            out = renderer.render(p, cam)
+            first = first or out
+        renderer.synchronize()
+        last = renderer.render(p, cam)
+        renderer.synchronize()
+        same = bool(rank != 0 or torch.equal(first[1], last[1]))
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+            json.dump({"history": native.corun_history(), "state": native.corun_state(),
+                       "rounds": comm.control_rounds(), "same": same}, fh)
+        dist.barrier()
+        native.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_search_their_corun_layout_as_one_system(tmp_path):
+    """Four rank processes on one GPU (the box admits six processes on the card; eight ranks as
+    threads: tests/cxx/adapter_test): the co-run search is coordinated -- every rank holds the same
+    candidate in EVERY frame, although one rank's pipeline drains on its own twice, and the windows'
+    periods are agreed on over the control plane (one allgather per window).  Scheduling only:
+    the frames stay the same."""
+    import json
+    world, frames = 4, 400
+    name = f"/avr_lockstep_{os.getpid()}"
+    mp.spawn(_lockstep_worker, args=(world, _free_port(), name, frames, str(tmp_path)),
+             nprocs=world, join=True)
+    got = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
+    assert all(g["same"] for g in got)
+    assert len(got[0]["history"]) == frames
+    for r in range(1, world):
+        assert got[r]["history"] == got[0]["history"], f"rank {r} held other candidates than rank 0"
+        assert got[r]["state"] == got[0]["state"]
+        assert got[r]["rounds"] == got[0]["rounds"]
+    assert len(set(got[0]["history"])) >= 5, "the search moved through its candidates"
+    windows = got[0]["state"]["timed_windows"]
+    # one control-plane round per timed or void window, plus the plan agreement
+    assert windows >= 10 and got[0]["rounds"] >= windows + 1
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3])
