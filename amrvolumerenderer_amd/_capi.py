@@ -240,6 +240,7 @@ SIGNATURES = {
     "avr_renderer_timings": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "avr_set_frame_timeout_ms": (C.c_int, [C.c_int]),
+    "avr_debug_stall_stream": (C.c_int, [_vp, C.c_int]),
     "avr_comm_set_control": (C.c_int, [_vp, _vp, _vp]),
     "avr_comm_control_allgather": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "avr_comm_control_rounds": (C.c_long, [_vp]),

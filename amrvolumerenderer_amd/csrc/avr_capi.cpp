@@ -504,6 +504,13 @@ const char* avr_last_error(void) { return avr::g_last_error.c_str(); }
 
 int avr_abi_version(void) { return 1; }
 
+int avr_debug_stall_stream(void* hip_stream, int milliseconds) {
+  return guarded([&]() -> int {
+    require(milliseconds >= 1 && milliseconds <= 2000, "milliseconds must be in [1, 2000]");
+    return avr::launch_stall(milliseconds, hip_stream);
+  });
+}
+
 int avr_set_frame_timeout_ms(int milliseconds) {
   avr::set_frame_timeout_ms(milliseconds);
   return AVR_OK;

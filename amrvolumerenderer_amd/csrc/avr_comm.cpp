@@ -108,11 +108,21 @@ struct LocalWorld {
   std::vector<std::vector<int64_t>> offsets;  // byte offset of the block for each peer
   std::vector<std::vector<int64_t>> sizes;    // byte size of the block for each peer
   std::vector<std::vector<unsigned char>> control;  // avr_comm_control_allgather
+  std::vector<std::pair<uint32_t, uint64_t>> tags;  // which collective each rank is in (meet)
 
   // Every rank arrives, or the wait gives up (AVR_FRAME_TIMEOUT_MS): a rank thread that died must
   // not leave its peers waiting.
+  // (a meeting that timed out for one rank is over for all: its count is off for good, so the
+  // world is marked broken and every later or pending meeting ends in the same error at once)
+  bool broken = false;
   void barrier() {
     std::unique_lock<std::mutex> lock(mutex);
+    const int limit_ms = frame_timeout_ms();
+    auto gone = [&] {
+      return DeadlineExceeded("local communicator: a peer did not arrive within " +
+                              std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
+    };
+    if (broken) throw gone();
     const uint64_t mine = generation;
     if (++waiting == n_ranks) {
       waiting = 0;
@@ -120,16 +130,57 @@ struct LocalWorld {
       arrived.notify_all();
       return;
     }
-    const int limit_ms = frame_timeout_ms();
+    auto released = [&] { return generation != mine || broken; };
     if (limit_ms <= 0) {
-      arrived.wait(lock, [&] { return generation != mine; });
-    } else if (!arrived.wait_for(lock, std::chrono::milliseconds(limit_ms),
-                                 [&] { return generation != mine; })) {
-      throw DeadlineExceeded("local communicator: a peer did not arrive within " +
-                             std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
+      arrived.wait(lock, released);
+    } else if (!arrived.wait_for(lock, std::chrono::milliseconds(limit_ms), released)) {
+      broken = true;
+      arrived.notify_all();
+    }
+    if (generation == mine) throw gone();
+  }
+  // First meeting of a collective: every rank says which one it is in, and all must say the same
+  // -- a rehearsal in which an exchange and a control round paired up silently would rehearse
+  // nothing (over RCCL such ranks never get out of their rounds: the deadline ends those).
+  void meet(int me, uint32_t kind, uint64_t detail);
+};
+
+const char* collective_name(uint32_t kind) {
+  switch (kind) {
+    case 1: return "the frame's exchange";
+    case 2: return "the classic direct send";
+    case 3: return "the gather";
+    case 4: return "a control-plane allgather";
+    default: return "an unknown collective";
+  }
+}
+
+// (every rank reaches this verdict from the same tags: nobody goes on to the collective's second
+// meeting, so whoever catches it must not either)
+struct CallsDiffer : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+[[noreturn]] void calls_differ(int me, uint32_t mine, int other, uint32_t theirs) {
+  throw CallsDiffer("the ranks' calls differ: rank " + std::to_string(other) + " is in " +
+                           collective_name(theirs) + " while rank " + std::to_string(me) + " is in " +
+                           collective_name(mine) + " (the ranks were not driven alike)");
+}
+
+void LocalWorld::meet(int me, uint32_t kind, uint64_t detail) {
+  {
+    std::lock_guard<std::mutex> lock(mutex);
+    tags[static_cast<size_t>(me)] = {kind, detail};
+  }
+  barrier();
+  for (int s = 0; s < n_ranks; ++s) {
+    for (int t = 0; t < n_ranks; ++t) {  // every rank scans all pairs: the same verdict everywhere
+      if (tags[static_cast<size_t>(s)] != tags[static_cast<size_t>(t)]) {
+        const int other = (tags[static_cast<size_t>(s)] != tags[static_cast<size_t>(me)]) ? s : t;
+        calls_differ(me, kind, other, tags[static_cast<size_t>(other)].first);
+      }
     }
   }
-};
+}
 
 // ---- cross-process rehearsal communicator --------------------------------------------------
 // N rank PROCESSES sharing one GPU meet in a POSIX shared-memory segment: a header with a
@@ -144,6 +195,8 @@ struct SharedHeader {
   int64_t offsets[kMaxRanks][kMaxRanks];  // [source][peer]: byte offset inside the source's region
   int64_t sizes[kMaxRanks][kMaxRanks];
   unsigned char control[kMaxRanks][AVR_CONTROL_MAX_BYTES];  // avr_comm_control_allgather
+  uint64_t tag_kind[kMaxRanks], tag_detail[kMaxRanks];       // which collective each rank is in
+  std::atomic<uint32_t> broken;  // a meeting timed out for some rank: over for all, for good
 };
 
 struct SharedWorld {
@@ -162,10 +215,30 @@ struct SharedWorld {
     if (mapping != nullptr) (void)munmap(mapping, mapped_bytes);
     if (owner) (void)shm_unlink(name.c_str());
   }
+  // First meeting of a collective (LocalWorld::meet): all ranks must be in the same one.
+  void meet(int me, uint32_t kind, uint64_t detail) {
+    SharedHeader* h = header();
+    h->tag_kind[me] = kind;
+    h->tag_detail[me] = detail;
+    barrier();
+    for (int s = 0; s < n_ranks; ++s) {
+      for (int t = 0; t < n_ranks; ++t) {
+        if (h->tag_kind[s] != h->tag_kind[t] || h->tag_detail[s] != h->tag_detail[t]) {
+          const int other = (h->tag_kind[s] != kind || h->tag_detail[s] != detail) ? s : t;
+          calls_differ(me, kind, other, static_cast<uint32_t>(h->tag_kind[other]));
+        }
+      }
+    }
+  }
   // Every rank arrives, or the wait gives up: a rehearsal must not hang a GPU box.
   void barrier(int limit_ms = -1) {
     if (limit_ms < 0) limit_ms = frame_timeout_ms();
     SharedHeader* h = header();
+    auto gone = [&] {
+      return DeadlineExceeded("shared communicator: a peer did not arrive within " +
+                              std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
+    };
+    if (h->broken.load(std::memory_order_acquire) != 0) throw gone();
     const uint32_t mine = h->generation.load(std::memory_order_acquire);
     if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == static_cast<uint32_t>(n_ranks)) {
       h->arrived.store(0, std::memory_order_relaxed);
@@ -175,9 +248,12 @@ struct SharedWorld {
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(limit_ms);
     for (unsigned spins = 0; h->generation.load(std::memory_order_acquire) == mine; ++spins) {
       if (spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(20));
-      if (limit_ms > 0 && (spins & 255u) == 255u && std::chrono::steady_clock::now() > deadline) {
-        throw DeadlineExceeded("shared communicator: a peer did not arrive within " +
-                               std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS)");
+      if ((spins & 255u) == 255u) {
+        if (h->broken.load(std::memory_order_acquire) != 0) throw gone();
+        if (limit_ms > 0 && std::chrono::steady_clock::now() > deadline) {
+          h->broken.store(1, std::memory_order_release);
+          throw gone();
+        }
       }
     }
   }
@@ -280,6 +356,7 @@ int avr_comm_create_local(int n_ranks, avr_comm** out_comms) {
     world->offsets.resize(static_cast<size_t>(n_ranks));
     world->sizes.resize(static_cast<size_t>(n_ranks));
     world->control.resize(static_cast<size_t>(n_ranks));
+    world->tags.assign(static_cast<size_t>(n_ranks), {0u, 0ull});
     for (int r = 0; r < n_ranks; ++r) {
       auto* comm = new avr_comm();
       comm->rank = r;
@@ -449,7 +526,7 @@ int avr_comm_control_allgather(avr_comm* comm, avr_context* ctx, const void* min
     if (comm->shared) {
       avr::SharedWorld& world = *comm->shared;
       std::memcpy(world.header()->control[me], mine, each);
-      world.barrier();
+      world.meet(me, 4, each);
       for (int s = 0; s < n; ++s) {
         std::memcpy(out + static_cast<size_t>(s) * each, world.header()->control[s], each);
       }
@@ -463,7 +540,7 @@ int avr_comm_control_allgather(avr_comm* comm, avr_context* ctx, const void* min
         world.control[static_cast<size_t>(me)].assign(static_cast<const unsigned char*>(mine),
                                                       static_cast<const unsigned char*>(mine) + each);
       }
-      world.barrier();
+      world.meet(me, 4, each);
       for (int s = 0; s < n; ++s) {
         if (world.control[static_cast<size_t>(s)].size() != each) {
           throw std::runtime_error("control plane: the ranks' calls differ (message sizes)");
@@ -566,6 +643,7 @@ int avr_frame_plan_agree(const avr_frame_plan* plan, avr_comm* comm, avr_context
     std::copy(plan->recv_splits.begin(), plan->recv_splits.end(), mine.begin() + 1 + n);
     const int status = avr_comm_control_allgather(comm, ctx, mine.data(), all.data(), bytes);
     if (status != AVR_OK) return status;
+    plan->agreed_digest = digest;
     if (comm->solo) return AVR_OK;  // (alone: nobody to agree with)
     const size_t row = 1 + 2 * un;
     for (size_t a = 1; a < un; ++a) {  // every rank scans the same matrix: the same verdict everywhere
@@ -682,7 +760,15 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
       } catch (...) {
         failure = std::current_exception();
       }
-      world.barrier();
+      try {
+        world.meet(me, 1, 0);
+      } catch (const avr::CallsDiffer&) {
+        throw;
+      } catch (const avr::DeadlineExceeded&) {
+        throw;
+      } catch (...) {
+        if (!failure) failure = std::current_exception();
+      }
       try {
         if (failure) std::rethrow_exception(failure);
         for (int s = 0; s < n; ++s) {
@@ -714,11 +800,11 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
         world.offsets[static_cast<size_t>(me)][static_cast<size_t>(s)] = send_at[static_cast<size_t>(s)] * 4;
         world.sizes[static_cast<size_t>(me)][static_cast<size_t>(s)] = plan->send_splits[static_cast<size_t>(s)] * 4;
       }
-      world.barrier();
       // (whatever goes wrong between the two meetings, the second one is still attended: the
       // peers would otherwise wait for this rank forever)
       std::exception_ptr failure;
       try {
+        world.meet(me, 1, 0);
         for (int s = 0; s < n; ++s) {
           const int64_t bytes = world.sizes[static_cast<size_t>(s)][static_cast<size_t>(me)];
           if (bytes != plan->recv_splits[static_cast<size_t>(s)] * 4) {
@@ -732,6 +818,10 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
                       "hipMemcpyAsync(exchange)");
         }
         drain(stream);
+      } catch (const avr::CallsDiffer&) {
+        throw;
+      } catch (const avr::DeadlineExceeded&) {
+        throw;
       } catch (...) {
         failure = std::current_exception();
       }
@@ -836,7 +926,15 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
       } catch (...) {
         failure = std::current_exception();
       }
-      world.barrier();
+      try {
+        world.meet(me, 2, static_cast<uint64_t>(n_pixels) * static_cast<uint64_t>(bytes_per_pixel));
+      } catch (const avr::CallsDiffer&) {
+        throw;
+      } catch (const avr::DeadlineExceeded&) {
+        throw;
+      } catch (...) {
+        if (!failure) failure = std::current_exception();
+      }
       try {
         if (failure) std::rethrow_exception(failure);
         for (int k = 0; k < n && my_bytes > 0; ++k) {
@@ -856,9 +954,9 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
       avr::LocalWorld& world = *comm->local;
       drain(stream);  // my image is complete
       world.base[static_cast<size_t>(me)] = src;
-      world.barrier();
       std::exception_ptr failure;
       try {
+        world.meet(me, 2, static_cast<uint64_t>(n_pixels) * static_cast<uint64_t>(bytes_per_pixel));
         for (int k = 0; k < n; ++k) {  // the image of the rank at position k, my piece of it
           if (my_bytes == 0) break;
           avr::hip_ok(hipMemcpyAsync(dst + k * my_bytes,
@@ -868,6 +966,10 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
                       "hipMemcpyAsync(exchange_pieces)");
         }
         drain(stream);
+      } catch (const avr::CallsDiffer&) {
+        throw;
+      } catch (const avr::DeadlineExceeded&) {
+        throw;
       } catch (...) {
         failure = std::current_exception();
       }
@@ -968,7 +1070,15 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       } catch (...) {
         failure = std::current_exception();
       }
-      world.barrier();
+      try {
+        world.meet(me, 3, static_cast<uint64_t>(bytes_per_pixel));
+      } catch (const avr::CallsDiffer&) {
+        throw;
+      } catch (const avr::DeadlineExceeded&) {
+        throw;
+      } catch (...) {
+        if (!failure) failure = std::current_exception();
+      }
       try {
         if (failure) std::rethrow_exception(failure);
         if (me == root) {
@@ -997,9 +1107,9 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       avr::LocalWorld& world = *comm->local;
       drain(stream);
       world.base[static_cast<size_t>(me)] = static_cast<const char*>(piece);
-      world.barrier();
       std::exception_ptr failure;
       try {
+        world.meet(me, 3, static_cast<uint64_t>(bytes_per_pixel));
         if (me == root) {
           for (int s = 0; s < n; ++s) {
             int64_t b = 0, e = 0;
@@ -1011,6 +1121,10 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
           }
           drain(stream);
         }
+      } catch (const avr::CallsDiffer&) {
+        throw;
+      } catch (const avr::DeadlineExceeded&) {
+        throw;
       } catch (...) {
         failure = std::current_exception();
       }

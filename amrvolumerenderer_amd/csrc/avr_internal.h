@@ -266,6 +266,7 @@ struct RenderLaunch {
 // Copies `bytes` (rounded up to 16; both blocks are that large) from device-mapped pinned host
 // memory to device memory.
 int launch_upload(const void* host_mapped, void* dev, size_t bytes, void* stream);
+int launch_stall(int milliseconds, void* stream);  // test hook: a bounded busy kernel
 int launch_classify(const RenderLaunch& launch, void* stream);
 int launch_march(const RenderLaunch& launch, void* stream);
 int launch_blend(int kind, const void* top, const void* bottom, void* out, int64_t n, void* stream);

@@ -697,6 +697,17 @@ __global__ void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__
   }
 }
 
+// Test hook (avr_debug_stall_stream): one wave that keeps its stream busy for a BOUNDED time --
+// the constant 100 MHz wall clock, and an iteration cap that ends it whatever the clock says -- so
+// that the deadline of the host waits can be exercised on a real stream without ever hanging one.
+__global__ void stall_kernel(unsigned long long ticks, unsigned int max_iterations) {
+  const unsigned long long begin = wall_clock64();
+  for (unsigned int i = 0; i < max_iterations; ++i) {
+    if (wall_clock64() - begin >= ticks) break;
+    __builtin_amdgcn_s_sleep(127);
+  }
+}
+
 // ---- classify pass ---------------------------------------------------------------------------
 // Streams every f64 cell of the frame's boxes once (coalesced rows, the HBM-bound part of the
 // frame) and stores its transfer-function table index -- the value VolumePainter.cpp:870-883
@@ -1276,6 +1287,15 @@ int launch_upload(const void* host_mapped, void* dev, size_t bytes, void* stream
   hipLaunchKernelGGL(upload_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_v),
                      static_cast<const uint4*>(host_mapped), static_cast<uint4*>(dev), n);
   return check_launch("upload_kernel");
+}
+
+int launch_stall(int milliseconds, void* stream_v) {
+  const unsigned long long ticks = static_cast<unsigned long long>(milliseconds) * 100000ull;
+  // (an iteration sleeps ~8 K cycles = 3-4 us: the cap ends the kernel after a few times the
+  // requested time even if the clock never moved)
+  const unsigned int cap = static_cast<unsigned int>(milliseconds) * 1000u;
+  hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_v), ticks, cap);
+  return check_launch("stall_kernel");
 }
 
 int launch_classify(const RenderLaunch& L, void* stream_v) {

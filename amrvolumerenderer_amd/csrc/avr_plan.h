@@ -40,6 +40,7 @@ struct avr_frame_plan {
   // the settings epoch of the frame driver under which the ranks agreed on this plan
   // (avr_frame_plan_agree; 0 = not yet)
   mutable uint64_t agreed_epoch = 0;
+  mutable uint64_t agreed_digest = 0;  // of the plan's replicated part, as agreed on
 };
 
 namespace avr {

@@ -219,8 +219,12 @@ struct avr_renderer {
     if (!failed.empty()) {
       // A stream of this renderer does not move (a collective whose peer never came): waiting for
       // it, or freeing device memory (which waits for the device), would hang the caller too.
-      // Everything is leaked; the process is expected to report the error and exit.
+      // Everything on the device is leaked; the process is expected to report the error and exit.
       forget_plans();
+      for (DeviceBuffer* buffer : {&send[0], &send[1], &send[2], &recv, &piece, &piece_rgb8, &full_rgb8,
+                                   &full_image, &assembled_image, &small_image}) {
+        buffer->ptr = nullptr;  // (hipFree waits for the device)
+      }
       return;
     }
     for (avr_context* ctx : {classify, march, compose, pair_b}) {
@@ -848,6 +852,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // 8-bit conversion is per pixel, so without antialiasing it is done on each rank's piece
     // before the gather (3 bytes per pixel on the wire instead of 20); the wireframe of the tight
     // bounds is per pixel too, so each rank overlays its own piece
+    r->stage = "frame buffers";
     const bool early_rgb8 = root == 1;
     const bool overlay_piece = early_rgb8 && render->draw_bounds;
     const bool gather_image = want_image != 0;  // the same on every rank: it adds a collective
@@ -952,19 +957,34 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       // drained: a buffer grew) says so, and then everybody times the candidate again.
       r->stage = "co-run window agreement (control plane)";
       avr::wait_event_deadline(r->window_end, "the march that closes the co-run window");
-      float mine = -1.0f;
+      // (the message also says which frame of which plan the rank is in: ranks that were driven
+      // apart -- same block sizes, another camera -- are found out here at the latest)
+      struct Word {
+        float period_ms;
+        uint32_t frame;
+        uint64_t plan_digest;
+      } mine{-1.0f, r->frame, plan->agreed_digest};
+      static_assert(sizeof(Word) == 16, "control word");
       if (!tuner.window_void) {
         float elapsed_ms = 0.0f;
         hip_ok(hipEventElapsedTime(&elapsed_ms, r->window_begin, r->window_end), "hipEventElapsedTime");
-        mine = elapsed_ms / static_cast<float>(tuner.window_length);
+        mine.period_ms = elapsed_ms / static_cast<float>(tuner.window_length);
       }
-      std::vector<float> periods(static_cast<size_t>(r->n_ranks), 0.0f);
-      abi_ok(avr_comm_control_allgather(r->comm, r->compose, &mine, periods.data(), 4));
+      std::vector<Word> words(static_cast<size_t>(r->n_ranks));
+      abi_ok(avr_comm_control_allgather(r->comm, r->compose, &mine, words.data(), sizeof(Word)));
       float agreed = 0.0f;
       bool any_void = false;
-      for (float period : periods) {
-        any_void = any_void || !(period >= 0.0f);
-        agreed = std::max(agreed, period);
+      for (size_t peer = 0; peer < words.size(); ++peer) {
+        const Word& word = words[peer];
+        if (word.frame != mine.frame || word.plan_digest != mine.plan_digest) {
+          throw std::runtime_error("rank " + std::to_string(peer) + " is in frame " +
+                                   std::to_string(word.frame) + (word.plan_digest != mine.plan_digest
+                                                                     ? " of another frame plan" : "") +
+                                   " while rank " + std::to_string(r->rank) + " is in frame " +
+                                   std::to_string(mine.frame) + ": the ranks were not driven alike");
+        }
+        any_void = any_void || !(word.period_ms >= 0.0f);
+        agreed = std::max(agreed, word.period_ms);
       }
       if (any_void) {
         tuner.retime();

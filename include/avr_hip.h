@@ -103,6 +103,9 @@ int avr_abi_version(void);
  * return AVR_ERR_RUNTIME with avr_last_error() naming what did not finish (stream, frame); the
  * renderer is then failed for good (every later call returns the error at once; destroy it). */
 int avr_set_frame_timeout_ms(int milliseconds);
+/* Test hook: keeps hip_stream busy for `milliseconds` (1..2000; one wave on a bounded timer -- it
+ * always ends) so that the deadline above can be exercised on a real stream. */
+int avr_debug_stall_stream(void *hip_stream, int milliseconds);
 
 /* Creates a context bound to HIP device `device_id` with its own stream.  Replaces the
  * function-local static VolumePainter / DirectSendBase instances of

@@ -384,7 +384,13 @@ def _failfast_worker(rank, world, port, name, mode, out_dir):
         error = ""
         try:
             if mode == "different_plan":
-                # rank 1 is handed another camera: its plan describes another exchange
+                # a new camera for everybody -- but rank 1 is handed another one: its plan
+                # describes another exchange
+                renderer.render(p, scenes.orbit_camera(5 if rank == 1 else 3))
+                renderer.synchronize()
+            elif mode == "different_calls":
+                # only rank 1 is handed a new camera: it goes to agree on a plan nobody else has,
+                # while the others queue the frame of the plan they already agreed on
                 renderer.render(p, scenes.orbit_camera(5) if rank == 1 else good)
                 renderer.synchronize()
             elif rank != 1:   # "missing_rank": rank 1 simply stops rendering
@@ -412,13 +418,16 @@ def _failfast_worker(rank, world, port, name, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["different_plan", "missing_rank"])
+@pytest.mark.parametrize("mode", ["different_plan", "different_calls", "missing_rank"])
 def test_ranks_fail_fast_instead_of_hanging(tmp_path, mode):
     """The N-rank frame completes or errors (DirectSendBase.cpp:206-220, 277), three rank
     processes over the shared-memory rehearsal communicator:
     * one rank is handed a deliberately different plan (another camera): the agreement check of a
       new plan (avr_frame_plan_agree, one control-plane allgather) makes EVERY rank return an
       error before anything of that frame is queued -- no hang, no deadline needed;
+    * only one rank is handed a new camera, so it alone goes to agree on a plan while the others
+      start the frame's exchange: the rehearsal communicators notice that the ranks are in different
+      collectives and every rank errors at once (over RCCL such rounds never end: the deadline);
     * one rank stops rendering: its peers' waits run into AVR_FRAME_TIMEOUT_MS (3 s here) and
       return an error naming rank, frame, stage and co-run state; the renderer is failed for good."""
     world = 3
@@ -430,6 +439,10 @@ def test_ranks_fail_fast_instead_of_hanging(tmp_path, mode):
         if mode == "different_plan":
             assert "frame plan: rank 1's plan differs from rank 0's" in error, (rank, error)
             assert float(elapsed) < 2.0 and failed == "" and int(rounds) == 1
+        elif mode == "different_calls":
+            assert "the ranks' calls differ" in error, (rank, error)
+            assert ("differ: rank 1 is in a control-plane allgather" in error) == (rank != 1), (rank, error)
+            assert float(elapsed) < 2.0
         elif rank == 1:
             assert error == ""
         else:

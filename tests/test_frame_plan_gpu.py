@@ -14,6 +14,10 @@ import plan_helpers as PH
 from helpers import assert_bit_equal, device_box
 from test_frame_plan import local_indices, oracle_overlay, painted_scene
 
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -428,6 +432,64 @@ def test_timing_toggled_under_the_paired_layout(ctx):
     for image, rgb8 in got:
         assert torch.equal(image.view(torch.int32), want[0].view(torch.int32))
         assert torch.equal(rgb8, want[1])
+
+
+def test_a_stream_that_does_not_move_ends_in_an_error_not_a_hang():
+    """avr_set_frame_timeout_ms on a REAL stream: the compositing stream is kept busy for 1.2 s by
+    a bounded stall kernel (it always ends by itself) while the deadline is 0.25 s -- the
+    synchronise returns AVR_ERR_RUNTIME naming that stream, the rank, the frame, the stage and the
+    co-run state; the renderer is failed for good and its destruction does not wait either.  In a
+    child process, so that the leaked renderer never meets the other tests."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import torch
+        from amrvolumerenderer_amd import _capi, runtime, scenes
+        from amrvolumerenderer_amd.renderer import FrameRenderer, RenderParameters
+        from helpers import device_box
+        ctx = runtime.Context(0)
+        spec = scenes.make_amr_scene(32, 1, 16, "smooth")
+        cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+        meta = [scenes.metadata_box(spec, i) for i in range(len(cells))]
+        local = [device_box(ctx, c, m.min_corner, m.max_corner, m.level) for c, m in zip(cells, spec.boxes)]
+        renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range)
+        native = renderer.native
+        p, cam = RenderParameters(96, 64, 0.9, 1), scenes.default_camera()
+        for _ in range(4):          # every rotating buffer has its size
+            renderer.render(p, cam)
+        renderer.synchronize()
+        runtime.set_frame_timeout_ms(250)
+        _capi.check(_capi.lib().avr_debug_stall_stream(native.streams[2].cuda_stream, 1200))
+        t0 = time.monotonic()
+        try:
+            renderer.render(p, cam)
+            renderer.synchronize()
+            print("NO ERROR")
+        except _capi.AvrError as error:
+            print("ERROR", round(time.monotonic() - t0, 3), str(error))
+        try:
+            renderer.render(p, cam)
+            print("NO ERROR")
+        except _capi.AvrError as error:
+            print("LATER", str(error) == native.failure())
+        t0 = time.monotonic()
+        native.close()
+        print("CLOSED", round(time.monotonic() - t0, 3))
+        time.sleep(1.5)            # the stall kernel ends by itself; then the process may go
+        torch.cuda.synchronize()
+        print("DRAINED")
+    """) % (ROOT, os.path.join(ROOT, "tests"))
+    done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = done.stdout.strip().splitlines()
+    assert lines[0].startswith("ERROR ") and "the compositing stream" in lines[0], lines
+    assert "AVR_FRAME_TIMEOUT_MS" in lines[0] and "rank 0 of 1" in lines[0] and "co-run:" in lines[0]
+    assert 0.2 < float(lines[0].split()[1]) < 1.0, lines[0]
+    assert lines[1] == "LATER True" and lines[2].startswith("CLOSED") and lines[3] == "DRAINED"
+    assert float(lines[2].split()[1]) < 0.2, lines[2]
 
 
 def test_plans_made_ahead_on_another_thread_change_nothing(ctx):
