@@ -181,7 +181,11 @@ struct CoRunTuner {
       // frames end in pairs, not evenly spaced: an odd window read a period 1/L short or long)
       // (the finalists' windows are twice as long: 8 frames of 1 ms are good to 1.5 %, and the
       // reserve next to the best one is often within that)
-      window_length = frames_per_window() * (phase == kVerify ? 2 : 1);
+      // (the held candidate's are four times as long: a rare window, and at 0.1 ms per frame forty
+      // frames are 4 ms -- short enough for one hiccup to read 5 % slow; the window that checks a
+      // suspected drift is eight times as long)
+      window_length = frames_per_window() *
+                      (phase == kVerify ? 2 : phase == kHold ? (drift_suspected ? 8 : 4) : 1);
       if (is_paired(candidate)) window_length += window_length & 1;
       return kOpenWindow;
     }
