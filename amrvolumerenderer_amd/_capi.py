@@ -246,6 +246,11 @@ SIGNATURES = {
     "avr_comm_control_rounds": (C.c_long, [_vp]),
     "avr_frame_plan_agree": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "avr_renderer_set_plan_check": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_deferred_gather": (C.c_int, [_vp, C.c_int]),
+    "avr_frame_plan_piece_ranges": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "avr_gather_run": (C.c_int, [_vp, _vp, _vp]),
+    "avr_exchange_peers_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "avr_assemble_rows_own": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "avr_renderer_set_corun_coordination": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_corun_history": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_corun_history": (C.c_int, [_vp, C.POINTER(C.c_int16), C.c_int,

@@ -1048,6 +1048,13 @@ int fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_bu
     // A rank of several folds its piece on the stream that also carries the exchange and the
     // gather, five kernels per frame: there it should be through quickly.
     launch.max_workgroups = plan->info.n_ranks == 1 ? 256 : 0;
+    {
+      static const int forced = [] {  // A/B only (tools/ab_env_share.sh)
+        const char* text = std::getenv("AVR_FOLD_WORKGROUPS");
+        return text != nullptr ? std::atoi(text) : 0;
+      }();
+      if (forced > 0) launch.max_workgroups = forced;
+    }
     launch.flip_height = to_image ? plan->params.height : 0;
     if (own_send_buffer != nullptr) {
       // the rank's block for itself: where the receive layout has it and where the march put it
@@ -1171,6 +1178,21 @@ int avr_assemble_rows(avr_context* ctx, const avr_frame_plan* plan, const void* 
     return avr::launch_assemble_rows(plan->pieces, static_cast<const uint8_t*>(gathered),
                                      static_cast<int64_t>(plan->params.width) * bytes_per_pixel,
                                      flip, static_cast<uint8_t*>(image), ctx->stream);
+  });
+}
+
+int avr_assemble_rows_own(avr_context* ctx, const avr_frame_plan* plan, const void* gathered,
+                          const void* own_piece, int bytes_per_pixel, int flip, void* image) {
+  return guarded([&]() -> int {
+    bind_device(ctx);
+    require(plan != nullptr && bytes_per_pixel > 0, "invalid argument");
+    if (plan->info.n_pixels == 0) return AVR_OK;
+    require(gathered != nullptr && image != nullptr && gathered != image, "invalid image pointers");
+    const int mine = plan->piece_of_rank[static_cast<size_t>(plan->info.rank)];
+    return avr::launch_assemble_rows(plan->pieces, static_cast<const uint8_t*>(gathered),
+                                     static_cast<int64_t>(plan->params.width) * bytes_per_pixel,
+                                     flip, static_cast<uint8_t*>(image), ctx->stream,
+                                     static_cast<const uint8_t*>(own_piece), mine);
   });
 }
 

@@ -382,7 +382,7 @@ int avr_comm_create_solo(int rank, int n_ranks, avr_comm** out_comm) {
 
 int avr_comm_create_solo_rccl(int device_id, int rank, int n_ranks, int percent, avr_comm** out_comm) {
   return guarded([&]() -> int {
-    require(out_comm != nullptr && n_ranks >= 1 && rank >= 0 && rank < n_ranks && percent >= 1 &&
+    require(out_comm != nullptr && n_ranks >= 1 && rank >= 0 && rank < n_ranks && percent >= 0 &&
                 percent <= 100, "invalid argument");
     *out_comm = nullptr;
     avr::hip_ok(hipSetDevice(device_id), "hipSetDevice");
@@ -673,7 +673,8 @@ int avr_comm_size(const avr_comm* comm) { return comm ? comm->n_ranks : -1; }
 
 namespace {
 int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
-             float* recv, bool move_own);
+             float* recv, bool move_own, const avr_gather_op* rider = nullptr);
+void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool in_group);
 }
 
 int avr_exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
@@ -686,13 +687,20 @@ int avr_exchange_peers(avr_context* ctx, const avr_frame_plan* plan, avr_comm* c
   return exchange(ctx, plan, comm, send, recv, /*move_own=*/false);
 }
 
+int avr_exchange_peers_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm,
+                              const float* send, float* recv, const avr_gather_op* rider) {
+  return exchange(ctx, plan, comm, send, recv, /*move_own=*/false, rider);
+}
+
 }  // extern "C"
 
 namespace {
 // move_own: whether the rank's block for itself is copied from the send to the receive buffer
 // (avr_fold_plan_own reads it where it is)
+// rider: a gather (of an earlier frame's pieces) that travels in the same grouped RCCL round -- one
+// launch per frame on the compositing stream instead of two
 int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const float* send,
-             float* recv, bool move_own) {
+             float* recv, bool move_own, const avr_gather_op* rider) {
   return guarded([&]() -> int {
     check_plan(comm, plan);
     hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
@@ -722,20 +730,39 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
         // of it: on the real node the seven blocks travel over seven links at once, here one
         // after the other over one connection (timing only: what lands in the receive buffer is
         // this rank's own data).
+        // (percent 0, "one link": only the LARGEST peer block, whole -- RCCL works off the operations
+        // for one peer one after the other, ~13 us each, so N - 1 pairs to the rank itself measure
+        // that serialisation, which the node, with one peer per link, does not have)
         const avr::Rccl& api = avr::rccl();
+        int busiest = -1;
+        if (comm->solo_percent == 0) {
+          int64_t most = 0;
+          for (int s = 0; s < n; ++s) {
+            const int64_t count = (s == me) ? 0 : std::min(plan->send_splits[static_cast<size_t>(s)],
+                                                           plan->recv_splits[static_cast<size_t>(s)]);
+            if (count > most) {
+              most = count;
+              busiest = s;
+            }
+          }
+        }
         avr::nccl_ok(api.group_start(), "ncclGroupStart");
         for (int s = 0; s < n; ++s) {
           if (s == me) continue;
+          if (comm->solo_percent == 0 && s != busiest) continue;
           const int64_t count = std::min(plan->send_splits[static_cast<size_t>(s)],
                                          plan->recv_splits[static_cast<size_t>(s)]) *
-                                comm->solo_percent / 100;
+                                (comm->solo_percent == 0 ? 100 : comm->solo_percent) / 100;
           if (count <= 0) continue;
           avr::nccl_ok(api.send(send + send_at[static_cast<size_t>(s)], static_cast<size_t>(count), ncclFloat, 0,
                                 comm->nccl, stream), "ncclSend");
           avr::nccl_ok(api.recv(recv + recv_at[static_cast<size_t>(s)], static_cast<size_t>(count), ncclFloat, 0,
                                 comm->nccl, stream), "ncclRecv");
         }
+        if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/true);
         avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+      } else if (rider != nullptr) {
+        run_gather(ctx, comm, *rider, /*in_group=*/false);
       }
       return AVR_OK;
     }
@@ -787,6 +814,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
       }
       world.barrier();  // every rank has pulled: the regions may be rewritten
       if (failure) std::rethrow_exception(failure);
+      if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/false);
       return AVR_OK;
     }
     if (comm->local) {
@@ -827,6 +855,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
       }
       world.barrier();  // every rank has pulled: the send buffers may be rewritten
       if (failure) std::rethrow_exception(failure);
+      if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/false);
       return AVR_OK;
     }
     // RCCL: one grouped round; a rank's block for itself is a device copy
@@ -835,10 +864,13 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
     if (n == 1) {
       // a one-rank communicator only exists to exercise this path where a single GPU is all
       // there is: the block for itself goes through ncclSend / ncclRecv like any other
-      if (own > 0 && move_own) {
+      if ((own > 0 && move_own) || rider != nullptr) {
         avr::nccl_ok(api.group_start(), "ncclGroupStart");
-        avr::nccl_ok(api.send(send, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclSend");
-        avr::nccl_ok(api.recv(recv, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclRecv");
+        if (own > 0 && move_own) {
+          avr::nccl_ok(api.send(send, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclSend");
+          avr::nccl_ok(api.recv(recv, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclRecv");
+        }
+        if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/true);
         avr::nccl_ok(api.group_end(), "ncclGroupEnd");
       }
       return AVR_OK;
@@ -862,6 +894,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
                               comm->nccl, stream), "ncclRecv");
       }
     }
+    if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/true);
     avr::nccl_ok(api.group_end(), "ncclGroupEnd");
     return AVR_OK;
   });
@@ -999,27 +1032,35 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
   });
 }
 
-int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const void* piece,
-               int bytes_per_pixel, void* full, int root) {
-  return guarded([&]() -> int {
-    check_plan(comm, plan);
+}  // extern "C"
+
+namespace {
+// ImageFull::Gather of pieces whose places in the gathered buffer are given as pixel ranges (of
+// the frame's plan -- possibly an EARLIER frame's: the frame driver lets the gather of frame f ride
+// in the grouped round of frame f + 1).  in_group: an RCCL group is open (the caller closes it);
+// skip_own: the root does not copy its own piece (its assemble pass reads it where it is).
+void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool in_group) {
     hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
     const int n = comm->n_ranks, me = comm->rank;
-    require(bytes_per_pixel > 0 && root >= 0 && root < n, "invalid argument");
-    const int64_t n_pixels = plan->info.n_pixels;
-    // where a rank's piece sits in the gathered buffer: its pixel range of the image
-    // (getPieceRange, DirectSendBase.cpp:59-74) or, with row bands, piece after piece
-    // (avr_assemble_rows restores the image order)
+    const int bytes_per_pixel = op.bytes_per_pixel, root = op.root;
+    const void* piece = op.piece;
+    void* full = op.full;
+    require(bytes_per_pixel > 0 && root >= 0 && root < n && op.begin != nullptr && op.end != nullptr,
+            "invalid gather");
     auto piece_range = [&](int rank, int64_t* begin, int64_t* end) {
-      avr::piece_pixel_range(plan->pieces, plan->piece_of_rank[static_cast<size_t>(rank)], begin, end);
+      *begin = op.begin[rank];
+      *end = op.end[rank];
     };
+    const bool copy_own = op.skip_own == 0;
     int64_t my_begin = 0, my_end = 0;
     piece_range(me, &my_begin, &my_end);
     require(my_end == my_begin || piece != nullptr, "null piece");
-    require(me != root || full != nullptr || n_pixels == 0, "null destination on the root");
+    bool anything = false;
+    for (int s = 0; s < n; ++s) anything = anything || op.end[s] > op.begin[s];
+    require(me != root || full != nullptr || !anything, "null destination on the root");
     char* dst = static_cast<char*>(full);
     if (comm->solo) {
-      if (me == root && my_end > my_begin) {
+      if (me == root && my_end > my_begin && copy_own) {
         avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
                                    static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                    hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
@@ -1029,7 +1070,7 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
         // piece from every other rank, the others send theirs
         const avr::Rccl& api = avr::rccl();
         const size_t bytes = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
-        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
         if (me != root) {
           // (no destination buffer off the root: the piece's first half lands on its second --
           // the piece has been handed over by then, and a solo rank's pixels mean nothing)
@@ -1040,20 +1081,23 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
             avr::nccl_ok(api.recv(target, half, ncclUint8, 0, comm->nccl, stream), "ncclRecv");
           }
         } else {
+          bool one_done = false;
           for (int s = 0; s < n; ++s) {
             if (s == me) continue;
+            if (comm->solo_percent == 0 && one_done) break;  // "one link": one peer's piece
             int64_t b = 0, e = 0;
             piece_range(s, &b, &e);
             const size_t count = std::min(bytes, static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel));
             if (count == 0) continue;
+            one_done = true;
             avr::nccl_ok(api.send(piece, count, ncclUint8, 0, comm->nccl, stream), "ncclSend");
             avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, count, ncclUint8, 0, comm->nccl, stream),
                          "ncclRecv");
           }
         }
-        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+        if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
       }
-      return AVR_OK;
+      return;
     }
     if (comm->shared) {
       avr::SharedWorld& world = *comm->shared;
@@ -1088,8 +1132,10 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
             if (e == b) continue;
             const size_t bytes = static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel);
             if (s == me) {
-              avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, piece, bytes, hipMemcpyDeviceToDevice),
-                          "hipMemcpy(gather)");
+              if (copy_own) {
+                avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, piece, bytes, hipMemcpyDeviceToDevice),
+                            "hipMemcpy(gather)");
+              }
             } else {
               avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, world.region(s), bytes, hipMemcpyHostToDevice),
                           "hipMemcpy(gather)");
@@ -1101,7 +1147,7 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       }
       world.barrier();
       if (failure) std::rethrow_exception(failure);
-      return AVR_OK;
+      return;
     }
     if (comm->local) {
       avr::LocalWorld& world = *comm->local;
@@ -1114,7 +1160,7 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
           for (int s = 0; s < n; ++s) {
             int64_t b = 0, e = 0;
             piece_range(s, &b, &e);
-            if (e == b) continue;
+            if (e == b || (s == me && !copy_own)) continue;
             avr::hip_ok(hipMemcpyAsync(dst + b * bytes_per_pixel, world.base[static_cast<size_t>(s)],
                                        static_cast<size_t>(e - b) * bytes_per_pixel,
                                        hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
@@ -1130,26 +1176,26 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       }
       world.barrier();
       if (failure) std::rethrow_exception(failure);
-      return AVR_OK;
+      return;
     }
     const avr::Rccl& api = avr::rccl();
     if (n == 1) {  // as in avr_exchange: the one-rank case goes through RCCL on purpose
       if (my_end > my_begin) {
         const size_t bytes = static_cast<size_t>(my_end - my_begin) * bytes_per_pixel;
-        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
         avr::nccl_ok(api.send(piece, bytes, ncclChar, 0, comm->nccl, stream), "ncclSend");
         avr::nccl_ok(api.recv(dst + my_begin * bytes_per_pixel, bytes, ncclChar, 0, comm->nccl, stream),
                      "ncclRecv");
-        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+        if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
       }
-      return AVR_OK;
+      return;
     }
-    if (me == root && my_end > my_begin) {
+    if (me == root && my_end > my_begin && copy_own) {
       avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
                                  static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                  hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
     }
-    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
     if (me == root) {
       for (int s = 0; s < n; ++s) {
         if (s == root) continue;
@@ -1163,9 +1209,61 @@ int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, con
       avr::nccl_ok(api.send(piece, static_cast<size_t>(my_end - my_begin) * bytes_per_pixel, ncclChar,
                             root, comm->nccl, stream), "ncclSend");
     }
-    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+}
+
+// the ranges of a plan's pieces in the gathered buffer: a rank's pixel range of the image
+// (getPieceRange, DirectSendBase.cpp:59-74) or, with row bands, piece after piece
+// (avr_assemble_rows restores the image order)
+void plan_piece_ranges(const avr_frame_plan* plan, std::vector<int64_t>* begin, std::vector<int64_t>* end) {
+  const size_t n = static_cast<size_t>(plan->info.n_ranks);
+  begin->assign(n, 0);
+  end->assign(n, 0);
+  for (size_t rank = 0; rank < n; ++rank) {
+    avr::piece_pixel_range(plan->pieces, plan->piece_of_rank[rank], &(*begin)[rank], &(*end)[rank]);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int avr_gather(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const void* piece,
+               int bytes_per_pixel, void* full, int root) {
+  return guarded([&]() -> int {
+    check_plan(comm, plan);
+    std::vector<int64_t> begin, end;
+    plan_piece_ranges(plan, &begin, &end);
+    avr_gather_op op{};
+    op.piece = piece;
+    op.bytes_per_pixel = bytes_per_pixel;
+    op.root = root;
+    op.full = full;
+    op.begin = begin.data();
+    op.end = end.data();
+    op.skip_own = 0;
+    run_gather(ctx, comm, op, /*in_group=*/false);
     return AVR_OK;
   });
 }
+
+int avr_frame_plan_piece_ranges(const avr_frame_plan* plan, int64_t* begin_out, int64_t* end_out) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && begin_out != nullptr && end_out != nullptr, "null argument");
+    std::vector<int64_t> begin, end;
+    plan_piece_ranges(plan, &begin, &end);
+    std::copy(begin.begin(), begin.end(), begin_out);
+    std::copy(end.begin(), end.end(), end_out);
+    return AVR_OK;
+  });
+}
+
+int avr_gather_run(avr_context* ctx, avr_comm* comm, const avr_gather_op* op) {
+  return guarded([&]() -> int {
+    require(comm != nullptr && op != nullptr, "null argument");
+    run_gather(ctx, comm, *op, /*in_group=*/false);
+    return AVR_OK;
+  });
+}
+
 
 }  // extern "C"

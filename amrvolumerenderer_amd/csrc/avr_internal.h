@@ -301,8 +301,9 @@ int launch_quantize(const float* src, int w, int h, int stride, uint8_t* dst, vo
 int launch_flip_rows(const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst, void* stream);
 // Gathered, piece-major rows (row bands: piece 0's rows, then piece 1's, ...) -> image order;
 // flip != 0 also turns the image upside down (bottom-up image -> top-down file rows).
+// own (may be null): piece own_piece is read from there instead of from src.
 int launch_assemble_rows(const PieceMapDev& pieces, const uint8_t* src, int64_t row_bytes, int flip,
-                         uint8_t* dst, void* stream);
+                         uint8_t* dst, void* stream, const uint8_t* own = nullptr, int own_piece = -1);
 
 constexpr uint32_t kScanWorkgroups = 2048;  // grid of the grid-stride cell scans
 // scene statistics (avr_scene_stats.hip).  partial_dev: kScanWorkgroups x 32 bytes of scratch;

@@ -1241,9 +1241,12 @@ __global__ void flip_rows_kernel(const T* __restrict__ src, int64_t row_items, i
 // Gathered piece-major rows -> image rows (row bands), optionally upside down: destination row
 // y_out holds image row y = flip ? h - 1 - y_out : y_out, which is piece row j of piece k and
 // sits after the rows of the pieces before k in the gathered buffer.
+// own (may be null): the rows of piece own_piece are read from there -- the root's own piece where
+// its fold wrote it -- instead of from the gathered buffer (one device copy less per frame).
 template <typename T>
 __global__ void assemble_rows_kernel(const T* __restrict__ src, int64_t row_items,
-                                     const PieceMapDev pieces, int flip, T* __restrict__ dst) {
+                                     const PieceMapDev pieces, int flip, T* __restrict__ dst,
+                                     const T* __restrict__ own, int own_piece) {
   const int h = pieces.height;
   const int64_t n = row_items * h;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -1252,12 +1255,28 @@ __global__ void assemble_rows_kernel(const T* __restrict__ src, int64_t row_item
     const int64_t out_row = q / row_items;
     const int y = flip ? (h - 1 - static_cast<int>(out_row)) : static_cast<int>(out_row);
     int64_t src_row = y;
+    const T* from = src;
     if (pieces.layout == kPiecesRowBands) {
       const int k = piece_of_row(pieces, y);
       src_row = piece_row_of(pieces, y);
-      for (int before = 0; before < k; ++before) src_row += piece_row_count(pieces, before);
+      if (own != nullptr && k == own_piece) {
+        from = own;
+      } else {
+        for (int before = 0; before < k; ++before) src_row += piece_row_count(pieces, before);
+      }
+    } else if (own != nullptr) {
+      // contiguous pieces: piece k = pixels [k * piece_size, ...) of the image, the last to the end
+      const int64_t pixel = static_cast<int64_t>(y) * pieces.width;
+      const int64_t own_begin = pieces.piece_size * own_piece;
+      const int64_t own_end = (own_piece < pieces.n_pieces - 1) ? own_begin + pieces.piece_size
+                                                               : static_cast<int64_t>(pieces.width) * pieces.height;
+      // (rows are whole only if the piece boundaries fall on rows: the caller checks)
+      if (pixel >= own_begin && pixel < own_end) {
+        from = own;
+        src_row = y - own_begin / pieces.width;
+      }
     }
-    dst[q] = src[src_row * row_items + (q - out_row * row_items)];
+    dst[q] = from[src_row * row_items + (q - out_row * row_items)];
   }
 }
 
@@ -1476,28 +1495,34 @@ int launch_flip_rows(const uint8_t* src, int64_t row_bytes, int h, uint8_t* dst,
 }
 
 int launch_assemble_rows(const PieceMapDev& pieces, const uint8_t* src, int64_t row_bytes, int flip,
-                         uint8_t* dst, void* stream_v) {
+                         uint8_t* dst, void* stream_v, const uint8_t* own, int own_piece) {
   const int h = pieces.height;
   if (row_bytes <= 0 || h <= 0) return AVR_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_v);
-  const bool wide = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0);
+  if (own != nullptr && pieces.layout != kPiecesRowBands &&
+      (pieces.piece_size % pieces.width != 0 || own_piece < 0)) {
+    set_error("assemble_rows: the own piece can only be read in place if the pieces are whole rows");
+    return AVR_ERR_INVALID_ARGUMENT;
+  }
+  const uintptr_t alignment = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) |
+                              reinterpret_cast<uintptr_t>(own);
+  const bool wide = (row_bytes % 16 == 0) && ((alignment & 15u) == 0);
   // (a small grid: the pass runs beside the paint kernels of the next frames on the root rank and
   // should take bandwidth, which it barely needs, not workgroup slots)
   if (wide) {
     const int64_t items = row_bytes / 16;
     hipLaunchKernelGGL(assemble_rows_kernel<uint4>, dim3(std::min(grid_for(items * h, 256), 256)), dim3(256), 0,
                        stream, reinterpret_cast<const uint4*>(src), items, pieces, flip,
-                       reinterpret_cast<uint4*>(dst));
-  } else if (row_bytes % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & 3u) == 0) &&
-             ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0)) {
+                       reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(own), own_piece);
+  } else if (row_bytes % 4 == 0 && (alignment & 3u) == 0) {
     const int64_t items = row_bytes / 4;
     hipLaunchKernelGGL(assemble_rows_kernel<uint32_t>, dim3(grid_for(items * h, 256)), dim3(256), 0,
                        stream, reinterpret_cast<const uint32_t*>(src), items, pieces, flip,
-                       reinterpret_cast<uint32_t*>(dst));
+                       reinterpret_cast<uint32_t*>(dst), reinterpret_cast<const uint32_t*>(own),
+                       own_piece);
   } else {
     hipLaunchKernelGGL(assemble_rows_kernel<uint8_t>, dim3(grid_for(row_bytes * h, 256)), dim3(256),
-                       0, stream, src, row_bytes, pieces, flip, dst);
+                       0, stream, src, row_bytes, pieces, flip, dst, own, own_piece);
   }
   return check_launch("assemble_rows_kernel");
 }

@@ -188,6 +188,20 @@ struct avr_renderer {
   }
 
   DeviceBuffer send[AVR_CLASSIFIED_SLOTS], recv, piece, piece_rgb8, full_rgb8, full_image, assembled_image, small_image;
+  // Ranks of several: the RGB8 pieces of frame f travel to the root inside the grouped round of
+  // frame f + 1 (avr_exchange_peers_gather) -- ONE RCCL launch per frame on the compositing stream
+  // instead of two.  The fold of frame f + 1 must not overwrite what that round still sends: two
+  // piece buffers alternate.  avr_renderer_synchronize sends what is still pending (collective).
+  DeviceBuffer piece_rgb8_odd;
+  int deferred_gather = -1;  // avr_renderer_set_deferred_gather: -1 = ranks of several
+  struct PendingGather {
+    bool valid = false;
+    avr::PieceMapDev pieces{};
+    std::vector<int64_t> begin, end;  // every rank's piece in the gathered buffer (pixels)
+    int own_piece = 0;
+    const uint8_t* piece = nullptr;   // this rank's RGB8 piece of that frame
+    uint8_t* out = nullptr;           // root: that frame's rgb8_out
+  } pending;
   // classified volume and send buffer f % 3
   hipEvent_t classified_event[AVR_CLASSIFIED_SLOTS] = {};  // classify pass of the volume finished
   hipEvent_t marched_event[AVR_CLASSIFIED_SLOTS] = {};     // march finished reading the volume
@@ -221,8 +235,8 @@ struct avr_renderer {
       // it, or freeing device memory (which waits for the device), would hang the caller too.
       // Everything on the device is leaked; the process is expected to report the error and exit.
       forget_plans();
-      for (DeviceBuffer* buffer : {&send[0], &send[1], &send[2], &recv, &piece, &piece_rgb8, &full_rgb8,
-                                   &full_image, &assembled_image, &small_image}) {
+      for (DeviceBuffer* buffer : {&send[0], &send[1], &send[2], &recv, &piece, &piece_rgb8, &piece_rgb8_odd,
+                                   &full_rgb8, &full_image, &assembled_image, &small_image}) {
         buffer->ptr = nullptr;  // (hipFree waits for the device)
       }
       return;
@@ -268,7 +282,8 @@ struct avr_renderer {
     uint64_t digest = 0xcbf29ce484222325ull;
     for (int64_t value : {static_cast<int64_t>(overlap_classify), static_cast<int64_t>(share_fixed),
                           static_cast<int64_t>(cache_classification), static_cast<int64_t>(tighten_exchange),
-                          static_cast<int64_t>(coordinate), static_cast<int64_t>(plan_check)}) {
+                          static_cast<int64_t>(coordinate), static_cast<int64_t>(plan_check),
+                          static_cast<int64_t>(deferred_gather)}) {
       digest = (digest ^ static_cast<uint64_t>(value)) * 0x100000001b3ull;
     }
     return digest;
@@ -633,6 +648,16 @@ int avr_renderer_set_overlap(avr_renderer* r, int overlap_classify) {
   });
 }
 
+int avr_renderer_set_deferred_gather(avr_renderer* r, int mode) {
+  return guarded_renderer(r, [&]() -> int {
+    require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
+    require(!r->pending.valid, "a frame's gather is pending: call avr_renderer_synchronize first");
+    r->deferred_gather = mode;
+    ++r->settings_epoch;
+    return AVR_OK;
+  });
+}
+
 int avr_renderer_set_plan_check(avr_renderer* r, int mode) {
   return guarded_renderer(r, [&]() -> int {
     require(mode == 0 || mode == 1, "mode must be 0 or 1");
@@ -699,6 +724,36 @@ void* avr_renderer_stream(avr_renderer* r, int which) {
 int avr_renderer_synchronize(avr_renderer* r) {
   return guarded_renderer(r, [&]() -> int {
     r->stage = "synchronize";
+    hip_ok(hipSetDevice(r->device), "hipSetDevice");
+    if (r->pending.valid) {
+      // the last frame's RGB8 pieces have not travelled yet: a gather round of their own
+      // (collective -- every rank synchronises after the same frame)
+      r->stage = "synchronize: the last frame's gather";
+      avr_renderer::PendingGather& pending = r->pending;
+      uint8_t* gathered = nullptr;
+      if (r->rank == 0) {
+        const size_t bytes = static_cast<size_t>(pending.pieces.width) * pending.pieces.height * 3 + 1;
+        gathered = static_cast<uint8_t*>(r->full_rgb8.reserve(bytes, [&] { r->drain_all(); }));
+      }
+      avr_gather_op op{};
+      op.piece = pending.piece;
+      op.bytes_per_pixel = 3;
+      op.root = 0;
+      op.full = gathered;
+      op.begin = pending.begin.data();
+      op.end = pending.end.data();
+      op.skip_own = 1;
+      abi_ok(avr_gather_run(r->compose, r->comm, &op));
+      if (r->rank == 0 &&
+          avr::launch_assemble_rows(pending.pieces, gathered,
+                                    static_cast<int64_t>(pending.pieces.width) * 3, /*flip=*/1,
+                                    pending.out, r->stream_of(r->compose), pending.piece,
+                                    pending.own_piece) != AVR_OK) {
+        throw std::runtime_error(avr_last_error());
+      }
+      pending.valid = false;
+      r->stage = "synchronize";
+    }
     r->drain_all();
     r->stage = "idle";
     return AVR_OK;
@@ -870,16 +925,24 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
                        : nullptr;
     float* piece = bytes_only ? nullptr
                               : static_cast<float*>(r->piece.reserve(bytes_of(piece_pixels, 20), drain));
+    // (ranks of several: two RGB8 pieces alternate, see PendingGather)
+    DeviceBuffer& rgb8_buffer = (many && (r->frame & 1u)) ? r->piece_rgb8_odd : r->piece_rgb8;
     uint8_t* piece_rgb8 =
-        early_rgb8 ? static_cast<uint8_t*>(r->piece_rgb8.reserve(bytes_of(piece_pixels, 3), drain))
+        early_rgb8 ? static_cast<uint8_t*>(rgb8_buffer.reserve(bytes_of(piece_pixels, 3), drain))
                    : nullptr;
+    const bool defer_gather = many && r->deferred_gather != 0 && early_rgb8 && !gather_image;
     uint8_t* gathered_rgb8 = nullptr;
     float* gathered_image = nullptr;
     float* assembled = nullptr;
     float* small = nullptr;
     if (is_root) {
-      if (early_rgb8 && many) {
-        gathered_rgb8 = static_cast<uint8_t*>(r->full_rgb8.reserve(bytes_of(n_pixels, 3), drain));
+      if (many && (early_rgb8 || r->pending.valid)) {
+        int64_t pixels = early_rgb8 ? n_pixels : 0;
+        if (r->pending.valid) {
+          pixels = std::max<int64_t>(pixels, static_cast<int64_t>(r->pending.pieces.width) *
+                                                 r->pending.pieces.height);
+        }
+        gathered_rgb8 = static_cast<uint8_t*>(r->full_rgb8.reserve(bytes_of(pixels, 3), drain));
       }
       if (many && ((early_rgb8 && gather_image && banded) || !early_rgb8)) {
         gathered_image = static_cast<float*>(r->full_image.reserve(bytes_of(n_pixels, 20), drain));
@@ -1155,7 +1218,28 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     const float* received = send;
     const float* own = nullptr;
     if (many) {
-      abi_ok(avr_exchange_peers(r->compose, plan, r->comm, send, recv));
+      // ... and in the same grouped round the RGB8 pieces of the frame before travel to the root
+      avr_renderer::PendingGather& pending = r->pending;
+      avr_gather_op rider{};
+      if (pending.valid) {
+        rider.piece = pending.piece;
+        rider.bytes_per_pixel = 3;
+        rider.root = 0;
+        rider.full = gathered_rgb8;
+        rider.begin = pending.begin.data();
+        rider.end = pending.end.data();
+        rider.skip_own = 1;  // (the assemble pass reads the root's own piece where its fold wrote it)
+      }
+      abi_ok(avr_exchange_peers_gather(r->compose, plan, r->comm, send, recv,
+                                       pending.valid ? &rider : nullptr));
+      if (pending.valid && is_root) {
+        if (avr::launch_assemble_rows(pending.pieces, gathered_rgb8,
+                                      static_cast<int64_t>(pending.pieces.width) * 3, /*flip=*/1,
+                                      pending.out, stream_x, pending.piece, pending.own_piece) != AVR_OK) {
+          throw std::runtime_error(avr_last_error());
+        }
+      }
+      pending.valid = false;
       received = recv;
       own = send;
     }
@@ -1178,7 +1262,18 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
 
     lap(4);
     r->stage = "gather and frame tail";
-    if (early_rgb8) {
+    if (defer_gather) {
+      // the bytes travel with the next frame's round (or with avr_renderer_synchronize)
+      avr_renderer::PendingGather& pending = r->pending;
+      pending.valid = true;
+      pending.pieces = plan->pieces;
+      pending.begin.resize(static_cast<size_t>(r->n_ranks));
+      pending.end.resize(static_cast<size_t>(r->n_ranks));
+      abi_ok(avr_frame_plan_piece_ranges(plan, pending.begin.data(), pending.end.data()));
+      pending.own_piece = plan->piece_of_rank[static_cast<size_t>(r->rank)];
+      pending.piece = piece_rgb8;
+      pending.out = rgb8_out;
+    } else if (early_rgb8) {
       uint8_t* full = piece_rgb8;
       if (many) {
         full = gathered_rgb8;

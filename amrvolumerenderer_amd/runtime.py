@@ -778,7 +778,11 @@ class NativeRenderer:
                                                          int(bool(cache_classification))))
 
     def synchronize(self) -> None:
+        """avr_renderer_synchronize: everything queued so far has finished.  For ranks of several
+        also sends the last frame's RGB8 pieces to rank 0 (collective: every rank calls it after
+        the same frame)."""
         _capi.check(_capi.lib().avr_renderer_synchronize(self._handle))
+        self._held_outputs = None
 
     def set_overlap(self, overlap_classify: int) -> None:
         """avr_renderer_set_overlap (-1 default: measured, 0 back to back, 1 classify beside the
@@ -817,6 +821,12 @@ class NativeRenderer:
         return {"classify": layout.get(overlap.value, str(overlap.value)),
                 "lds_reserve_bytes": reserve.value, "settled": bool(settled.value),
                 "timed_windows": windows.value}
+
+    def set_deferred_gather(self, mode: int = -1) -> None:
+        """avr_renderer_set_deferred_gather: -1 default (ranks of several: a frame's RGB8 pieces
+        travel to rank 0 with the NEXT frame's grouped round; synchronize() sends the last
+        frame's), 0 every frame gathers at once, 1 on."""
+        _capi.check(_capi.lib().avr_renderer_set_deferred_gather(self._handle, int(mode)))
 
     def set_plan_check(self, enabled: bool = True) -> None:
         """avr_renderer_set_plan_check: whether a new plan of a rank of several is agreed on over
@@ -939,6 +949,9 @@ class NativeRenderer:
             C.c_void_p(samples.data_ptr()) if samples is not None else None, int(bool(want_image)),
             C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
             C.c_void_p(image.data_ptr()) if image is not None else None))
+        # (ranks of several: this frame's bytes are written while the NEXT frame is queued, or by
+        # synchronize(): the tensor must outlive the caller's interest in it until then)
+        self._held_outputs = (image, rgb8)
         return image, rgb8
 
 

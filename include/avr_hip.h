@@ -470,7 +470,11 @@ int avr_comm_create_solo(int rank, int n_ranks, avr_comm **out_comm);
  * of the real round: its launch on the host, its kernel beside the paint kernels, its bytes
  * through HBM; not the links.  percent (1..100): the share of every peer's block avr_exchange
  * moves -- on the node the N - 1 blocks travel over N - 1 links at once, here one after the other
- * over one connection, so 100 overstates how long the round's kernel runs.  Timing only. */
+ * over one connection, so 100 overstates how long the round's kernel runs.  percent 0 = "one link":
+ * only the largest peer block travels, whole, and the root's gather receives one peer's piece --
+ * what the busiest of a rank's N - 1 links carries; RCCL works off the operations for ONE peer one
+ * after the other (~13 us each, measured), a serialisation the node, with one peer per link, does
+ * not have.  Timing only. */
 int avr_comm_create_solo_rccl(int device_id, int rank, int n_ranks, int percent,
                               avr_comm **out_comm);
 /* Rehearsal of the N-rank frame across PROCESSES that share one GPU (RCCL refuses two ranks on
@@ -544,6 +548,27 @@ int avr_exchange_pieces(avr_context *ctx, avr_comm *comm, const int32_t *group_o
  * elsewhere).  Collective; on the context's stream. */
 int avr_gather(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm, const void *piece,
                int bytes_per_pixel, void *full, int root);
+/* The same gather described without a plan: begin / end [n_ranks] = where each rank's piece sits in
+ * `full`, in pixels (avr_frame_plan_piece_ranges of the frame the pieces belong to).  skip_own: the
+ * root does not copy its own piece into `full` (avr_assemble_rows_own reads it where it is).
+ * avr_exchange_peers_gather: avr_exchange_peers with such a gather -- of an EARLIER frame's pieces
+ * -- riding in the same grouped ncclSend / ncclRecv round: the frame driver's compositing stream
+ * then carries ONE RCCL launch per frame (the reference's Gather is a second collective after the
+ * compositing, Common/ImageColorOnly.hpp:220-270; frames are independent, so frame f's bytes may
+ * travel to the root while frame f + 1 is exchanged).  rider may be NULL. */
+typedef struct {
+  const void *piece;       /* this rank's piece (device) */
+  int32_t bytes_per_pixel;
+  int32_t root;
+  void *full;              /* on the root: the gathered, piece-major buffer (device) */
+  const int64_t *begin;    /* [n_ranks] */
+  const int64_t *end;      /* [n_ranks] */
+  int32_t skip_own;
+} avr_gather_op;
+int avr_frame_plan_piece_ranges(const avr_frame_plan *plan, int64_t *begin_out, int64_t *end_out);
+int avr_gather_run(avr_context *ctx, avr_comm *comm, const avr_gather_op *op);
+int avr_exchange_peers_gather(avr_context *ctx, const avr_frame_plan *plan, avr_comm *comm,
+                              const float *send, float *recv, const avr_gather_op *rider);
 
 /* ---- frame driver -------------------------------------------------------------------------- */
 
@@ -644,6 +669,15 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
  *   avr_set_frame_timeout_ms (stream, rank, frame, stage, co-run state); the renderer is then
  *   failed: every call returns AVR_ERR_RUNTIME with that message, avr_renderer_destroy releases
  *   host memory only (device memory and streams of a hung GPU queue are left to process exit). */
+/* avr_renderer_set_deferred_gather (default -1 = on for ranks of several; the same on every rank):
+ *   the RGB8 pieces of frame f travel to rank 0 inside the grouped round of frame f + 1
+ *   (avr_exchange_peers_gather) instead of in a gather round of their own -- ONE RCCL launch per
+ *   frame.  Rank 0's rgb8_out of frame f is then complete when the compositing stream has passed
+ *   the NEXT frame's round, or after avr_renderer_synchronize -- which, while such a gather is
+ *   pending, runs it and is therefore collective (every rank synchronises after the same frame);
+ *   the caller's rgb8_out buffer must stay valid until then.  Frames with want_image or
+ *   antialiasing gather at once as before.  0: every frame gathers at once. */
+int avr_renderer_set_deferred_gather(avr_renderer *renderer, int mode);
 int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
 int avr_renderer_set_corun_coordination(avr_renderer *renderer, int mode);
 int avr_renderer_set_corun_history(avr_renderer *renderer, int frames);
@@ -662,7 +696,8 @@ const char *avr_renderer_failure(const avr_renderer *renderer);
  * top-down = the output file's pixel bytes, required) and, with want_image, image_out (device,
  * width*height*5 floats, origin bottom-left).  Other ranks pass NULL for both.  The outputs are
  * complete when the compositing stream (avr_renderer_stream(r, 2)) reaches this point:
- * avr_renderer_synchronize, or order your stream after it. */
+ * avr_renderer_synchronize, or order your stream after it -- for ranks of several the RGB8 bytes
+ * of a frame without want_image arrive one frame later (avr_renderer_set_deferred_gather). */
 #define AVR_DEFAULT_STREAM ((void *)(intptr_t)-1) /* input_stream: the legacy default (null) stream */
 int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
                         const avr_camera *camera, const int32_t *group_order, void *input_stream,
@@ -752,6 +787,11 @@ int avr_bbox_overlay_piece(avr_context *ctx, const avr_frame_plan *plan, const d
  * image, so this is a (flipped) copy -- avr_flip_rows generalised to AVR_PIECES_ROW_BANDS. */
 int avr_assemble_rows(avr_context *ctx, const avr_frame_plan *plan, const void *gathered,
                       int bytes_per_pixel, int flip, void *image);
+/* The same with this rank's own piece read where its fold wrote it (own_piece, device) instead of
+ * from the gathered buffer: the root of a gather with skip_own saves a device copy per frame.  With
+ * contiguous pieces only if the pieces are whole rows. */
+int avr_assemble_rows_own(avr_context *ctx, const avr_frame_plan *plan, const void *gathered,
+                          const void *own_piece, int bytes_per_pixel, int flip, void *image);
 
 /* ---- scene statistics -------------------------------------------------- */
 

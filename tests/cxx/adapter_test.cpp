@@ -276,7 +276,10 @@ int main(int argc, char** argv) {
       write_file(argv[6], out.data(), out.size());
       return 0;
     }
-    if (mode == "frame" && argc == 11) {
+    if (mode == "frame" && (argc == 11 || argc == 12)) {
+      // (a twelfth argument "bytes": no float image is asked for -- the frames' RGB8 pieces then
+      // travel to rank 0 with the next frame's grouped round, the last frame's with synchronize())
+      const bool want_image = !(argc == 12 && std::string(argv[11]) == "bytes");
       const int n_ranks = std::atoi(argv[3]);
       const int W = std::atoi(argv[4]), H = std::atoi(argv[5]);
       const float transparency = static_cast<float>(std::atof(argv[6]));
@@ -372,8 +375,8 @@ int main(int argc, char** argv) {
                 planned = std::async(std::launch::async,
                                      [&driver, &render, next] { driver.prepare(render, next); });
               }
-              driver.render(render, away(frame) ? elsewhere : camera,
-                            r == 0 ? bytes.data() : nullptr, true, r == 0 ? image.data() : nullptr);
+              driver.render(render, away(frame) ? elsewhere : camera, r == 0 ? bytes.data() : nullptr,
+                            want_image, (r == 0 && want_image) ? image.data() : nullptr);
               if (planned.valid()) planned.get();
             }
             driver.synchronize();

@@ -56,6 +56,9 @@ def test_adapter_single_rank_compose(O, avr_lib, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_ranks,policy,antialiasing,frames", [
     (1, "morton", 1, 3), (3, "morton", 1, 3), (4, "round_robin", 1, 3), (2, "morton", 4, 3),
+    # negative frame count = bytes only: no float image, so a frame's RGB8 pieces reach rank 0 with
+    # the NEXT frame's grouped round and the last frame's with synchronize()
+    (8, "level_pairs", 1, -5), (3, "morton", 1, -4),
     # long enough for every rank's driver to try all its ways of running the classify pass and
     # the march (back to back, side by side with each LDS reserve) and settle: the last frame
     # must still be the oracle's
@@ -77,6 +80,7 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
     from amrvolumerenderer_amd import scenes
     from test_frame_plan import local_indices, oracle_overlay, painted_scene
     subprocess.run(["make", "-C", CXX, "adapter_test"], check=True, stdout=subprocess.DEVNULL)
+    bytes_only, frames = frames < 0, abs(frames)
     W, H, transparency = 96, 64, 0.8
     root = int(round(antialiasing ** 0.5))
     spec = scenes.make_amr_scene(32, 2, 8, "smooth")
@@ -92,7 +96,8 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
             fh.write(np.ascontiguousarray(c, dtype="<f8").tobytes())
     done = subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
                            str(transparency), str(antialiasing), str(frames),
-                           str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin")], check=True,
+                           str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin")] +
+                          (["bytes"] if bytes_only else []), check=True,
                           timeout=300, stdout=subprocess.PIPE, text=True)
     if frames >= 330 and n_ranks > 1:   # the search moved, and it moved on every rank alike
         distinct = int(done.stdout.split("corun candidates held:")[1].split()[0])
@@ -101,8 +106,9 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
     if root > 1:
         want = O.downsample(want, W, H, root).reshape(-1, 5)
     want = oracle_overlay(O, spec, cells, cam, want, W, H)
-    got = np.fromfile(tmp_path / "image.bin", dtype=np.float32)
-    assert_bit_equal(got, want, "C++ multi-rank frame")
+    if not bytes_only:
+        got = np.fromfile(tmp_path / "image.bin", dtype=np.float32)
+        assert_bit_equal(got, want, "C++ multi-rank frame")
     got8 = np.fromfile(tmp_path / "rgb8.bin", dtype=np.uint8).reshape(H, W, 3)
     assert np.array_equal(got8, O.quantize_rgb8(want, W, H))   # rows top-down, the file's bytes
     scenes.assign_owners(spec, 1, "morton")

@@ -272,7 +272,7 @@ def test_native_rccl_exchange_and_gather_with_one_rank(O):
     comm.close()
 
 
-def _native_worker(rank, world, port, policy, antialiasing, name, out_path):
+def _native_worker(rank, world, port, policy, antialiasing, name, out_path, bytes_only=False):
     """One rank PROCESS of the C++ frame driver on the shared GPU: avr_renderer with the
     cross-process rehearsal communicator (avr_comm_create_shared) -- the plans, offsets and
     ordering of the RCCL flavour, blocks through a shared-memory segment."""
@@ -305,7 +305,11 @@ def _native_worker(rank, world, port, policy, antialiasing, name, out_path):
                                  rank, world, dist.group.WORLD, comm=comm)
         assert renderer.native is not None
         # pipelined: three frames (two cameras, the first one again) without a host sync between
-        frames = [renderer.render(RenderParameters(W, H, 0.85, antialiasing), cam, want_image=True)
+        # (bytes_only: no float image is asked for, so the RGB8 pieces of a frame travel to rank 0
+        # with the NEXT frame's grouped round and the last frame's with the synchronise: every
+        # frame's bytes must still land in that frame's own tensor)
+        frames = [renderer.render(RenderParameters(W, H, 0.85, antialiasing), cam,
+                                  want_image=not bytes_only)
                   for cam in cams]
         renderer.synchronize()
         info = renderer.native.plan_info()
@@ -319,7 +323,8 @@ def _native_worker(rank, world, port, policy, antialiasing, name, out_path):
                 if root > 1:
                     want = O.downsample(want, W, H, root).reshape(-1, 5)
                 want = oracle_overlay(O, spec, cells, cam, want, W, H)
-                flags.append(np.array_equal(image.cpu().numpy().reshape(-1, 5).view(np.uint32),
+                flags.append(bytes_only or
+                             np.array_equal(image.cpu().numpy().reshape(-1, 5).view(np.uint32),
                                             want.view(np.uint32)))
                 flags.append(np.array_equal(rgb8.cpu().numpy(), O.quantize_rgb8(want, W, H)))
             with open(out_path, "w") as fh:
@@ -333,16 +338,18 @@ def _native_worker(rank, world, port, policy, antialiasing, name, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,policy,antialiasing", [(3, "level_pairs", 1), (2, "morton", 4),
-                                                       (4, "round_robin", 1)])
-def test_native_driver_across_processes(tmp_path, world, policy, antialiasing):
+@pytest.mark.parametrize("world,policy,antialiasing,bytes_only", [
+    (3, "level_pairs", 1, False), (2, "morton", 4, False), (4, "round_robin", 1, False),
+    (3, "level_pairs", 1, True), (4, "morton", 1, True)])
+def test_native_driver_across_processes(tmp_path, world, policy, antialiasing, bytes_only):
     """The C++ frame driver as N rank PROCESSES on one GPU (what `bench.py --gpus N` and the
     reference's MPI ranks are), wired by the shared-memory rehearsal communicator: row-band pieces,
     exchange layout tightened from the first frame, frames pipelined; rank 0's frames are the
     oracle's N-rank compose bit for bit."""
     out = tmp_path / "result.txt"
-    name = f"/avr_test_{os.getpid()}_{world}_{antialiasing}"
-    mp.spawn(_native_worker, args=(world, _free_port(), policy, antialiasing, name, str(out)),
+    name = f"/avr_test_{os.getpid()}_{world}_{antialiasing}_{int(bytes_only)}"
+    mp.spawn(_native_worker, args=(world, _free_port(), policy, antialiasing, name, str(out),
+                                   bytes_only),
              nprocs=world, join=True)
     flags = out.read_text().split()
     assert len(flags) == 6 and all(f == "1" for f in flags), flags
@@ -483,7 +490,9 @@ def _lockstep_worker(rank, world, port, name, frames, out_dir):
         first = None
         for f in range(frames):
             if rank == 2 and f in (57, 131):
-                native.synchronize()   # ONE rank's pipeline drains: only its window is void
+                # ONE rank's pipeline drains (what a buffer that grows does): only its window is
+                # void.  (Not synchronize(): with a frame's gather pending that is a collective.)
+                native.set_timing(False)
             out = renderer.render(p, cam)
             first = first or out
         renderer.synchronize()
@@ -555,7 +564,7 @@ def test_bench_multi_rank_flow_on_one_gpu(n_ranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("percent", [100, 25])
+@pytest.mark.parametrize("percent", [100, 25, 0])
 def test_one_rank_of_four_played_through_rccl(percent):
     """avr_comm_create_solo_rccl (timing studies, tools/rank_share.py --through-rccl): a rank of
     four played alone with its grouped send / receive round and its gather going through a one-rank
@@ -591,4 +600,4 @@ def test_one_rank_of_four_played_through_rccl(percent):
     assert plans[(1, "solo")] == plans[(1, "rccl")]
     assert all(s > 0 for s, _, _ in plans[(0, "rccl")])
     with pytest.raises(Exception):
-        runtime.Comm.solo_rccl(0, 0, 4, 0)
+        runtime.Comm.solo_rccl(0, 0, 4, 101)

@@ -108,8 +108,10 @@ def measure_share(n_ranks, rank):
     if n_ranks > 1:
         # --through-rccl: the rank's exchange and gather go through a one-rank RCCL communicator to
         # the rank itself (RCCL's launch, kernel and bytes beside the paint kernels; not the links)
-        comm = (runtime.Comm.solo_rccl(0, rank, n_ranks, args.through_rccl) if args.through_rccl
-                else runtime.Comm.solo(rank, n_ranks))
+        # (--through-rccl -1: "one link" -- only the largest peer block, whole: RCCL works off the
+        # operations for ONE peer one after the other, which the node does not have)
+        comm = (runtime.Comm.solo_rccl(0, rank, n_ranks, max(args.through_rccl, 0))
+                if args.through_rccl else runtime.Comm.solo(rank, n_ranks))
     r = runtime.NativeRenderer(0, merged, spec.transform, spec.bounds, spec.scalar_range, rank,
                                n_ranks, comm)
     r.set_options(args.march_occupancy, False)
@@ -232,7 +234,7 @@ def child(extra):
 print(f"{args.config}, {args.size}^2, ownership {args.ownership}, "
       f"{'contiguous pieces' if args.contiguous_pieces else 'row-band pieces'}, "
       f"{'no RCCL in the share processes' if args.no_rccl else 'live one-rank RCCL communicator in every share process'}"
-      f"{f', EXCHANGE ({args.through_rccl} % of every block) AND GATHER THROUGH RCCL (to the rank itself)' if args.through_rccl else ''}"
+      f"{f', EXCHANGE ({args.through_rccl} % of every block) AND GATHER THROUGH RCCL (to the rank itself)' if args.through_rccl > 0 else ', EXCHANGE (the busiest link: the largest peer block, whole) AND GATHER (one peer) THROUGH RCCL (to the rank itself)' if args.through_rccl < 0 else ''}"
       f"{', FLY-THROUGH (a new camera every frame)' if args.fly_through else ''}",
       flush=True)
 summary = []
