@@ -729,7 +729,13 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
   __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
 
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
+#ifdef AVR_EXPERIMENT_CLASSIFY_REPEAT
+  // experiment build only (tools/upper_bound_persistent.py): ONE launch sweeps the frame's tiles
+  // several times over -- a classify pass that never ends between frames
+  const uint32_t tile = blockIdx.x % tile_begin[n_boxes];
+#else
   const uint32_t tile = blockIdx.x;
+#endif
   int lo = 0, hi = n_boxes;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -1325,6 +1331,16 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
                       fc.inverse_range == 1.0f;
   const size_t pad = L.classify_lds_pad;  // occupancy cap beside the march (avr_renderer)
+#ifdef AVR_EXPERIMENT_CLASSIFY_REPEAT
+  {
+    const char* text = std::getenv("AVR_CLASSIFY_REPEAT");
+    const unsigned repeat = text != nullptr ? static_cast<unsigned>(std::max(std::atoi(text), 1)) : 1u;
+    hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles * repeat), dim3(kBlockThreads), pad,
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
+                       L.classify_stream_stores);
+    return check_launch("classify_kernel");
+  }
+#endif
   if (simple) {
     hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
