@@ -185,35 +185,59 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
     }
 
 
+PMC_SUMMARY = os.path.join("profiles", "r4_final", "pmc_summary.txt")
+PMC_SOURCES = ("avr_kernels.hip", "avr_device.h", "avr_renderer.cpp")
+
+
+def kernel_sources_sha256():
+    """Identity of what the PMC counters were taken on: the two paint kernels and the driver that
+    schedules them (tools/pmc_passes.sh writes the same digest into its summary)."""
+    import hashlib
+    digest = hashlib.sha256()
+    for name in PMC_SOURCES:
+        with open(os.path.join(ROOT, "amrvolumerenderer_amd", "csrc", name), "rb") as fh:
+            digest.update(fh.read())
+    return digest.hexdigest()
+
+
 def profiled_traffic(args, world):
     """HBM bytes per paint-stage launch from the committed rocprofv3 PMC summary of THIS command
-    (profiles/r3_final/pmc_summary.txt: separate --pmc passes, tools/pmc_passes.sh, taken at the
-    kernels of this commit -- the march with its RunSpanDev / band_shift arguments).  FETCH_SIZE
-    and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane)
+    (separate --pmc passes, tools/pmc_passes.sh) -- only if that summary was taken on the kernels
+    of this tree: its first line carries the sha256 of the kernel and driver sources, and a tree
+    whose sources differ gets (None, "stale ...") instead of somebody else's bytes.  FETCH_SIZE and
+    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane)
     coalesced stream, so the classify kernel's reads are doubled and the march's byte gathers
     are not (MI355X_MICROARCH.md, HBM).  Only valid for the default single-GPU workload."""
     default = (world == 1 and args.config == "config4" and args.field == "smooth"
                and args.transparency == 0.97 and not args.width and not args.height
                and args.antialiasing == 1 and args.orbit == 0 and not args.fly_through)
-    path = os.path.join(ROOT, "profiles", "r3_final", "pmc_summary.txt")
-    if not default or not os.path.exists(path):
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not default:
         return None, None
-    counters, kernel = {}, None
+    if not os.path.exists(path):
+        return None, f"no PMC summary ({PMC_SUMMARY})"
+    counters, kernel, recorded = {}, None, None
     for line in open(path):
+        if line.startswith("# sources sha256:"):
+            recorded = line.split(":", 1)[1].split()[0]
+            continue
         if not line.startswith(" "):
             kernel = line.strip()
             continue
         parts = line.split()
         if len(parts) >= 3 and parts[-1].startswith("mean="):
             counters[(kernel, parts[0])] = float(parts[-1][5:])
+    if recorded != kernel_sources_sha256():
+        return None, (f"stale: {PMC_SUMMARY} was taken on other kernel sources "
+                      f"({(recorded or 'no digest')[:12]}...): rerun tools/pmc_passes.sh")
     try:
         kib = (2.0 * counters[("classify_kernel", "FETCH_SIZE")]
                + counters[("classify_kernel", "WRITE_SIZE")]
                + counters[("render_runs_kernel", "FETCH_SIZE")]
                + counters[("render_runs_kernel", "WRITE_SIZE")])
     except KeyError:
-        return None, None
-    return int(kib * 1024), "profiles/r3_final/pmc_summary.txt"
+        return None, f"{PMC_SUMMARY} lacks FETCH_SIZE / WRITE_SIZE"
+    return int(kib * 1024), PMC_SUMMARY
 
 
 def launcher_command(n_ranks, port, argv):

@@ -81,3 +81,27 @@ def test_bare_multi_gpu_start_spawns_children_before_touching_the_gpu(tmp_path):
                           stderr=subprocess.PIPE, text=True, cwd=str(tmp_path))
     assert done.returncode == 7, done.stderr
     assert "SPAWN False ['-m', 'torch.distributed.run']" in done.stdout
+
+
+def test_profiled_traffic_is_only_quoted_for_the_kernels_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC summary: bench.py quotes it only when the
+    summary's digest equals the sha256 of this tree's kernel and driver sources -- an edited kernel
+    makes the line say "stale" instead of quoting the old bytes."""
+    bench = load_bench()
+    args = types.SimpleNamespace(config="config4", field="smooth", transparency=0.97, width=0,
+                                 height=0, antialiasing=1, orbit=0, fly_through=False)
+    summary = tmp_path / "pmc_summary.txt"
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(summary))
+    body = ("classify_kernel\n  FETCH_SIZE    n=5 mean=1000\n  WRITE_SIZE    n=5 mean=100\n"
+            "render_runs_kernel\n  FETCH_SIZE    n=5 mean=200\n  WRITE_SIZE    n=5 mean=30\n")
+    assert bench.profiled_traffic(args, 1)[0] is None              # no summary at all
+    summary.write_text("# sources sha256: %s  (x)\n" % bench.kernel_sources_sha256() + body)
+    traffic, source = bench.profiled_traffic(args, 1)
+    assert traffic == int((2 * 1000 + 100 + 200 + 30) * 1024) and source == str(summary)
+    summary.write_text("# sources sha256: %s  (x)\n" % ("0" * 64) + body)
+    traffic, source = bench.profiled_traffic(args, 1)
+    assert traffic is None and source.startswith("stale")
+    summary.write_text(body)                                       # a summary without a digest
+    assert bench.profiled_traffic(args, 1)[0] is None
+    args.config = "config2"                                        # not the profiled workload
+    assert bench.profiled_traffic(args, 1) == (None, None)

@@ -36,7 +36,15 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
         else:
             continue
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+import hashlib, os
+digest = hashlib.sha256()
+sources = ("avr_kernels.hip", "avr_device.h", "avr_renderer.cpp")   # bench.py: PMC_SOURCES
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+for name in sources:
+    digest.update(open(os.path.join(root, "amrvolumerenderer_amd", "csrc", name), "rb").read())
 with open(out + "/summary.txt", "w") as fh:
+    # what the counters were taken on: bench.py quotes them only for a tree with the same digest
+    fh.write("# sources sha256: %s  (%s)\n" % (digest.hexdigest(), " ".join(sources)))
     for k, d in agg.items():
         fh.write(k + "\n")
         for c, v in sorted(d.items()):
