@@ -11,7 +11,7 @@
 
 // How the classify pass and the march of a rank share the GPU is MEASURED, not assumed.  Beside
 // the march the classify pass takes memory-system time from it in proportion to the bandwidth it
-// reaches -- whatever its arithmetic, occupancy or cache policy -- so the
+// reaches -- whatever its arithmetic, occupancy or cache policy (profiles/experiments_rounds_1_to_3.md section 3) -- so the
 // frame is shortest where the two take equally long; how many classify workgroups a CU admits
 // (an LDS reserve per workgroup, avr_context_set_classify_lds_reserve) moves that balance, and
 // for the short kernels of an N-rank share running them back to back can win outright.  A third

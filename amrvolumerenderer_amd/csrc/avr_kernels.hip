@@ -718,7 +718,7 @@ constexpr int kStagedStride = 34;  // dwords per staged bricklet (32 + 2: confli
 constexpr int kRawBufferFlags = 0x00020000;  // word 3 of a raw (untyped) gfx9 buffer resource
 // Cache policy of the cell loads (buffer_load aux bits: 1 = sc0, 2 = nt, 16 = sc1): every cell is
 // read once per frame, so non-temporal.  Measured beside the march, the policy does not matter
-// (0, nt, sc1, nt|sc1, sc0|sc1|nt: 1.049-1.063 ms per frame).
+// (0, nt, sc1, nt|sc1, sc0|sc1|nt: 1.049-1.063 ms per frame, profiles/experiments_rounds_1_to_3.md section 3).
 constexpr int kStreamingLoad = 2;
 
 template <bool SIMPLE>

@@ -152,7 +152,7 @@ def _morton3(x: int, y: int, z: int) -> int:
 def box_cost(meta: BoxMeta, pixels_per_unit: float) -> float:
     """Estimated GPU time (ms) of one box per frame: the classify pass streams every cell, the
     march takes rays x steps with rays ~ projected face area.  Constants measured on MI355X
-    (DESIGN.md section 4): 0.52 ms / 369 M cells, 1.31 ms / 759 M samples."""
+    (profiles/experiments_rounds_1_to_3.md section 4): 0.52 ms / 369 M cells, 1.31 ms / 759 M samples."""
     ext = [meta.max_corner[c] - meta.min_corner[c] for c in range(3)]
     cells = meta.dims[0] * meta.dims[1] * meta.dims[2]
     face = (ext[0] * ext[1] * ext[1] * ext[2] * ext[0] * ext[2]) ** (1.0 / 3.0)

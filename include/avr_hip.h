@@ -142,7 +142,7 @@ int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
 /* LDS (bytes, 0 = none) each classify workgroup of this context's launches claims beyond the
  * 2 KiB it stages bricklets in: caps how many of them a CU holds at once.  Beside the march the
  * classify pass takes memory-system time from the march in proportion to the bandwidth it
- * reaches, whatever its arithmetic, occupancy or cache policy; the
+ * reaches, whatever its arithmetic, occupancy or cache policy (profiles/experiments_rounds_1_to_3.md section 3); the
  * renderer's frame driver uses this to make both kernels of a frame take equally long
  * (avr_renderer_set_classify_share).  Never changes results. */
 #define AVR_CLASSIFY_LDS_RESERVE_MAX 61440
