@@ -124,6 +124,7 @@ struct CoRunTuner {
     n_verify = verify_at = 0;
     refined = 0;
     drift_suspected = false;
+    shrink = 0;
     interrupt();
   }
   void interrupt() {  // the pipeline drained or the candidate changed: the window is void
@@ -137,12 +138,30 @@ struct CoRunTuner {
       if (open) window_void = true;
       return;
     }
-    if (!closing) interrupt();
+    if (!closing) {
+      if (phase == kVerify && shrink < 2) ++shrink;
+      interrupt();
+    }
   }
   void set_coordinated(bool on) {
     if (on == coordinated) return;
     coordinated = on;
     restart();
+  }
+  // Frames let pass after a change of candidate before its window opens.  The finalists get at
+  // least kVerifySettle: a candidate one step past the best reserve is classify-bound by a few per
+  // cent, and the classify stream's lead of two frames (three classified volumes) takes
+  // 2 / 0.06 = ~30 frames to run out -- until then the pipeline still shows the period of the
+  // candidate before (the fly-through bench held 26 KiB at 1.08 ms where 24 KiB runs 0.98: its 16
+  // settling frames had flattered it in every window).
+  static constexpr int kVerifySettle = 40;
+  // A caller who drains the pipeline every so many frames voids every window longer than that:
+  // each drain that interrupts a finalist halves what the finalists are given (down to the
+  // search's own windows), so that the search still ends; reset when a new search starts.
+  int shrink = 0;
+  int settle_frames() const {
+    const int frames = std::max(kSettleFrames, frames_per_window());
+    return phase == kVerify ? std::max(frames, kVerifySettle >> shrink) : frames;
   }
   // frames the held candidate runs before it is timed again
   int hold_frames() const {
@@ -157,7 +176,7 @@ struct CoRunTuner {
   }
   // coordinated: some rank's window was void -- the same candidate is timed again, by all
   void retime() {
-    const int start = (phase == kHold) ? hold_frames() : std::max(kSettleFrames, frames_per_window());
+    const int start = (phase == kHold) ? hold_frames() : settle_frames();
     open = closing = false;
     window_void = false;
     frames_since_close = 0;
@@ -173,19 +192,18 @@ struct CoRunTuner {
     // by side: tens of frames; a window timed right after the change read 3-5 % slow, which was
     // harmless while every candidate was side by side and is not beside the paired layout, which
     // settles at once): as many frames are let pass as the window then times.
-    const int start =
-        (phase == kHold) ? hold_frames() : std::max(kSettleFrames, frames_per_window());
+    const int start = (phase == kHold) ? hold_frames() : settle_frames();
     if (!open && frames_at_candidate >= start) {
       open = true;
       // paired, the window's two events must lie on the same one of the two streams (whose
       // frames end in pairs, not evenly spaced: an odd window read a period 1/L short or long)
-      // (the finalists' windows are twice as long: 8 frames of 1 ms are good to 1.5 %, and the
+      // (the finalists' windows are four times as long: 8 frames of 1 ms are good to 1.5 %, and the
       // reserve next to the best one is often within that)
       // (the held candidate's are four times as long: a rare window, and at 0.1 ms per frame forty
       // frames are 4 ms -- short enough for one hiccup to read 5 % slow; the window that checks a
       // suspected drift is eight times as long)
       window_length = frames_per_window() *
-                      (phase == kVerify ? 2 : phase == kHold ? (drift_suspected ? 8 : 4) : 1);
+                      (phase == kVerify ? (4 >> shrink) : phase == kHold ? (drift_suspected ? 8 : 4) : 1);
       if (is_paired(candidate)) window_length += window_length & 1;
       return kOpenWindow;
     }

@@ -494,10 +494,10 @@ def run(args, state):
         return renderer.native is None or renderer.native.corun_state()["settled"]
 
     # (N ranks: every frame is a collective, so every rank must run the same number of them --
-    # a fixed count, well past the <= 2400 frames the search takes at short frames, instead of a
+    # a fixed count, well past the <= 2900 frames the search takes at short frames, instead of a
     # clock)
     # (a one-GPU rehearsal moves every block through host memory: it is not there to settle)
-    fixed_burst = (48 if args.rehearse_on_one_gpu else 3200) if world > 1 else None
+    fixed_burst = (48 if args.rehearse_on_one_gpu else 4000) if world > 1 else None
     while True:
         for _ in range(16):
             step(burst)

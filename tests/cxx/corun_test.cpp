@@ -94,8 +94,10 @@ int main() {
     expect(t.settled(), "one rank settles");
     expect(run.candidate == 12 || run.candidate == 13, "one rank holds 24-26 KiB, got " +
                                                             std::to_string(run.candidate));
-    // (20 windows of 8 timed frames, each after 8 frames of settling, + the event lag)
-    expect(run.frames < 440, "one rank settles within 440 frames, took " + std::to_string(run.frames));
+    // (20 windows of 8 timed frames, each after 8 frames of settling, + the event lag; the three
+    // finalists after 40 frames each: a classify-bound candidate shows only when the classify
+    // stream's lead has run out)
+    expect(run.frames < 590, "one rank settles within 590 frames, took " + std::to_string(run.frames));
     int back_to_back = 0;
     for (int c : run.tried) back_to_back += (c == CoRunTuner::kBackToBack) ? 1 : 0;
     expect(run.tried.front() == 0 && back_to_back == 1 &&
@@ -149,7 +151,7 @@ int main() {
     CoRunTuner t;
     t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
     Run run = play(t, [](int c) { return 35.0f * one_rank(c); }, 5000);
-    expect(t.settled() && run.frames < 200, "35 ms frames settle within 200 frames, took " +
+    expect(t.settled() && run.frames < 310, "35 ms frames settle within 310 frames, took " +
                                                 std::to_string(run.frames));
     const int held = run.candidate;
     run = play(t, [](int c) { return 35.0f * one_rank(c); }, 2 * CoRunTuner::kHoldFrames + 40, 2, 0,
@@ -216,7 +218,7 @@ int main() {
     const Run run = play(t, model, 4000);
     expect(t.settled() && (run.candidate == 12 || run.candidate == 13),
            "one rank stays side by side at 24-26 KiB, got " + std::to_string(run.candidate));
-    expect(run.frames < 600, "one rank settles within 600 frames with the paired layout in the "
+    expect(run.frames < 740, "one rank settles within 740 frames with the paired layout in the "
                              "search, took " + std::to_string(run.frames));
   }
   {  // the caller asked for the paired layout only: its reserves alone are searched

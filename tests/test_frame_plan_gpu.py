@@ -351,9 +351,9 @@ def test_corun_tuning_never_changes_results(O, ctx):
     # (2: the paired layout -- every frame's two kernels on one stream, the frames alternating
     # between two streams; with the reserve fixed, then searched; with host-side back-pressure)
     # (frame counts: a window of this scene's 0.1 ms frames is 40 frames after 40 let pass, the
-    # finalists' windows 80: a whole search is 26 x 80 + 3 x 120 = 2440 frames, back to back against
-    # one fixed reserve 2 x 80 + 2 x 120 = 400)
-    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 3200), (4096, -1, 800), (8192, 2, 13),
+    # finalists' windows 160: a whole search is 28 x 80 + 3 x 200 = 2840 frames, back to back
+    # against one fixed reserve 2 x 80 + 3 x 200 = 760)
+    for share, overlap, frames in ((61440, 1, 12), (-1, -1, 3600), (4096, -1, 1100), (8192, 2, 13),
                                    (-1, 2, 600)):
         renderer, got = run(share, overlap, frames)
         state = renderer.native.corun_state()
