@@ -64,9 +64,15 @@ const Rccl& rccl() {
   static std::once_flag once;
   static std::string failure;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (api.handle != nullptr) break;
+    // (AVR_RCCL_LIBRARY: a test hook -- tests/cxx/mock_rccl.cpp, a double with RCCL's matching
+    // semantics, lets the N > 1 branch below run as rank threads on one GPU)
+    if (const char* forced = std::getenv("AVR_RCCL_LIBRARY")) {
+      api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle != nullptr) break;
+      }
     }
     if (api.handle == nullptr) {
       failure = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();

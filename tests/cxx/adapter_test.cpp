@@ -276,10 +276,16 @@ int main(int argc, char** argv) {
       write_file(argv[6], out.data(), out.size());
       return 0;
     }
-    if (mode == "frame" && (argc == 11 || argc == 12)) {
+    if (mode == "frame" && argc >= 11 && argc <= 13) {
       // (a twelfth argument "bytes": no float image is asked for -- the frames' RGB8 pieces then
-      // travel to rank 0 with the next frame's grouped round, the last frame's with synchronize())
-      const bool want_image = !(argc == 12 && std::string(argv[11]) == "bytes");
+      // travel to rank 0 with the next frame's grouped round, the last frame's with synchronize();
+      // a thirteenth "rccl" / "rccl_inband": the ranks' communicators are the RCCL flavour, made
+      // from a unique id over the threads' control plane as the reference's host would make them
+      // over MPI -- with AVR_RCCL_LIBRARY naming tests/cxx/libmock_rccl.so, since RCCL itself
+      // refuses two ranks on one device; "rccl_inband" drops the caller's control plane, so that
+      // the plan agreement and the co-run windows travel as tiny grouped rounds in band)
+      const bool want_image = !(argc >= 12 && std::string(argv[11]) == "bytes");
+      const std::string flavour = argc == 13 ? argv[12] : "local";
       const int n_ranks = std::atoi(argv[3]);
       const int W = std::atoi(argv[4]), H = std::atoi(argv[5]);
       const float transparency = static_cast<float>(std::atof(argv[6]));
@@ -343,7 +349,10 @@ int main(int argc, char** argv) {
       render.draw_bounds = 1;
 
       // one host thread per rank, connected by the in-process rehearsal communicator
-      auto comms = avr::Communicator::local(n_ranks);
+      std::vector<std::unique_ptr<avr::Communicator>> comms;
+      if (flavour == "local") comms = avr::Communicator::local(n_ranks);
+      standin::ThreadWorld world;
+      world.n = n_ranks;
       const size_t n_pixels = static_cast<size_t>(W) * H;
       avr::DeviceBuffer<float> image(n_pixels * 5 + 1);
       avr::DeviceBuffer<unsigned char> bytes(n_pixels * 3 + 1);
@@ -356,8 +365,17 @@ int main(int argc, char** argv) {
         threads.emplace_back([&, r] {
           try {
             avr::hip_ok(hipSetDevice(0), "hipSetDevice");
-            avr::FrameDriver driver(0, r, n_ranks, n_ranks > 1 ? comms[static_cast<size_t>(r)].get() : nullptr,
-                                    boxes, owner, transform, bmin, bmax);
+            standin::ThreadControl control{&world, r};
+            std::unique_ptr<avr::Communicator> own;
+            avr::Communicator* comm = nullptr;
+            if (n_ranks > 1 && flavour == "local") {
+              comm = comms[static_cast<size_t>(r)].get();
+            } else if (n_ranks > 1) {
+              own = std::make_unique<avr::Communicator>(control, 0);  // collective: unique id, broadcast, init
+              if (flavour == "rccl_inband") avr::check(avr_comm_set_control(own->get(), nullptr, nullptr));
+              comm = own.get();
+            }
+            avr::FrameDriver driver(0, r, n_ranks, comm, boxes, owner, transform, bmin, bmax);
             avr::check(avr_renderer_set_corun_history(driver.get(), frames));
             // pipelined: no synchronisation between the frames.  Every third frame before the
             // last looks from elsewhere: the camera then comes back to a cached plan (whose

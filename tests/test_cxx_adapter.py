@@ -76,6 +76,33 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
     avr_renderer: visibility order, frame plan, classify + march on their streams, exchange, fold,
     overlay, gather, downsample, bytes) per rank, every rank a host thread of one process, wired
     with the in-process rehearsal communicator; the frames back to back without synchronising."""
+    run_rank_threads(O, tmp_path, n_ranks, policy, antialiasing, frames, "local")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,policy,antialiasing,frames,flavour", [
+    (2, "morton", 1, 3, "rccl"), (3, "round_robin", 4, 3, "rccl"), (8, "level_pairs", 1, -6, "rccl"),
+    (4, "level_pairs", 1, -5, "rccl_inband"), (3, "morton", 1, 3, "rccl_inband"),
+    # through a good part of the co-run search (its window agreements over the caller's control
+    # plane / in band), eight ranks
+    (8, "level_pairs", 1, -500, "rccl"), (5, "level_pairs", 1, -400, "rccl_inband")])
+def test_adapter_frames_through_the_rccl_branch_of_the_communicator(O, avr_lib, tmp_path, n_ranks,
+                                                                    policy, antialiasing, frames,
+                                                                    flavour):
+    """The N > 1 branch of the RCCL flavour -- avr_comm_create from a unique id carried by the
+    caller's control plane, the frame's grouped ncclSend / ncclRecv round with the gather riding in
+    it, the standalone gather, the in-band control rounds -- executed by N rank threads against a
+    test double of RCCL (tests/cxx/mock_rccl.cpp: operations between a pair match in program order,
+    counts must agree, every rank must reach its group end; loaded through the AVR_RCCL_LIBRARY
+    hook, because RCCL itself refuses two ranks on one device).  What the double cannot show is
+    RCCL's own kernels and the links; what it does show is that every rank issues the operations
+    its peers expect, in the order they expect them: rank 0's frames are the oracle's bit for bit."""
+    subprocess.run(["make", "-C", CXX, "libmock_rccl.so"], check=True, stdout=subprocess.DEVNULL)
+    run_rank_threads(O, tmp_path, n_ranks, policy, antialiasing, frames, flavour,
+                     env={"AVR_RCCL_LIBRARY": os.path.join(CXX, "libmock_rccl.so")})
+
+
+def run_rank_threads(O, tmp_path, n_ranks, policy, antialiasing, frames, flavour, env=None):
     import struct
     from amrvolumerenderer_amd import scenes
     from test_frame_plan import local_indices, oracle_overlay, painted_scene
@@ -96,9 +123,10 @@ def test_adapter_multi_rank_frame_without_python(O, avr_lib, tmp_path, n_ranks, 
             fh.write(np.ascontiguousarray(c, dtype="<f8").tobytes())
     done = subprocess.run([EXE, "frame", str(tmp_path / "scene.bin"), str(n_ranks), str(W), str(H),
                            str(transparency), str(antialiasing), str(frames),
-                           str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin")] +
-                          (["bytes"] if bytes_only else []), check=True,
-                          timeout=300, stdout=subprocess.PIPE, text=True)
+                           str(tmp_path / "image.bin"), str(tmp_path / "rgb8.bin"),
+                           "bytes" if bytes_only else "image", flavour], check=True,
+                          timeout=300, stdout=subprocess.PIPE, text=True,
+                          env=dict(os.environ, **(env or {})))
     if frames >= 330 and n_ranks > 1:   # the search moved, and it moved on every rank alike
         distinct = int(done.stdout.split("corun candidates held:")[1].split()[0])
         assert distinct >= 5, done.stdout
