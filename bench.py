@@ -370,6 +370,9 @@ def run(args, state):
         token = [f"/avr_bench_{os.getpid()}_{int(time.time() * 1e3) & 0xffffff:x}"]
         dist.broadcast_object_list(token, src=0, group=group)
         rehearsal_comm = runtime.Comm.shared(token[0], rank, world, 512 << 20)
+        # the control plane the real run uses (gloo through the C ABI's callback), so that the
+        # rehearsal exercises it too: plan agreement and co-run windows travel over it
+        rehearsal_comm.set_control(runtime.control_over_process_group(group))
     renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
                              spec.scalar_range, rank, world, group, comm=rehearsal_comm,
                              stage_through_host=(args.rehearse_on_one_gpu and
