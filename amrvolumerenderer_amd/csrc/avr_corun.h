@@ -65,6 +65,7 @@ struct CoRunTuner {
   // and config-3: 0.402 in the search, 0.381 held) and the paired layout as it is: paired is only
   // gone on with if it wins by more than that.
   static constexpr float kPairedMargin = 1.02f;
+  static constexpr float kPairedMaxPeriodMs = 0.35f;  // one rank: frames longer than this never pair
   int verify[3] = {0, 0, 0}, n_verify = 0, verify_at = 0;  // kVerify: candidates re-timed in turn
   int refined = 0, repeated = 0;
   bool drift_suspected = false;  // kHold: the last window read slow
@@ -297,7 +298,14 @@ struct CoRunTuner {
         next = (last >= 0) ? 0 : -2;
       } else if (!is_paired(candidate)) {
         next = candidate + kCoarse;
-        if (next > last_beside) next = (last >= kPairedBase) ? std::max(first, kPairedBase) : -2;
+        if (next > last_beside) {
+          // The paired layout pays for SHORT kernels (a rank of four or eight: 0.15-0.3 ms frames);
+          // one rank with frames above 0.35 ms has never held it (config-2 0.414 against 0.377 ms,
+          // config-3, config-4 1.015 against 0.986): its eight coarse windows are not spent there.
+          const bool worth_pairing = !(start_beside && best_ms > kPairedMaxPeriodMs);
+          next = (last >= kPairedBase && (worth_pairing || first >= kPairedBase))
+                     ? std::max(first, kPairedBase) : -2;
+        }
       } else {
         next = candidate + kPairedCoarse;
         if (next > last) next = -2;
