@@ -456,6 +456,14 @@ def run(args, state):
 
     if args.fly_through and renderer.native is not None:
         renderer.native.set_tighten(True)   # forgets the plans the sample counting left behind
+        if world > 1:
+            # every frame of a fly-through has a NEW plan: agreeing on each over the control plane
+            # (a gloo allgather: a few tenths of a millisecond) would cost more than a rank of
+            # eight's frame.  The ranks' first plans were agreed on above (same scene, settings and
+            # camera path on every rank by construction of this script), so the check is off from
+            # here on -- what avr_renderer_set_plan_check(0) is for; the deadline still ends a
+            # frame whose ranks were driven apart.
+            renderer.native.set_plan_check(False)
 
     # A scripted fly-through knows its next camera: for N > 1 the plan of frame f + 1 is made on a
     # helper thread while frame f is queued (avr_renderer_prepare; at N = 1 a plan costs the host
