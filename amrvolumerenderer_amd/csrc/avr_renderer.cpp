@@ -199,6 +199,7 @@ struct avr_renderer {
     avr::PieceMapDev pieces{};
     std::vector<int64_t> begin, end;  // every rank's piece in the gathered buffer (pixels)
     int own_piece = 0;
+    bool own_in_place = true;         // the root's assemble pass reads its own piece where it lies
     const uint8_t* piece = nullptr;   // this rank's RGB8 piece of that frame
     uint8_t* out = nullptr;           // root: that frame's rgb8_out
   } pending;
@@ -742,12 +743,13 @@ int avr_renderer_synchronize(avr_renderer* r) {
       op.full = gathered;
       op.begin = pending.begin.data();
       op.end = pending.end.data();
-      op.skip_own = 1;
+      op.skip_own = pending.own_in_place ? 1 : 0;
       abi_ok(avr_gather_run(r->compose, r->comm, &op));
       if (r->rank == 0 &&
           avr::launch_assemble_rows(pending.pieces, gathered,
                                     static_cast<int64_t>(pending.pieces.width) * 3, /*flip=*/1,
-                                    pending.out, r->stream_of(r->compose), pending.piece,
+                                    pending.out, r->stream_of(r->compose),
+                                    pending.own_in_place ? pending.piece : nullptr,
                                     pending.own_piece) != AVR_OK) {
         throw std::runtime_error(avr_last_error());
       }
@@ -1228,14 +1230,18 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         rider.full = gathered_rgb8;
         rider.begin = pending.begin.data();
         rider.end = pending.end.data();
-        rider.skip_own = 1;  // (the assemble pass reads the root's own piece where its fold wrote it)
+        // (the assemble pass reads the root's own piece where its fold wrote it -- unless the
+        // reference's contiguous pieces cut through rows)
+        rider.skip_own = pending.own_in_place ? 1 : 0;
       }
       abi_ok(avr_exchange_peers_gather(r->compose, plan, r->comm, send, recv,
                                        pending.valid ? &rider : nullptr));
       if (pending.valid && is_root) {
         if (avr::launch_assemble_rows(pending.pieces, gathered_rgb8,
                                       static_cast<int64_t>(pending.pieces.width) * 3, /*flip=*/1,
-                                      pending.out, stream_x, pending.piece, pending.own_piece) != AVR_OK) {
+                                      pending.out, stream_x,
+                                      pending.own_in_place ? pending.piece : nullptr,
+                                      pending.own_piece) != AVR_OK) {
           throw std::runtime_error(avr_last_error());
         }
       }
@@ -1271,6 +1277,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       pending.end.resize(static_cast<size_t>(r->n_ranks));
       abi_ok(avr_frame_plan_piece_ranges(plan, pending.begin.data(), pending.end.data()));
       pending.own_piece = plan->piece_of_rank[static_cast<size_t>(r->rank)];
+      pending.own_in_place = banded || (plan->pieces.width > 0 &&
+                                        plan->pieces.piece_size % plan->pieces.width == 0);
       pending.piece = piece_rgb8;
       pending.out = rgb8_out;
     } else if (early_rgb8) {

@@ -272,7 +272,8 @@ def test_native_rccl_exchange_and_gather_with_one_rank(O):
     comm.close()
 
 
-def _native_worker(rank, world, port, policy, antialiasing, name, out_path, bytes_only=False):
+def _native_worker(rank, world, port, policy, antialiasing, name, out_path, bytes_only=False,
+                   contiguous=False):
     """One rank PROCESS of the C++ frame driver on the shared GPU: avr_renderer with the
     cross-process rehearsal communicator (avr_comm_create_shared) -- the plans, offsets and
     ordering of the RCCL flavour, blocks through a shared-memory segment."""
@@ -304,6 +305,9 @@ def _native_worker(rank, world, port, policy, antialiasing, name, out_path, byte
         renderer = FrameRenderer(ctx, meta, local, spec.transform, spec.bounds, spec.scalar_range,
                                  rank, world, dist.group.WORLD, comm=comm)
         assert renderer.native is not None
+        H = globals()["H"] + (1 if contiguous == 2 else 0)   # 73 rows: a third / half cuts a row
+        if contiguous:   # the reference's contiguous pieces
+            renderer.native.set_piece_layout(0, 1)
         # pipelined: three frames (two cameras, the first one again) without a host sync between
         # (bytes_only: no float image is asked for, so the RGB8 pieces of a frame travel to rank 0
         # with the NEXT frame's grouped round and the last frame's with the synchronise: every
@@ -313,7 +317,8 @@ def _native_worker(rank, world, port, policy, antialiasing, name, out_path, byte
                   for cam in cams]
         renderer.synchronize()
         info = renderer.native.plan_info()
-        assert info.piece_layout == 1 and info.band_rows == 8      # the driver's row bands
+        assert info.piece_layout == (0 if contiguous else 1), (info.piece_layout, info.band_rows)
+        assert contiguous or info.band_rows == 8      # the driver's row bands
         if rank == 0:
             flags = []
             for cam, (image, rgb8) in zip(cams, frames):
@@ -338,18 +343,23 @@ def _native_worker(rank, world, port, policy, antialiasing, name, out_path, byte
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,policy,antialiasing,bytes_only", [
-    (3, "level_pairs", 1, False), (2, "morton", 4, False), (4, "round_robin", 1, False),
-    (3, "level_pairs", 1, True), (4, "morton", 1, True)])
-def test_native_driver_across_processes(tmp_path, world, policy, antialiasing, bytes_only):
+@pytest.mark.parametrize("world,policy,antialiasing,bytes_only,contiguous", [
+    (3, "level_pairs", 1, False, False), (2, "morton", 4, False, False),
+    (4, "round_robin", 1, False, False), (3, "level_pairs", 1, True, False),
+    (4, "morton", 1, True, False),
+    # the reference's contiguous pieces: over 73 rows they cut through rows (2: the root's own
+    # piece then travels through the gathered buffer), over 72 they do not (1: read in place)
+    (3, "morton", 1, True, 2), (2, "level_pairs", 1, True, 1)])
+def test_native_driver_across_processes(tmp_path, world, policy, antialiasing, bytes_only,
+                                        contiguous):
     """The C++ frame driver as N rank PROCESSES on one GPU (what `bench.py --gpus N` and the
     reference's MPI ranks are), wired by the shared-memory rehearsal communicator: row-band pieces,
     exchange layout tightened from the first frame, frames pipelined; rank 0's frames are the
     oracle's N-rank compose bit for bit."""
     out = tmp_path / "result.txt"
-    name = f"/avr_test_{os.getpid()}_{world}_{antialiasing}_{int(bytes_only)}"
+    name = f"/avr_test_{os.getpid()}_{world}_{antialiasing}_{int(bytes_only)}_{int(contiguous)}"
     mp.spawn(_native_worker, args=(world, _free_port(), policy, antialiasing, name, str(out),
-                                   bytes_only),
+                                   bytes_only, contiguous),
              nprocs=world, join=True)
     flags = out.read_text().split()
     assert len(flags) == 6 and all(f == "1" for f in flags), flags
