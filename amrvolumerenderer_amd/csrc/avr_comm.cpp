@@ -1046,176 +1046,176 @@ namespace {
 // in the grouped round of frame f + 1).  in_group: an RCCL group is open (the caller closes it);
 // skip_own: the root does not copy its own piece (its assemble pass reads it where it is).
 void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool in_group) {
-    hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
-    const int n = comm->n_ranks, me = comm->rank;
-    const int bytes_per_pixel = op.bytes_per_pixel, root = op.root;
-    const void* piece = op.piece;
-    void* full = op.full;
-    require(bytes_per_pixel > 0 && root >= 0 && root < n && op.begin != nullptr && op.end != nullptr,
-            "invalid gather");
-    auto piece_range = [&](int rank, int64_t* begin, int64_t* end) {
-      *begin = op.begin[rank];
-      *end = op.end[rank];
-    };
-    const bool copy_own = op.skip_own == 0;
-    int64_t my_begin = 0, my_end = 0;
-    piece_range(me, &my_begin, &my_end);
-    require(my_end == my_begin || piece != nullptr, "null piece");
-    bool anything = false;
-    for (int s = 0; s < n; ++s) anything = anything || op.end[s] > op.begin[s];
-    require(me != root || full != nullptr || !anything, "null destination on the root");
-    char* dst = static_cast<char*>(full);
-    if (comm->solo) {
-      if (me == root && my_end > my_begin && copy_own) {
-        avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
-                                   static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
-                                   hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
-      }
-      if (comm->nccl != nullptr && my_end > my_begin) {
-        // through RCCL to this rank itself (timing only, as avr_exchange): the root receives a
-        // piece from every other rank, the others send theirs
-        const avr::Rccl& api = avr::rccl();
-        const size_t bytes = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
-        if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
-        if (me != root) {
-          // (no destination buffer off the root: the piece's first half lands on its second --
-          // the piece has been handed over by then, and a solo rank's pixels mean nothing)
-          const size_t half = bytes / 2;
-          if (half > 0) {
-            char* target = static_cast<char*>(const_cast<void*>(piece)) + half;
-            avr::nccl_ok(api.send(piece, half, ncclUint8, 0, comm->nccl, stream), "ncclSend");
-            avr::nccl_ok(api.recv(target, half, ncclUint8, 0, comm->nccl, stream), "ncclRecv");
-          }
-        } else {
-          bool one_done = false;
-          for (int s = 0; s < n; ++s) {
-            if (s == me) continue;
-            if (comm->solo_percent == 0 && one_done) break;  // "one link": one peer's piece
-            int64_t b = 0, e = 0;
-            piece_range(s, &b, &e);
-            const size_t count = std::min(bytes, static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel));
-            if (count == 0) continue;
-            one_done = true;
-            avr::nccl_ok(api.send(piece, count, ncclUint8, 0, comm->nccl, stream), "ncclSend");
-            avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, count, ncclUint8, 0, comm->nccl, stream),
-                         "ncclRecv");
-          }
-        }
-        if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
-      }
-      return;
-    }
-    if (comm->shared) {
-      avr::SharedWorld& world = *comm->shared;
-      const size_t mine = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
-      if (mine > world.capacity) {
-        throw std::runtime_error("shared communicator: the piece exceeds the segment's capacity");
-      }
-      std::exception_ptr failure;
-      try {
-        drain(stream);
-        if (mine > 0 && me != root) {
-          avr::hip_ok(hipMemcpy(world.region(me), piece, mine, hipMemcpyDeviceToHost), "hipMemcpy(gather)");
-        }
-      } catch (...) {
-        failure = std::current_exception();
-      }
-      try {
-        world.meet(me, 3, static_cast<uint64_t>(bytes_per_pixel));
-      } catch (const avr::CallsDiffer&) {
-        throw;
-      } catch (const avr::DeadlineExceeded&) {
-        throw;
-      } catch (...) {
-        if (!failure) failure = std::current_exception();
-      }
-      try {
-        if (failure) std::rethrow_exception(failure);
-        if (me == root) {
-          for (int s = 0; s < n; ++s) {
-            int64_t b = 0, e = 0;
-            piece_range(s, &b, &e);
-            if (e == b) continue;
-            const size_t bytes = static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel);
-            if (s == me) {
-              if (copy_own) {
-                avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, piece, bytes, hipMemcpyDeviceToDevice),
-                            "hipMemcpy(gather)");
-              }
-            } else {
-              avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, world.region(s), bytes, hipMemcpyHostToDevice),
-                          "hipMemcpy(gather)");
-            }
-          }
-        }
-      } catch (...) {
-        failure = std::current_exception();
-      }
-      world.barrier();
-      if (failure) std::rethrow_exception(failure);
-      return;
-    }
-    if (comm->local) {
-      avr::LocalWorld& world = *comm->local;
-      drain(stream);
-      world.base[static_cast<size_t>(me)] = static_cast<const char*>(piece);
-      std::exception_ptr failure;
-      try {
-        world.meet(me, 3, static_cast<uint64_t>(bytes_per_pixel));
-        if (me == root) {
-          for (int s = 0; s < n; ++s) {
-            int64_t b = 0, e = 0;
-            piece_range(s, &b, &e);
-            if (e == b || (s == me && !copy_own)) continue;
-            avr::hip_ok(hipMemcpyAsync(dst + b * bytes_per_pixel, world.base[static_cast<size_t>(s)],
-                                       static_cast<size_t>(e - b) * bytes_per_pixel,
-                                       hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
-          }
-          drain(stream);
-        }
-      } catch (const avr::CallsDiffer&) {
-        throw;
-      } catch (const avr::DeadlineExceeded&) {
-        throw;
-      } catch (...) {
-        failure = std::current_exception();
-      }
-      world.barrier();
-      if (failure) std::rethrow_exception(failure);
-      return;
-    }
-    const avr::Rccl& api = avr::rccl();
-    if (n == 1) {  // as in avr_exchange: the one-rank case goes through RCCL on purpose
-      if (my_end > my_begin) {
-        const size_t bytes = static_cast<size_t>(my_end - my_begin) * bytes_per_pixel;
-        if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
-        avr::nccl_ok(api.send(piece, bytes, ncclChar, 0, comm->nccl, stream), "ncclSend");
-        avr::nccl_ok(api.recv(dst + my_begin * bytes_per_pixel, bytes, ncclChar, 0, comm->nccl, stream),
-                     "ncclRecv");
-        if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
-      }
-      return;
-    }
+  hipStream_t stream = static_cast<hipStream_t>(avr::context_stream(ctx));
+  const int n = comm->n_ranks, me = comm->rank;
+  const int bytes_per_pixel = op.bytes_per_pixel, root = op.root;
+  const void* piece = op.piece;
+  void* full = op.full;
+  require(bytes_per_pixel > 0 && root >= 0 && root < n && op.begin != nullptr && op.end != nullptr,
+          "invalid gather");
+  auto piece_range = [&](int rank, int64_t* begin, int64_t* end) {
+    *begin = op.begin[rank];
+    *end = op.end[rank];
+  };
+  const bool copy_own = op.skip_own == 0;
+  int64_t my_begin = 0, my_end = 0;
+  piece_range(me, &my_begin, &my_end);
+  require(my_end == my_begin || piece != nullptr, "null piece");
+  bool anything = false;
+  for (int s = 0; s < n; ++s) anything = anything || op.end[s] > op.begin[s];
+  require(me != root || full != nullptr || !anything, "null destination on the root");
+  char* dst = static_cast<char*>(full);
+  if (comm->solo) {
     if (me == root && my_end > my_begin && copy_own) {
       avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
                                  static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                  hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
     }
-    if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
-    if (me == root) {
-      for (int s = 0; s < n; ++s) {
-        if (s == root) continue;
-        int64_t b = 0, e = 0;
-        piece_range(s, &b, &e);
-        if (e == b) continue;
-        avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, static_cast<size_t>(e - b) * bytes_per_pixel,
-                              ncclChar, s, comm->nccl, stream), "ncclRecv");
+    if (comm->nccl != nullptr && my_end > my_begin) {
+      // through RCCL to this rank itself (timing only, as avr_exchange): the root receives a
+      // piece from every other rank, the others send theirs
+      const avr::Rccl& api = avr::rccl();
+      const size_t bytes = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
+      if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
+      if (me != root) {
+        // (no destination buffer off the root: the piece's first half lands on its second --
+        // the piece has been handed over by then, and a solo rank's pixels mean nothing)
+        const size_t half = bytes / 2;
+        if (half > 0) {
+          char* target = static_cast<char*>(const_cast<void*>(piece)) + half;
+          avr::nccl_ok(api.send(piece, half, ncclUint8, 0, comm->nccl, stream), "ncclSend");
+          avr::nccl_ok(api.recv(target, half, ncclUint8, 0, comm->nccl, stream), "ncclRecv");
+        }
+      } else {
+        bool one_done = false;
+        for (int s = 0; s < n; ++s) {
+          if (s == me) continue;
+          if (comm->solo_percent == 0 && one_done) break;  // "one link": one peer's piece
+          int64_t b = 0, e = 0;
+          piece_range(s, &b, &e);
+          const size_t count = std::min(bytes, static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel));
+          if (count == 0) continue;
+          one_done = true;
+          avr::nccl_ok(api.send(piece, count, ncclUint8, 0, comm->nccl, stream), "ncclSend");
+          avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, count, ncclUint8, 0, comm->nccl, stream),
+                       "ncclRecv");
+        }
       }
-    } else if (my_end > my_begin) {
-      avr::nccl_ok(api.send(piece, static_cast<size_t>(my_end - my_begin) * bytes_per_pixel, ncclChar,
-                            root, comm->nccl, stream), "ncclSend");
+      if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
     }
-    if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    return;
+  }
+  if (comm->shared) {
+    avr::SharedWorld& world = *comm->shared;
+    const size_t mine = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
+    if (mine > world.capacity) {
+      throw std::runtime_error("shared communicator: the piece exceeds the segment's capacity");
+    }
+    std::exception_ptr failure;
+    try {
+      drain(stream);
+      if (mine > 0 && me != root) {
+        avr::hip_ok(hipMemcpy(world.region(me), piece, mine, hipMemcpyDeviceToHost), "hipMemcpy(gather)");
+      }
+    } catch (...) {
+      failure = std::current_exception();
+    }
+    try {
+      world.meet(me, 3, static_cast<uint64_t>(bytes_per_pixel));
+    } catch (const avr::CallsDiffer&) {
+      throw;
+    } catch (const avr::DeadlineExceeded&) {
+      throw;
+    } catch (...) {
+      if (!failure) failure = std::current_exception();
+    }
+    try {
+      if (failure) std::rethrow_exception(failure);
+      if (me == root) {
+        for (int s = 0; s < n; ++s) {
+          int64_t b = 0, e = 0;
+          piece_range(s, &b, &e);
+          if (e == b) continue;
+          const size_t bytes = static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel);
+          if (s == me) {
+            if (copy_own) {
+              avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, piece, bytes, hipMemcpyDeviceToDevice),
+                          "hipMemcpy(gather)");
+            }
+          } else {
+            avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, world.region(s), bytes, hipMemcpyHostToDevice),
+                        "hipMemcpy(gather)");
+          }
+        }
+      }
+    } catch (...) {
+      failure = std::current_exception();
+    }
+    world.barrier();
+    if (failure) std::rethrow_exception(failure);
+    return;
+  }
+  if (comm->local) {
+    avr::LocalWorld& world = *comm->local;
+    drain(stream);
+    world.base[static_cast<size_t>(me)] = static_cast<const char*>(piece);
+    std::exception_ptr failure;
+    try {
+      world.meet(me, 3, static_cast<uint64_t>(bytes_per_pixel));
+      if (me == root) {
+        for (int s = 0; s < n; ++s) {
+          int64_t b = 0, e = 0;
+          piece_range(s, &b, &e);
+          if (e == b || (s == me && !copy_own)) continue;
+          avr::hip_ok(hipMemcpyAsync(dst + b * bytes_per_pixel, world.base[static_cast<size_t>(s)],
+                                     static_cast<size_t>(e - b) * bytes_per_pixel,
+                                     hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+        }
+        drain(stream);
+      }
+    } catch (const avr::CallsDiffer&) {
+      throw;
+    } catch (const avr::DeadlineExceeded&) {
+      throw;
+    } catch (...) {
+      failure = std::current_exception();
+    }
+    world.barrier();
+    if (failure) std::rethrow_exception(failure);
+    return;
+  }
+  const avr::Rccl& api = avr::rccl();
+  if (n == 1) {  // as in avr_exchange: the one-rank case goes through RCCL on purpose
+    if (my_end > my_begin) {
+      const size_t bytes = static_cast<size_t>(my_end - my_begin) * bytes_per_pixel;
+      if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
+      avr::nccl_ok(api.send(piece, bytes, ncclChar, 0, comm->nccl, stream), "ncclSend");
+      avr::nccl_ok(api.recv(dst + my_begin * bytes_per_pixel, bytes, ncclChar, 0, comm->nccl, stream),
+                   "ncclRecv");
+      if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    }
+    return;
+  }
+  if (me == root && my_end > my_begin && copy_own) {
+    avr::hip_ok(hipMemcpyAsync(dst + my_begin * bytes_per_pixel, piece,
+                               static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
+                               hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
+  }
+  if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
+  if (me == root) {
+    for (int s = 0; s < n; ++s) {
+      if (s == root) continue;
+      int64_t b = 0, e = 0;
+      piece_range(s, &b, &e);
+      if (e == b) continue;
+      avr::nccl_ok(api.recv(dst + b * bytes_per_pixel, static_cast<size_t>(e - b) * bytes_per_pixel,
+                            ncclChar, s, comm->nccl, stream), "ncclRecv");
+    }
+  } else if (my_end > my_begin) {
+    avr::nccl_ok(api.send(piece, static_cast<size_t>(my_end - my_begin) * bytes_per_pixel, ncclChar,
+                          root, comm->nccl, stream), "ncclSend");
+  }
+  if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
 }
 
 // the ranges of a plan's pieces in the gathered buffer: a rank's pixel range of the image
