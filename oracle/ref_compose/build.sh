@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds oracle/_ref/ref_compose: the REFERENCE's compositor (its own translation units, compiled
+# Builds oracle/_ref/ref_compose and oracle/_ref/ref_blend: the REFERENCE's compositor / image classes (its own translation units, compiled
 # where they lie under /root/reference -- nothing is copied) + oracle/ref_compose/driver.cpp.
 #   Common/Image.cpp  Common/ImageRGBAFloatColorDepthSort.cpp  Common/ImageSparse.cpp
 #   Common/LayeredVolumeImage.cpp  Common/SavePPM.cpp  DirectSend/Base/DirectSendBase.cpp
@@ -28,4 +28,10 @@ g++ -std=c++20 -O2 -I"$OUT/include" -I"$REF" -I"$OUT/mpi" \
   "$REF/Common/LayeredVolumeImage.cpp" "$REF/Common/SavePPM.cpp" "$REF/DirectSend/Base/DirectSendBase.cpp" \
   "$HERE/driver.cpp" \
   -static-libstdc++ -static-libgcc "$MPI/lib/libmpi.so" -Wl,-rpath,"$MPI/lib" -o "$OUT/ref_compose"
-echo "built $OUT/ref_compose"
+# the reference's image classes alone (blend / regions / ubyte encode-decode): oracle/_ref/ref_blend
+g++ -std=c++20 -O2 -I"$OUT/include" -I"$REF" -I"$OUT/mpi" \
+  "$REF/Common/Image.cpp" "$REF/Common/ImageRGBAFloatColorDepthSort.cpp" "$REF/Common/ImageRGBAFloatColorOnly.cpp" \
+  "$REF/Common/ImageRGBAUByteColorOnly.cpp" "$REF/Common/ImageSparse.cpp" \
+  "$HERE/blend_driver.cpp" \
+  -static-libstdc++ -static-libgcc "$MPI/lib/libmpi.so" -Wl,-rpath,"$MPI/lib" -o "$OUT/ref_blend"
+echo "built $OUT/ref_compose and $OUT/ref_blend"
