@@ -1017,14 +1017,26 @@ __device__ __forceinline__ uint32_t component_as_byte(float c) {
   return static_cast<uint32_t>((tv < 0) ? 0 : (tv > 255) ? 255 : tv);
 }
 
+// The same for ARBITRARY floats (encodeColor of a caller's colour, Common/ImageRGBAUByteColorOnly.cpp:
+// 16-27).  int(c * 256.f) is undefined in C++ when the product does not fit an int; on the CPU the
+// reference runs on (x86-64: cvttss2si) it is INT_MIN for NaN and for |product| >= 2^31, hence byte
+// 0 -- where this GPU's conversion saturates (3e9 -> 255).  Found by the vectors made with the
+// reference's own object code (tests/golden/ref_blend.npz); the frame's own colours (<= 1 after the
+// march's clamp) never get there, so the hot kernels keep the plain conversion.
+__device__ __forceinline__ uint32_t component_as_byte_of_any_float(float c) {
+  const float t = c * 256.f;
+  const int tv = (t >= -2147483648.f && t < 2147483648.f) ? static_cast<int>(t) : (-2147483647 - 1);
+  return static_cast<uint32_t>((tv < 0) ? 0 : (tv > 255) ? 255 : tv);
+}
+
 __global__ void encode_u8_kernel(const float4* __restrict__ rgba, uint32_t* __restrict__ out,
                                  int64_t n) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < n;
        p += stride) {
     const float4 c = rgba[p];
-    out[p] = component_as_byte(c.x) | (component_as_byte(c.y) << 8) |
-             (component_as_byte(c.z) << 16) | (component_as_byte(c.w) << 24);
+    out[p] = component_as_byte_of_any_float(c.x) | (component_as_byte_of_any_float(c.y) << 8) |
+             (component_as_byte_of_any_float(c.z) << 16) | (component_as_byte_of_any_float(c.w) << 24);
   }
 }
 

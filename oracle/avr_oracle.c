@@ -874,7 +874,11 @@ void orc_blend_regions(int kind, const void *top, int tb, int te, const void *bo
 }
 
 static inline unsigned char component_as_byte(float c) { /* Color.hpp:86-90 */
-  const int tv = (int)(c * 256.f);
+  /* int(c * 256.f) is undefined in C when the product does not fit an int; what the reference gets on
+     the CPU it runs on (x86-64, cvttss2si: INT_MIN for NaN and |product| >= 2^31) is spelled out, so
+     that this restatement does not depend on the compiler (pinned by tests/golden/ref_blend.npz) */
+  const float t = c * 256.f;
+  const int tv = (t >= -2147483648.f && t < 2147483648.f) ? (int)t : (-2147483647 - 1);
   return (unsigned char)((tv < 0) ? 0 : (tv > 255) ? 255 : tv);
 }
 
