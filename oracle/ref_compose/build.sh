@@ -25,6 +25,7 @@ ln -sf "$MPI"/include/mpi*.h "$OUT/mpi/"
 #  static libstdc++: conda's older one must not be picked up through the MPI rpath)
 g++ -std=c++20 -O2 -I"$OUT/include" -I"$REF" -I"$OUT/mpi" \
   "$REF/Common/Image.cpp" "$REF/Common/ImageRGBAFloatColorDepthSort.cpp" "$REF/Common/ImageSparse.cpp" \
+  "$REF/Common/ImageRGBAFloatColorOnly.cpp" "$REF/Common/ImageRGBAUByteColorOnly.cpp" \
   "$REF/Common/LayeredVolumeImage.cpp" "$REF/Common/SavePPM.cpp" "$REF/DirectSend/Base/DirectSendBase.cpp" \
   "$HERE/driver.cpp" \
   -static-libstdc++ -static-libgcc "$MPI/lib/libmpi.so" -Wl,-rpath,"$MPI/lib" -o "$OUT/ref_compose"

@@ -90,6 +90,54 @@ def run_reference(layers, hints, owner, n_ranks, reverse=False):
     return image, regions, rgb8
 
 
+def classic_images(kind, n_ranks, seed=31):
+    """One plain image per rank for the classic direct send (kinds as in make_ref_blend.py)."""
+    rng = np.random.default_rng(seed + 7 * kind)
+    p = W * H
+    images = []
+    for _ in range(n_ranks):
+        if kind == 2:
+            images.append(rng.integers(0, 2 ** 32, p, dtype=np.uint64).astype(np.uint32))
+            continue
+        vec = 5 if kind == 0 else 4
+        alpha = rng.random(p, dtype=np.float32)
+        alpha[rng.random(p) < 0.25] = 0.0
+        img = np.zeros((p, vec), np.float32)
+        img[:, :3] = rng.random((p, 3), dtype=np.float32) * alpha[:, None]
+        img[:, 3] = alpha
+        if vec == 5:
+            depth = (1.0 + 3.0 * rng.random(p, dtype=np.float32)).astype(np.float32)
+            img[:, 4] = np.where(alpha > 0, depth, np.inf)
+        images.append(img)
+    return images
+
+
+def run_classic(kind, images, reverse=False):
+    n_ranks = len(images)
+    with tempfile.TemporaryDirectory() as tmp:
+        src, dst = os.path.join(tmp, "images.bin"), os.path.join(tmp, "out.bin")
+        with open(src, "wb") as fh:
+            fh.write(struct.pack("<3i", W, H, n_ranks))
+            for image in images:
+                fh.write(np.ascontiguousarray(image).tobytes())
+        cmd = [MPIEXEC, "-n", str(n_ranks), BINARY, "classic", str(kind), src, dst] + (
+            ["reverse"] if reverse else [])
+        subprocess.run(cmd, check=True, timeout=300)
+        raw = open(dst, "rb").read()
+    n = struct.unpack_from("<i", raw, 0)[0]
+    regions = np.frombuffer(raw, "<i4", 2 * n, 4).reshape(n, 2).copy()
+    dtype = np.uint32 if kind == 2 else np.float32
+    image = np.frombuffer(raw, dtype, offset=4 + 8 * n).copy()
+    return image, regions
+
+
+CLASSIC = [(kind, n, reverse) for kind in (0, 1, 2) for n, reverse in ((1, False), (2, False), (2, True))]
+
+
+def classic_name(kind, n, reverse):
+    return f"classic_kind{kind}_n{n}" + ("_reversed" if reverse else "")
+
+
 CASES = ([(n, policy, False, False) for n in (1, 2, 3, 4, 8) for policy in ("round_robin", "block")]
          + [(4, "block", True, False), (3, "round_robin", True, False), (3, "rank1_empty", False, False),
             (4, "block", False, True), (2, "round_robin", False, True)])
@@ -116,6 +164,15 @@ def main():
         out[name + "/rgb8"] = rgb8       # the reference's SavePPM of it: rows top-down
         out[name + "/regions"] = regions
         out[name + "/owner"] = np.asarray(owner, np.int32)
+        print(f"{name}: pieces {regions.tolist()}")
+    # the classic direct send of ONE plain image per rank (DirectSendBase.cpp:257-281): two ranks
+    # have one blend and therefore one answer (the first group member on top)
+    for kind, n, reverse in CLASSIC:
+        images = classic_images(kind, n)
+        image, regions = run_classic(kind, images, reverse)
+        name = classic_name(kind, n, reverse)
+        out[name + "/image"] = image
+        out[name + "/regions"] = regions
         print(f"{name}: pieces {regions.tolist()}")
     np.savez_compressed(os.path.join(HERE, "ref_compose.npz"), **out)
     print("wrote tests/golden/ref_compose.npz")
