@@ -873,11 +873,30 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     // are still in the caches if they were stored plainly: a rank of eight 0.143 ms plain, 0.149
     // streamed (the march's L2 hit rate is 63.4 % either way, tools/share_cache_pmc.sh: what helps
     // sits below L2, in the memory-side cache, or is the write traffic itself).
+#ifdef AVR_EXPERIMENT_CLASSIFY_NO_STORES
+    // experiment build only (profiles/r4_contention/): the pass without its write stream (the
+    // condition never holds; it keeps the conversion alive)
+    if (v.x == 0xdeadbeefu && v.y == 0xfeedfaceu) *target = v;
+#elif defined(AVR_EXPERIMENT_CLASSIFY_CONTIGUOUS_STORES)
+    // experiment build only: the same bytes written as ONE contiguous 2 KiB block per workgroup
+    // (the wrong place: timing only) -- what a brick order whose x-neighbours are adjacent in
+    // memory would give the write stream
+    {
+      uint2* const packed_target = reinterpret_cast<uint2*>(
+          classified + static_cast<uint64_t>(blockIdx.x) * 2048u + static_cast<uint32_t>(t) * 8u);
+      if (stream_stores != 0) {
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(packed_target), "v"(v) : "memory");
+      } else {
+        *packed_target = v;
+      }
+    }
+#else
     if (stream_stores != 0) {  // (wave-uniform)
       asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(target), "v"(v) : "memory");
     } else {
       *target = v;
     }
+#endif
   }
 }
 
