@@ -69,6 +69,10 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostics: no HIP timing events around the two paint kernels in the "
                          "timed region (roofline.kernel_ms is then the frame time itself)")
+    ap.add_argument("--debug-stall-rank", type=int, default=-1,
+                    help="test hook: this rank stops rendering after the settling frames and sleeps "
+                         "(a peer that hangs): the others must run into AVR_FRAME_TIMEOUT_MS, say "
+                         "where, and the launch must end non-zero")
     ap.add_argument("--no-coordination", action="store_true",
                     help="N > 1, A/B only: every rank runs the co-run search on its own (round 3) "
                          "instead of all ranks as one system (avr_renderer_set_corun_coordination)")
@@ -531,6 +535,9 @@ def run(args, state):
     renderer.synchronize()
     params, _ = renderer.make_params(rparams)
     native = renderer.native is not None
+    if args.debug_stall_rank == rank and world > 1:
+        print(f"bench.py: rank {rank} stalls on purpose (--debug-stall-rank)", file=sys.stderr, flush=True)
+        time.sleep(3600)
     for i in range(args.warmup):
         step(i)
 

@@ -573,6 +573,30 @@ def test_bench_multi_rank_flow_on_one_gpu(n_ranks):
     assert line["value"] > 0 and line["cpu_baseline"] is None
 
 
+def test_bench_ends_with_an_error_when_a_rank_hangs():
+    """`bench.py --gpus 3` (rehearsed on one GPU) with one rank that stops rendering and sleeps: its
+    peers run into AVR_FRAME_TIMEOUT_MS (4 s here), print which rank failed where and how its co-run
+    search stood, and the launch ends non-zero within seconds instead of sitting to the launcher's
+    own limit."""
+    import subprocess
+    import time
+    env = dict(os.environ, AVR_FRAME_TIMEOUT_MS="4000")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    begin = time.monotonic()
+    done = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rehearse-on-one-gpu",
+         "--config", "tiny", "--steps", "4", "--warmup", "2", "--debug-stall-rank", "1"],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    elapsed = time.monotonic() - begin
+    assert done.returncode != 0
+    assert not [l for l in done.stdout.splitlines() if l.startswith('{"metric"')]
+    assert "rank 1 stalls on purpose" in done.stderr
+    assert "failed: AvrError" in done.stderr and "AVR_FRAME_TIMEOUT_MS" in done.stderr
+    assert "renderer:" in done.stderr and "corun_state:" in done.stderr and "stage:" in done.stderr
+    assert elapsed < 120, elapsed
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("percent", [100, 25, 0])
 def test_one_rank_of_four_played_through_rccl(percent):
