@@ -96,3 +96,59 @@ def test_directsend_over_gloo(tmp_path, O, avr_lib, world, policy, group):
     assert ok == "1", "gathered float image differs from the oracle's layered compose"
     assert ok8 == "1", "gathered RGB8 bytes differ"
     assert int(runs) >= world
+
+
+def _control_worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        from amrvolumerenderer_amd import _capi, runtime, scenes
+        from amrvolumerenderer_amd.compositor import FramePlan
+        from amrvolumerenderer_amd.types import make_params
+
+        lib = _capi.lib()
+        spec = scenes.make_amr_scene(32, 2, 8, "smooth")
+        scenes.assign_owners(spec, world, "level_pairs")
+        boxes = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+        params = make_params(W, H, spec.scalar_range, TRANSPARENCY, 0.01, spec.bounds)
+        # the communicator of the multi-process rehearsal, its control plane the CALLER's: gloo,
+        # reached from inside the C ABI through the callback (what bench.py --gpus N installs)
+        comm = runtime.Comm.shared(name, rank, world, 1 << 20)
+        comm.set_control(runtime.control_over_process_group(dist.group.WORLD))
+        results = []
+        everybody = comm.control_allgather(bytes([rank + 1] * 8))
+        results.append(everybody == [bytes([r + 1] * 8) for r in range(world)])
+        plan = FramePlan(boxes, params, scenes.default_camera(), rank, world)
+        _capi.check(lib.avr_frame_plan_agree(plan._handle, comm._handle, None, 3))
+        results.append(True)
+        # rank 1 is handed another camera: every rank gets the error, over gloo too
+        other = FramePlan(boxes, params, scenes.orbit_camera(5) if rank == 1 else scenes.default_camera(),
+                          rank, world)
+        try:
+            _capi.check(lib.avr_frame_plan_agree(other._handle, comm._handle, None, 3))
+            results.append(False)
+        except _capi.AvrError as error:
+            results.append("rank 1's plan differs from rank 0's" in str(error))
+        results.append(comm.control_rounds() == 3)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as fh:
+            fh.write(" ".join(str(int(bool(r))) for r in results))
+        dist.barrier()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plan_agreement_over_the_callers_control_plane(tmp_path, avr_lib):
+    """Two and three rank PROCESSES on the CPU: the communicator's small host-side agreements
+    (avr_comm_control_allgather, avr_frame_plan_agree) travel over the caller's control plane --
+    gloo here, MPI_Allgather in the reference's host -- through the C ABI's callback."""
+    for world in (2, 3):
+        name = f"/avr_control_{os.getpid()}_{world}"
+        out_dir = tmp_path / str(world)
+        out_dir.mkdir()
+        mp.spawn(_control_worker, args=(world, _free_port(), name, str(out_dir)), nprocs=world, join=True)
+        for rank in range(world):
+            assert (out_dir / f"rank{rank}.txt").read_text() == "1 1 1 1", (world, rank)
