@@ -198,7 +198,6 @@ SIGNATURES = {
     "avr_quantize_rgb8": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "avr_flip_rows": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "avr_context_create_with_priority": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
-    "avr_context_set_cu_mask_pattern": (C.c_int, [_vp, C.c_uint32]),
     "avr_context_stream": (_vp, [_vp]),
     "avr_comm_unique_id": (C.c_int, [C.c_char_p]),
     "avr_comm_create": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -233,6 +232,7 @@ SIGNATURES = {
                                        _vp, C.c_int, _vp, _vp]),
     "avr_renderer_prepare": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip]),
     "avr_renderer_synchronize": (C.c_int, [_vp]),
+    "avr_renderer_outputs_complete": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "avr_renderer_stream": (_vp, [_vp, C.c_int]),
     "avr_renderer_plan_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),
     "avr_renderer_host_profile": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_int]),

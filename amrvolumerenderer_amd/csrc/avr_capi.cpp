@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/avr_hip_debug.h"
 #include "avr_internal.h"
 #include "avr_plan.h"
 
@@ -51,18 +52,30 @@ void hip_check(hipError_t err, const char* what) {
 // this one: the wait throws, the C ABI call returns AVR_ERR_RUNTIME naming what did not finish.
 namespace {
 std::atomic<int> g_timeout_override{-1};
+thread_local int t_collective_depth = 0;
 }
 void set_frame_timeout_ms(int ms) { g_timeout_override.store(ms < 0 ? -1 : ms); }
+CollectiveScope::CollectiveScope(bool collective) : on_(collective) {
+  if (on_) ++t_collective_depth;
+}
+CollectiveScope::~CollectiveScope() {
+  if (on_) --t_collective_depth;
+}
+// A deadline somebody asked for (avr_set_frame_timeout_ms, AVR_FRAME_TIMEOUT_MS) holds for every
+// wait; the DEFAULT of 30 s only where a collective is involved (a renderer of several ranks, a
+// communicator's own calls): a single-rank context waiting for a deep queue of long frames, or
+// for a GPU it shares with other processes, waits as long as it takes.
 int frame_timeout_ms() {
   const int forced = g_timeout_override.load(std::memory_order_relaxed);
   if (forced >= 0) return forced;
   static const int value = [] {
     const char* text = std::getenv("AVR_FRAME_TIMEOUT_MS");
-    if (text == nullptr || text[0] == '\0') return 30000;
+    if (text == nullptr || text[0] == '\0') return -1;
     const long parsed = std::strtol(text, nullptr, 10);
     return static_cast<int>(std::min<long>(std::max<long>(parsed, 0), 3600000));
   }();
-  return value;
+  if (value >= 0) return value;
+  return t_collective_depth > 0 ? 30000 : 0;
 }
 
 // Host waits poll the event instead of blocking in hipEventSynchronize / hipStreamSynchronize:
@@ -285,7 +298,6 @@ struct avr_context {
   avr_scene scratch_scene;         // classified storage of avr_paint_box
   std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
   int priority = 0;                            // 1: own stream in the highest priority class
-  uint32_t cu_mask_pattern = 0;                // non-zero: own stream restricted to these CUs
   int march_workgroups_per_cu = 0;             // 0 = uncapped
   uint32_t classify_lds_pad = 0;               // avr_context_set_classify_lds_reserve
   bool classify_stream_stores = false;         // context_set_classify_stream_stores
@@ -323,13 +335,7 @@ void bind_device(avr_context* ctx) {
   require(ctx != nullptr, "null context");
   avr::hip_check(hipSetDevice(ctx->device), "hipSetDevice");
   if (ctx->stream == nullptr) {  // no external stream was supplied: create the context's own
-    if (ctx->cu_mask_pattern != 0) {
-      // experiment hook (avr_context_set_cu_mask_pattern): the stream's kernels only run on the
-      // CUs whose bit is set in the pattern, repeated over the device
-      std::vector<uint32_t> mask(8, ctx->cu_mask_pattern);   // 256 CUs
-      avr::hip_check(hipExtStreamCreateWithCUMask(&ctx->own_stream, static_cast<uint32_t>(mask.size()),
-                                                  mask.data()), "hipExtStreamCreateWithCUMask");
-    } else if (ctx->priority != 0) {
+    if (ctx->priority != 0) {
       int least = 0, greatest = 0;  // numerically lower = more urgent
       avr::hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
       avr::hip_check(hipStreamCreateWithPriority(&ctx->own_stream, hipStreamNonBlocking, greatest),
@@ -502,7 +508,7 @@ extern "C" {
 
 const char* avr_last_error(void) { return avr::g_last_error.c_str(); }
 
-int avr_abi_version(void) { return 1; }
+int avr_abi_version(void) { return AVR_ABI_VERSION; }
 
 int avr_debug_stall_stream(void* hip_stream, int milliseconds) {
   return guarded([&]() -> int {
@@ -539,15 +545,6 @@ int avr_context_create_with_priority(int device_id, int high_priority, avr_conte
   const int status = avr_context_create(device_id, out_ctx);
   if (status == AVR_OK) (*out_ctx)->priority = high_priority ? 1 : 0;
   return status;
-}
-
-int avr_context_set_cu_mask_pattern(avr_context* ctx, uint32_t pattern) {
-  return guarded([&]() -> int {
-    require(ctx != nullptr && ctx->own_stream == nullptr && ctx->stream == nullptr,
-            "the CU mask must be set before the context's stream exists");
-    ctx->cu_mask_pattern = pattern;
-    return AVR_OK;
-  });
 }
 
 void* avr_context_stream(avr_context* ctx) {

@@ -102,6 +102,34 @@ void nccl_ok(ncclResult_t result, const char* what) {
   }
 }
 
+// An open RCCL group is closed on every path out of its scope: an exception between
+// ncclGroupStart and ncclGroupEnd (a failed requirement of the gather riding in the round, a HIP
+// error) would otherwise leave the group open, and every later RCCL call of the process would
+// nest in it and never be launched.
+class RcclGroup {
+ public:
+  explicit RcclGroup(bool open = true) : open_(open) {
+    if (open_) nccl_ok(rccl().group_start(), "ncclGroupStart");
+  }
+  RcclGroup(const RcclGroup&) = delete;
+  RcclGroup& operator=(const RcclGroup&) = delete;
+  void end() {  // the normal path: errors of the launch itself are reported
+    if (!open_) return;
+    open_ = false;
+    nccl_ok(rccl().group_end(), "ncclGroupEnd");
+  }
+  ~RcclGroup() {
+    if (!open_) return;
+    try {
+      (void)rccl().group_end();  // unwinding: the first error is the one reported
+    } catch (...) {
+    }
+  }
+
+ private:
+  bool open_;
+};
+
 // ---- in-process rehearsal communicator -------------------------------------------------------
 struct LocalWorld {
   int n_ranks = 0;
@@ -292,6 +320,7 @@ namespace {
 
 template <typename F>
 int guarded(F&& body) {
+  const avr::CollectiveScope collective(true);  // a communicator's waits have the default deadline
   try {
     return body();
   } catch (const std::invalid_argument& e) {
@@ -520,9 +549,50 @@ int avr_comm_control_allgather(avr_comm* comm, avr_context* ctx, const void* min
     char* out = static_cast<char*>(all);
     ++comm->control_rounds;
     if (comm->control_fn != nullptr) {  // the caller's control plane
-      if (comm->control_fn(comm->control_user, mine, all, bytes) != 0) {
-        throw std::runtime_error("control plane: the caller's allgather failed");
+      // Under the same deadline as every other wait of a frame (AVR_FRAME_TIMEOUT_MS): plan
+      // agreement and the co-run windows block the host inside avr_renderer_render, and a peer that
+      // hangs would otherwise leave this rank in the caller's allgather for as long as THAT waits
+      // (gloo: 30 minutes by default).  The callback runs on a helper thread over buffers the
+      // helper co-owns; past the deadline the helper is left behind (it may still be inside the
+      // caller's collective: the renderer is failed and the process is expected to exit).
+      const int limit_ms = avr::frame_timeout_ms();
+      if (limit_ms <= 0) {
+        if (comm->control_fn(comm->control_user, mine, all, bytes) != 0) {
+          throw std::runtime_error("control plane: the caller's allgather failed");
+        }
+        return AVR_OK;
       }
+      struct Round {
+        std::mutex mutex;
+        std::condition_variable done_cv;
+        bool done = false;
+        int status = 0;
+        std::vector<unsigned char> mine, all;
+      };
+      auto round = std::make_shared<Round>();
+      round->mine.assign(static_cast<const unsigned char*>(mine), static_cast<const unsigned char*>(mine) + each);
+      round->all.resize(each * static_cast<size_t>(n));
+      const avr_control_allgather_fn fn = comm->control_fn;
+      void* const user = comm->control_user;
+      std::thread([round, fn, user, bytes] {
+        int status = -1;
+        try {
+          status = fn(user, round->mine.data(), round->all.data(), bytes);
+        } catch (...) {  // (a C callback must not throw; a C++ one that does is a failed round)
+        }
+        std::lock_guard<std::mutex> lock(round->mutex);
+        round->status = status;
+        round->done = true;
+        round->done_cv.notify_all();
+      }).detach();
+      std::unique_lock<std::mutex> lock(round->mutex);
+      if (!round->done_cv.wait_for(lock, std::chrono::milliseconds(limit_ms), [&] { return round->done; })) {
+        throw avr::DeadlineExceeded("control plane: the caller's allgather did not finish within " +
+                                    std::to_string(limit_ms) + " ms (AVR_FRAME_TIMEOUT_MS): a peer is "
+                                    "missing, or the ranks' calls differ");
+      }
+      if (round->status != 0) throw std::runtime_error("control plane: the caller's allgather failed");
+      std::memcpy(all, round->all.data(), round->all.size());
       return AVR_OK;
     }
     if (comm->solo) {  // alone: every peer "says" what this rank says
@@ -578,14 +648,14 @@ int avr_comm_control_allgather(avr_comm* comm, avr_context* ctx, const void* min
     std::memcpy(host, mine, each);
     if (avr::launch_upload(mapped, dev, each, stream) != AVR_OK) throw std::runtime_error(avr_last_error());
     const avr::Rccl& api = avr::rccl();
-    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    avr::RcclGroup group;
     for (int s = 0; s < n; ++s) {
       if (s == me && n > 1) continue;  // (a one-rank communicator talks to itself on purpose)
       avr::nccl_ok(api.send(dev, each, ncclChar, s, comm->nccl, stream), "ncclSend(control)");
       avr::nccl_ok(api.recv(dev + slot * static_cast<size_t>(s + 1), each, ncclChar, s, comm->nccl, stream),
                    "ncclRecv(control)");
     }
-    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    group.end();
     if (avr::launch_upload(dev + slot, mapped + slot, slot * static_cast<size_t>(n), stream) != AVR_OK) {
       throw std::runtime_error(avr_last_error());
     }
@@ -752,7 +822,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
             }
           }
         }
-        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        avr::RcclGroup group;
         for (int s = 0; s < n; ++s) {
           if (s == me) continue;
           if (comm->solo_percent == 0 && s != busiest) continue;
@@ -766,7 +836,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
                                 comm->nccl, stream), "ncclRecv");
         }
         if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/true);
-        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+        group.end();
       } else if (rider != nullptr) {
         run_gather(ctx, comm, *rider, /*in_group=*/false);
       }
@@ -871,13 +941,13 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
       // a one-rank communicator only exists to exercise this path where a single GPU is all
       // there is: the block for itself goes through ncclSend / ncclRecv like any other
       if ((own > 0 && move_own) || rider != nullptr) {
-        avr::nccl_ok(api.group_start(), "ncclGroupStart");
+        avr::RcclGroup group;
         if (own > 0 && move_own) {
           avr::nccl_ok(api.send(send, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclSend");
           avr::nccl_ok(api.recv(recv, static_cast<size_t>(own), ncclFloat, 0, comm->nccl, stream), "ncclRecv");
         }
         if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/true);
-        avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+        group.end();
       }
       return AVR_OK;
     }
@@ -886,7 +956,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
                                  static_cast<size_t>(own) * 4, hipMemcpyDeviceToDevice, stream),
                   "hipMemcpyAsync(exchange)");
     }
-    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    avr::RcclGroup group;
     for (int s = 0; s < n; ++s) {
       if (s == me) continue;
       const int64_t out = plan->send_splits[static_cast<size_t>(s)];
@@ -901,7 +971,7 @@ int exchange(avr_context* ctx, const avr_frame_plan* plan, avr_comm* comm, const
       }
     }
     if (rider != nullptr) run_gather(ctx, comm, *rider, /*in_group=*/true);
-    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    group.end();
     return AVR_OK;
   });
 }
@@ -1018,7 +1088,7 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
     }
     const avr::Rccl& api = avr::rccl();
     if (n > 1) keep_own();
-    avr::nccl_ok(api.group_start(), "ncclGroupStart");
+    avr::RcclGroup group;
     for (int k = 0; k < n; ++k) {
       const int peer = rank_at[static_cast<size_t>(k)];
       if (peer == me && n > 1) continue;  // (a one-rank communicator sends to itself on purpose)
@@ -1033,7 +1103,7 @@ int avr_exchange_pieces(avr_context* ctx, avr_comm* comm, const int32_t* group_o
                               comm->nccl, stream), "ncclRecv");
       }
     }
-    avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+    group.end();
     return AVR_OK;
   });
 }
@@ -1076,7 +1146,7 @@ void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool 
       // piece from every other rank, the others send theirs
       const avr::Rccl& api = avr::rccl();
       const size_t bytes = static_cast<size_t>(my_end - my_begin) * static_cast<size_t>(bytes_per_pixel);
-      if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
+      avr::RcclGroup group(!in_group);
       if (me != root) {
         // (no destination buffer off the root: the piece's first half lands on its second --
         // the piece has been handed over by then, and a solo rank's pixels mean nothing)
@@ -1101,7 +1171,7 @@ void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool 
                        "ncclRecv");
         }
       }
-      if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+      group.end();
     }
     return;
   }
@@ -1188,11 +1258,11 @@ void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool 
   if (n == 1) {  // as in avr_exchange: the one-rank case goes through RCCL on purpose
     if (my_end > my_begin) {
       const size_t bytes = static_cast<size_t>(my_end - my_begin) * bytes_per_pixel;
-      if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
+      avr::RcclGroup group(!in_group);
       avr::nccl_ok(api.send(piece, bytes, ncclChar, 0, comm->nccl, stream), "ncclSend");
       avr::nccl_ok(api.recv(dst + my_begin * bytes_per_pixel, bytes, ncclChar, 0, comm->nccl, stream),
                    "ncclRecv");
-      if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+      group.end();
     }
     return;
   }
@@ -1201,7 +1271,7 @@ void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool 
                                static_cast<size_t>(my_end - my_begin) * bytes_per_pixel,
                                hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync(gather)");
   }
-  if (!in_group) avr::nccl_ok(api.group_start(), "ncclGroupStart");
+  avr::RcclGroup group(!in_group);
   if (me == root) {
     for (int s = 0; s < n; ++s) {
       if (s == root) continue;
@@ -1215,7 +1285,7 @@ void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool 
     avr::nccl_ok(api.send(piece, static_cast<size_t>(my_end - my_begin) * bytes_per_pixel, ncclChar,
                           root, comm->nccl, stream), "ncclSend");
   }
-  if (!in_group) avr::nccl_ok(api.group_end(), "ncclGroupEnd");
+  group.end();
 }
 
 // the ranges of a plan's pieces in the gathered buffer: a rank's pixel range of the image

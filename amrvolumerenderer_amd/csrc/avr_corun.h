@@ -177,6 +177,11 @@ struct CoRunTuner {
   }
   // coordinated: some rank's window was void -- the same candidate is timed again, by all
   void retime() {
+    // (all ranks take this step in the same frame, so the shrinking below keeps them in lockstep:
+    // a caller who synchronises more often than a finalist's window is long voids every one of
+    // them on all ranks -- each void window halves what the finalists are given, down to the
+    // search's own windows, so that the search still ends, as the per-rank search does in drained())
+    if (phase == kVerify && shrink < 2) ++shrink;
     const int start = (phase == kHold) ? hold_frames() : settle_frames();
     open = closing = false;
     window_void = false;

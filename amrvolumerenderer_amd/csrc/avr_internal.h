@@ -375,6 +375,20 @@ void set_error(const std::string& message);
 // end in an error on this rank, not in a hang (DirectSendBase.cpp:206-220, 277 completes or errors).
 int frame_timeout_ms();
 void set_frame_timeout_ms(int ms);  // < 0: back to the environment's value
+// While one is alive on a thread, that thread's waits take the DEFAULT deadline (30 s) when nobody
+// set one: the calls of a renderer of several ranks and of a communicator.  A deadline that was
+// asked for (avr_set_frame_timeout_ms / AVR_FRAME_TIMEOUT_MS) holds everywhere; without either, a
+// single-rank context waits forever, as a plain HIP synchronise would.
+class CollectiveScope {
+ public:
+  explicit CollectiveScope(bool collective);
+  ~CollectiveScope();
+  CollectiveScope(const CollectiveScope&) = delete;
+  CollectiveScope& operator=(const CollectiveScope&) = delete;
+
+ private:
+  bool on_;
+};
 struct DeadlineExceeded : std::runtime_error {
   using std::runtime_error::runtime_error;
 };

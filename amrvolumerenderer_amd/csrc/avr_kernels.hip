@@ -485,9 +485,6 @@ render_runs_kernel(
     const MarchItemDev* __restrict__ items, float* __restrict__ out,
     unsigned long long* samples_out, unsigned long long* counters) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
-#if defined(AVR_TIMELINE)  // diagnostic build (tools/wg_timeline.py): per-workgroup start / end / CU
-  const unsigned long long avr_exp_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
   // Work item = one super-tile (2 x 2 workgroups in Morton order) of one run.  Workgroups are
@@ -522,7 +519,6 @@ render_runs_kernel(
 
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
   const int lane = static_cast<int>(threadIdx.x) & 63;
-#if !defined(AVR_WAVE_SHAPE) || AVR_WAVE_SHAPE == 0
   constexpr int kWaveW = 8, kWaveH = 8;
   const int wave_x0 = tile_x * kTile + (wave & 1) * 8;  // wave-uniform 8x8 sub-tile
   const int wave_y0 = tile_y * kTile + (wave >> 1) * 8;
@@ -531,21 +527,6 @@ render_runs_kernel(
   // bricklets (cache lines) per address-processing group
   const int px = wave_x0 + (lane & 3) + ((lane >> 2) & 4);
   const int py = wave_y0 + ((lane >> 2) & 3) + ((lane >> 3) & 4);
-#elif AVR_WAVE_SHAPE == 1
-  // experiment: a wave is a 16 x 4 strip (four 4 x 4 patches side by side)
-  constexpr int kWaveW = 16, kWaveH = 4;
-  const int wave_x0 = tile_x * kTile;
-  const int wave_y0 = tile_y * kTile + wave * 4;
-  const int px = wave_x0 + (lane & 3) + ((lane >> 4) << 2);
-  const int py = wave_y0 + ((lane >> 2) & 3);
-#else
-  // experiment: a wave is a 4 x 16 column (four 4 x 4 patches on top of each other)
-  constexpr int kWaveW = 4, kWaveH = 16;
-  const int wave_x0 = tile_x * kTile + wave * 4;
-  const int wave_y0 = tile_y * kTile;
-  const int px = wave_x0 + (lane & 3);
-  const int py = wave_y0 + ((lane >> 2) & 3) + ((lane >> 4) << 2);
-#endif
   const bool live = (px < fc.width) && (py < fc.height);
   const int64_t n_pixels = static_cast<int64_t>(fc.width) * fc.height;
   const int64_t p = static_cast<int64_t>(py) * fc.width + px;
@@ -657,18 +638,6 @@ render_runs_kernel(
     }
   }
 
-#if defined(AVR_TIMELINE)
-  if (counters != nullptr && threadIdx.x == 0) {
-    unsigned hw_id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    counters[4 * blockIdx.x + 0] = avr_exp_t0;
-    counters[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    counters[4 * blockIdx.x + 2] = (static_cast<unsigned long long>(xcc) << 32) | hw_id;
-    counters[4 * blockIdx.x + 3] = fetches;
-  }
-#endif
   if (STATS && samples_out != nullptr) {
     unsigned long long total = fetches;
     for (int offset = 32; offset > 0; offset >>= 1) {
@@ -729,13 +698,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
   __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
 
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
-#ifdef AVR_EXPERIMENT_CLASSIFY_REPEAT
-  // experiment build only (tools/upper_bound_persistent.py): ONE launch sweeps the frame's tiles
-  // several times over -- a classify pass that never ends between frames
-  const uint32_t tile = blockIdx.x % tile_begin[n_boxes];
-#else
   const uint32_t tile = blockIdx.x;
-#endif
   int lo = 0, hi = n_boxes;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -873,30 +836,11 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     // are still in the caches if they were stored plainly: a rank of eight 0.143 ms plain, 0.149
     // streamed (the march's L2 hit rate is 63.4 % either way, tools/share_cache_pmc.sh: what helps
     // sits below L2, in the memory-side cache, or is the write traffic itself).
-#ifdef AVR_EXPERIMENT_CLASSIFY_NO_STORES
-    // experiment build only (profiles/r4_contention/): the pass without its write stream (the
-    // condition never holds; it keeps the conversion alive)
-    if (v.x == 0xdeadbeefu && v.y == 0xfeedfaceu) *target = v;
-#elif defined(AVR_EXPERIMENT_CLASSIFY_CONTIGUOUS_STORES)
-    // experiment build only: the same bytes written as ONE contiguous 2 KiB block per workgroup
-    // (the wrong place: timing only) -- what a brick order whose x-neighbours are adjacent in
-    // memory would give the write stream
-    {
-      uint2* const packed_target = reinterpret_cast<uint2*>(
-          classified + static_cast<uint64_t>(blockIdx.x) * 2048u + static_cast<uint32_t>(t) * 8u);
-      if (stream_stores != 0) {
-        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(packed_target), "v"(v) : "memory");
-      } else {
-        *packed_target = v;
-      }
-    }
-#else
     if (stream_stores != 0) {  // (wave-uniform)
       asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(target), "v"(v) : "memory");
     } else {
       *target = v;
     }
-#endif
   }
 }
 
@@ -1362,16 +1306,6 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
                       fc.inverse_range == 1.0f;
   const size_t pad = L.classify_lds_pad;  // occupancy cap beside the march (avr_renderer)
-#ifdef AVR_EXPERIMENT_CLASSIFY_REPEAT
-  {
-    const char* text = std::getenv("AVR_CLASSIFY_REPEAT");
-    const unsigned repeat = text != nullptr ? static_cast<unsigned>(std::max(std::atoi(text), 1)) : 1u;
-    hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles * repeat), dim3(kBlockThreads), pad,
-                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
-                       L.classify_stream_stores);
-    return check_launch("classify_kernel");
-  }
-#endif
   if (simple) {
     hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,

@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/avr_hip_debug.h"
 #include "avr_corun.h"
 #include "avr_internal.h"
 #include "avr_plan.h"
@@ -343,6 +344,8 @@ int guarded_renderer(avr_renderer* r, F&& body) {
   return guarded([&]() -> int {
     if (r == nullptr) throw std::invalid_argument("null renderer");
     if (!r->failed.empty()) throw std::runtime_error(r->failed);
+    // (the default deadline belongs to frames with collectives in them: avr_internal.h)
+    const avr::CollectiveScope collective(r->n_ranks > 1 || r->comm != nullptr);
     try {
       return body();
     } catch (const avr::DeadlineExceeded& e) {
@@ -514,10 +517,6 @@ int avr_renderer_create(int device_id, int rank, int n_ranks, avr_comm* comm,
     abi_ok(avr_context_create_with_priority(device_id, 1, &r->march));
     abi_ok(avr_context_create_with_priority(device_id, 1, &r->compose));
     abi_ok(avr_context_create_with_priority(device_id, 0, &r->classify));
-    if (const char* pattern = std::getenv("AVR_CLASSIFY_CU_MASK")) {  // experiment: see DESIGN.md
-      abi_ok(avr_context_set_cu_mask_pattern(r->classify,
-                                             static_cast<uint32_t>(std::strtoul(pattern, nullptr, 0))));
-    }
     if (const char* bytes = std::getenv("AVR_CLASSIFY_LDS_RESERVE")) {  // experiment: fixed share
       r->share_fixed = std::clamp(std::atoi(bytes), 0, static_cast<int>(AVR_CLASSIFY_LDS_RESERVE_MAX));
     }
@@ -758,6 +757,16 @@ int avr_renderer_synchronize(avr_renderer* r) {
     }
     r->drain_all();
     r->stage = "idle";
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_outputs_complete(const avr_renderer* r, uint64_t* complete_out, uint64_t* frames_out) {
+  return guarded([&]() -> int {
+    require(r != nullptr && complete_out != nullptr, "null argument");
+    // (a pending gather is the last frame's: its bytes travel with the next round)
+    *complete_out = static_cast<uint64_t>(r->frame) - (r->pending.valid ? 1u : 0u);
+    if (frames_out != nullptr) *frames_out = r->frame;
     return AVR_OK;
   });
 }

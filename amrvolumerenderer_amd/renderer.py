@@ -321,8 +321,11 @@ class FrameRenderer:
         """One frame.  On rank 0 returns (image, rgb8): rgb8 = the output file's pixel bytes
         [H, W, 3] (rows top-down, SavePPM.cpp:25), image = the gathered (downsampled) depth-sort
         image [H, W, 5] if want_image (or antialiasing > 1), else None.  Other ranks get
-        (None, None).  The results are produced on comm_ctx.stream: call synchronize() (or order
-        your stream after it) before reading them."""
+        (None, None).  The results are produced on the compositing stream: call synchronize()
+        before reading them.  (Ordering a stream of your own after the compositing stream is
+        enough for one rank; for ranks of several the native driver delivers a frame's bytes with
+        the NEXT frame's round -- NativeRenderer.render / outputs_complete -- and synchronize() is
+        a collective that every rank calls after the same frame.)"""
         if self.native is not None:
             validate_render_parameters(p)
             out = self.native.render(p.width, p.height, p.box_transparency, p.antialiasing, camera,

@@ -784,6 +784,14 @@ class NativeRenderer:
         _capi.check(_capi.lib().avr_renderer_synchronize(self._handle))
         self._held_outputs = None
 
+    def outputs_complete(self):
+        """avr_renderer_outputs_complete: (frames whose outputs are written once stream X has
+        passed what is queued now, frames rendered so far)."""
+        done, frames = C.c_uint64(), C.c_uint64()
+        _capi.check(_capi.lib().avr_renderer_outputs_complete(self._handle, C.byref(done),
+                                                              C.byref(frames)))
+        return done.value, frames.value
+
     def set_overlap(self, overlap_classify: int) -> None:
         """avr_renderer_set_overlap (-1 default: measured, 0 back to back, 1 classify beside the
         march, 2 paired: frames alternate between two streams)."""
@@ -910,8 +918,13 @@ class NativeRenderer:
                group_order: Optional[Sequence[int]] = None,
                samples: Optional[torch.Tensor] = None, want_image: bool = False):
         """One frame (asynchronous).  Rank 0 returns (image [H, W, 5] or None, rgb8 [H, W, 3] with
-        rows top-down); other ranks (None, None).  The tensors are complete on stream X
-        (self.streams[2]): synchronize(), or order your stream after it."""
+        rows top-down); other ranks (None, None).  One rank: the tensors are complete on stream X
+        (self.streams[2]) -- synchronize(), or order your stream after it.  Ranks of several: the
+        RGB8 bytes of a frame without want_image travel to rank 0 inside the NEXT frame's round
+        (avr_renderer_set_deferred_gather, the default), so after ordering a stream behind stream X
+        only the frames outputs_complete() counts are written -- the last frame's tensor is still
+        uninitialised memory until the next render() has passed stream X or synchronize() (a
+        collective then: every rank calls it after the same frame) has returned."""
         # (a camera and parameters that repeat are converted once: per frame the Python layer costs
         # the host what matters beside a rank's 0.17 ms frame)
         key = (width, height, box_transparency, antialiasing, use_visibility_graph, draw_bounds,

@@ -340,7 +340,14 @@ def run(args, state):
         # sample-count and max-time reductions -- and runs over gloo, so that the one RCCL
         # communicator in the process is the C++ driver's own (a second one, torch's, would
         # share the GPU's queues with it for nothing).
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # Its collectives carry a timeout of their own (gloo's default is 30 minutes): a rank
+        # that hangs must end the job within minutes, also where the wait is a barrier or a
+        # reduction of this script and not the C++ driver's (whose control rounds run under
+        # AVR_FRAME_TIMEOUT_MS anyway, avr_comm_control_allgather).
+        import datetime
+        limit_ms = int(os.environ.get("AVR_FRAME_TIMEOUT_MS", "0") or 0) or 30000
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(milliseconds=max(4 * limit_ms, 120000)))
         group = dist.group.WORLD
 
     from amrvolumerenderer_amd import build as avr_build

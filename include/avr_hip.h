@@ -92,20 +92,26 @@ typedef struct {
 /* Message of the last failure on this thread ("" if none). */
 const char *avr_last_error(void);
 
-/* ABI version of this header (bumped on incompatible change). */
+/* ABI version of this header (bumped on incompatible change).
+ *   2 (round 5): for ranks of several the RGB8 bytes of a frame reach rank 0's rgb8_out one frame
+ *     late by default (avr_renderer_set_deferred_gather, avr_renderer_outputs_complete) and
+ *     avr_renderer_synchronize is collective while such a gather is pending; the test hooks and
+ *     diagnostics moved to avr_hip_debug.h; avr_context_set_cu_mask_pattern is gone.
+ *   1: rounds 1-4. */
+#define AVR_ABI_VERSION 2
 int avr_abi_version(void);
 
-/* Deadline, in milliseconds, of every host wait on device work inside this library (default: the
- * environment's AVR_FRAME_TIMEOUT_MS, else 30000; 0 = wait forever; < 0 = back to the default).
+/* Deadline, in milliseconds, of every host wait on device work inside this library (0 = wait
+ * forever; < 0 = back to the default).  Default: the environment's AVR_FRAME_TIMEOUT_MS; without
+ * it 30000 for the calls that involve other ranks (a renderer of several ranks or with a
+ * communicator, the avr_comm_* / avr_exchange* / avr_gather* calls) and NONE for single-rank
+ * contexts and renderers, which wait as long as a plain HIP synchronise would.
  * The frame of a rank of several contains collectives; the reference's exchange either completes
  * or errors (MPI_Waitany / MPI_Waitall, DirectSend/Base/DirectSendBase.cpp:206-220, 277).  Here a
  * wait that outlasts the deadline -- a peer that died, ranks whose calls differ -- makes the call
  * return AVR_ERR_RUNTIME with avr_last_error() naming what did not finish (stream, frame); the
  * renderer is then failed for good (every later call returns the error at once; destroy it). */
 int avr_set_frame_timeout_ms(int milliseconds);
-/* Test hook: keeps hip_stream busy for `milliseconds` (1..2000; one wave on a bounded timer -- it
- * always ends) so that the deadline above can be exercised on a real stream. */
-int avr_debug_stall_stream(void *hip_stream, int milliseconds);
 
 /* Creates a context bound to HIP device `device_id` with its own stream.  Replaces the
  * function-local static VolumePainter / DirectSendBase instances of
@@ -116,11 +122,6 @@ void avr_context_destroy(avr_context *ctx);
 /* The same with the context's own stream created in the device's most urgent priority class
  * (high_priority != 0) or in the default class. */
 int avr_context_create_with_priority(int device_id, int high_priority, avr_context **out_ctx);
-
-/* Restricts the context's OWN stream (before it is first used) to the compute units whose bit is
- * set in `pattern`, the 32-bit pattern being repeated over the device's CUs
- * (hipExtStreamCreateWithCUMask).  0 = no restriction. */
-int avr_context_set_cu_mask_pattern(avr_context *ctx, uint32_t pattern);
 
 /* The stream the context launches on (hipStream_t as void*), for ordering other work against it. */
 void *avr_context_stream(avr_context *ctx);
@@ -147,18 +148,6 @@ int avr_context_set_march_occupancy(avr_context *ctx, int workgroups_per_cu);
  * (avr_renderer_set_classify_share).  Never changes results. */
 #define AVR_CLASSIFY_LDS_RESERVE_MAX 61440
 int avr_context_set_classify_lds_reserve(avr_context *ctx, int bytes);
-
-/* Diagnostics for the parity tests: while set (device pointer to 5 x uint64; NULL = off), every
- * march launched with a samples_out counter also ADDS
- *   counters[0]  samples whose cell index took the exact IEEE divide of
- *                Common/VolumePainter.cpp:846-852 because the reciprocal product lay within the
- *                proven error bound of an integer ("Exact index without the divide"),
- *   counters[1..3]  samples of boxes indexed by the exact divide throughout (degenerate spacing) /
- *                by the reciprocal product / by the power-of-two product,
- *   counters[4]  non-empty pixels outside the row span of a tightened plan
- *                (avr_frame_plan_tighten): always 0.
- * Never changes results. */
-int avr_context_set_march_counters(avr_context *ctx, uint64_t *counters_dev);
 
 /* ---- host-side per-frame quantities (no device work) ------------------------------------- */
 
@@ -343,7 +332,7 @@ int avr_frame_plan_runs(const avr_frame_plan *plan, avr_run_info *runs);
  * while send_floats / recv_floats and the splits shrink (config-4: the rectangles are 48-72 %
  * filled).  Sizes still follow from the replicated metadata: EVERY rank must tighten the plan of
  * a frame or none.  all_boxes as given to avr_frame_plan_create.  The march counts, in the 5th
- * diagnostic counter (avr_context_set_march_counters), non-empty pixels it found outside a span:
+ * diagnostic counter (avr_context_set_march_counters, avr_hip_debug.h), non-empty pixels it found outside a span:
  * always 0.  avr_frame_plan_send_block / recv_block do not apply to a tightened plan. */
 int avr_frame_plan_tighten(avr_frame_plan *plan, const avr_box *all_boxes, int n_boxes);
 
@@ -501,7 +490,12 @@ int avr_comm_size(const avr_comm *comm);
  * bytes_per_rank bytes; bench.py: gloo): allgather(user, mine, all, bytes_per_rank) fills
  * all[rank * bytes_per_rank ...] for every rank and returns 0.  Without one, the RCCL flavour runs
  * a grouped round of tiny ncclSend / ncclRecv in band on the given context's stream (host-blocking,
- * with the deadline of avr_set_frame_timeout_ms); the rehearsal flavours meet in their own memory. */
+ * with the deadline of avr_set_frame_timeout_ms); the rehearsal flavours meet in their own memory.
+ * The caller's allgather runs under the same deadline: it is called on a helper thread over copies
+ * of the buffers, and a round that outlasts the deadline returns AVR_ERR_RUNTIME (the renderer
+ * that asked is failed for good) while the helper is left behind in the caller's collective -- so
+ * a caller's allgather should still carry a timeout of its own (MPI: a communicator error
+ * handler; gloo: the process group's timeout) to end that thread. */
 #define AVR_CONTROL_MAX_BYTES 2048
 typedef int (*avr_control_allgather_fn)(void *user, const void *mine, void *all, int bytes_per_rank);
 int avr_comm_set_control(avr_comm *comm, avr_control_allgather_fn allgather, void *user);
@@ -662,9 +656,6 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
  *   per window, three frames after the window's last); the held candidate is re-timed every
  *   half second.  0: every rank searches on its own (round 3).  A run that wants no search at all
  *   fixes layout and reserve: avr_renderer_set_overlap + avr_renderer_set_classify_share.
- * avr_renderer_set_corun_history / avr_renderer_corun_history: the candidate of each of the next
- *   `frames` frames (-1 back to back, k >= 0 side by side with reserve k * 2 KiB, 29 + k paired),
- *   for tests and the multi-rank rehearsal.
  * avr_renderer_failure: NULL, or what did not finish within the deadline of
  *   avr_set_frame_timeout_ms (stream, rank, frame, stage, co-run state); the renderer is then
  *   failed: every call returns AVR_ERR_RUNTIME with that message, avr_renderer_destroy releases
@@ -680,9 +671,6 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
 int avr_renderer_set_deferred_gather(avr_renderer *renderer, int mode);
 int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
 int avr_renderer_set_corun_coordination(avr_renderer *renderer, int mode);
-int avr_renderer_set_corun_history(avr_renderer *renderer, int frames);
-int avr_renderer_corun_history(const avr_renderer *renderer, int16_t *candidates_out, int capacity,
-                               int *frames_out);
 const char *avr_renderer_failure(const avr_renderer *renderer);
 /* One frame, asynchronously.  group_order: rank order of the compositing group, NULL = from the
  * visibility graph (VolumeRenderer.cpp:1235-1241).  input_stream: a HIP stream whose queued work
@@ -714,6 +702,14 @@ int avr_renderer_render(avr_renderer *renderer, const avr_render_params *render,
 int avr_renderer_prepare(avr_renderer *renderer, const avr_render_params *render,
                          const avr_camera *camera, const int32_t *group_order);
 int avr_renderer_synchronize(avr_renderer *renderer);
+/* How many of the frames rendered so far have their outputs (rgb8_out, image_out) written once the
+ * compositing stream (avr_renderer_stream(r, 2)) has passed everything queued up to now: all of
+ * them, or -- ranks of several with the deferred gather -- all but the last.  A caller that orders
+ * its own stream after the compositing stream reads frame `*complete_out - 1` and older; the last
+ * frame's bytes follow with the next frame's round or with avr_renderer_synchronize.  frames_out
+ * (may be NULL): frames rendered so far. */
+int avr_renderer_outputs_complete(const avr_renderer *renderer, uint64_t *complete_out,
+                                  uint64_t *frames_out);
 /* which: 0 classify, 1 march, 2 exchange / fold / gather / tail (hipStream_t as void*). */
 void *avr_renderer_stream(avr_renderer *renderer, int which);
 /* The plan of the last frame rendered (runs, piece, exchange volume). */

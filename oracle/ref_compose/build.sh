@@ -6,9 +6,9 @@
 # g++ directly, no CMake, no AMReX (none of these files includes it).  Needs from the image: MPICH
 # (/opt/conda: mpi.h, libmpi.so, mpiexec).  The ONE header the reference generates at configure time
 # (CMake/amrVolumeRendererConfig.h.in: a single @VAR@, the application's name in a string that none
-# of these files reads) is configured from the reference's own template into oracle/_ref/, as
-# configure_file() would -- whether that still counts as "the reference's own files" is stated as
-# an open point in DESIGN.md; if it does not, the vectors made with this binary pin nothing.
+# of these files reads) is produced from the reference's own template by CMake's configure_file()
+# (cmake -P configure_header.cmake: the same command the reference's build runs, without running
+# its build system) into oracle/_ref/include.
 # Exit 77: no reference tree / MPI here (the GPU box): skipped.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -18,7 +18,10 @@ MPI="${AVR_MPI_PREFIX:-/opt/conda}"
 [ -f "$REF/DirectSend/Base/DirectSendBase.cpp" ] && [ -f "$MPI/include/mpi.h" ] && [ -f "$MPI/lib/libmpi.so" ] \
   || { echo "skipped: no reference tree / MPICH here"; exit 77; }
 mkdir -p "$OUT/include" "$OUT/mpi"
-sed 's/@AMRVOLUMERENDERER_APP_NAME@/ref_compose/' "$REF/CMake/amrVolumeRendererConfig.h.in" > "$OUT/include/amrVolumeRendererConfig.h"
+# configure_file() itself, by the image's cmake in script mode, on the reference's own template
+cmake -DAMRVOLUMERENDERER_APP_NAME=ref_compose \
+      -DTEMPLATE="$REF/CMake/amrVolumeRendererConfig.h.in" -DOUTPUT="$OUT/include/amrVolumeRendererConfig.h" \
+      -P "$HERE/configure_header.cmake"
 # only MPI's own headers from the prefix (it holds unrelated packages' headers as well)
 ln -sf "$MPI"/include/mpi*.h "$OUT/mpi/"
 # (x86-64 baseline: no -march=native / -mfma / -ffast-math -- IEEE arithmetic without contraction;

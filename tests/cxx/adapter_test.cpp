@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/avr_reference_api.hpp"
+#include "../../include/avr_hip_debug.h"  // the search histories the coordinated-search check compares
 
 namespace standin {
 

@@ -19,13 +19,20 @@ LAB_MAP = [(0.0, 0.0, 0.0, 0.2, 0.0), (0.25, 0.1, 0.3, 0.9, 0.1), (0.5, 0.9, 0.9
 
 
 def test_library_exports_every_declared_symbol(avr_lib):
-    header = open(os.path.join(ROOT, "include", "avr_hip.h")).read()
-    declared = set(re.findall(r"\b(avr_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no declarations found"
+    # the drop-in boundary (avr_hip.h) and the test hooks / diagnostics kept apart from it
+    declared = set()
+    for name in ("avr_hip.h", "avr_hip_debug.h"):
+        header = open(os.path.join(ROOT, "include", name)).read()
+        found = set(re.findall(r"\b(avr_[a-z0-9_]+)\s*\(", header))
+        assert found, f"no declarations found in {name}"
+        declared |= found
+    product = set(re.findall(r"\b(avr_[a-z0-9_]+)\s*\(",
+                             open(os.path.join(ROOT, "include", "avr_hip.h")).read()))
+    assert not any("debug" in name or "history" in name or "counters" in name for name in product)
     assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
     for name in declared:
         assert hasattr(avr_lib, name), name
-    assert avr_lib.avr_abi_version() == 1
+    assert avr_lib.avr_abi_version() == 2
 
 
 def test_compute_entry_points_fail_without_device(avr_lib):
