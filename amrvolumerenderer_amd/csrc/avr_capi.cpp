@@ -301,6 +301,7 @@ struct avr_context {
   int march_workgroups_per_cu = 0;             // 0 = uncapped
   uint32_t classify_lds_pad = 0;               // avr_context_set_classify_lds_reserve
   bool classify_stream_stores = false;         // context_set_classify_stream_stores
+  bool fold_whole_grid = false;                // context_set_fold_whole_grid
   uint64_t* march_counters = nullptr;          // diagnostics (avr_context_set_march_counters)
 };
 
@@ -350,6 +351,39 @@ void bind_device(avr_context* ctx) {
 
 enum Phase { kClassify = 1, kMarch = 2 };
 
+// A frame cut into depth-ordered chunks of its global layer order (avr_classify_plan_chunked /
+// avr_march_plan_chunked): chunk k is classified by launch k of the classify call, which records
+// events[k] behind it, and marched by launch k of the march call, which waits for events[k] first.
+struct FrameChunks {
+  int count = 1;
+  hipEvent_t const* events = nullptr;  // count events, or null (both calls on one stream)
+  bool first_alone = false;            // classify: chunk 0 has the GPU to itself (no LDS reserve)
+};
+
+// Positions [bounds[k], bounds[k + 1]) of the global layer order for chunk k: equal shares of the
+// classify pass's work (tiles = cells), so that classifying chunk k + 1 takes about as long as
+// any other; a function of the plan alone -- the classify and the march call cut alike.
+std::vector<int> chunk_bounds(const avr::FramePlan& plan, const int32_t* box_order, int n_order,
+                              int n_chunks) {
+  std::vector<int> bounds(static_cast<size_t>(n_chunks) + 1, n_order);
+  bounds[0] = 0;
+  auto tiles_of = [&](int position) -> uint64_t {
+    const size_t b = static_cast<size_t>(box_order[position]);
+    return plan.classify_tile_begin[b + 1] - plan.classify_tile_begin[b];
+  };
+  uint64_t total = 0;
+  for (int i = 0; i < n_order; ++i) total += tiles_of(i);
+  uint64_t seen = 0;
+  int k = 1;
+  for (int i = 0; i < n_order && k < n_chunks; ++i) {
+    seen += tiles_of(i);
+    while (k < n_chunks && seen * static_cast<uint64_t>(n_chunks) >= total * static_cast<uint64_t>(k)) {
+      bounds[static_cast<size_t>(k++)] = i + 1;
+    }
+  }
+  return bounds;
+}
+
 // One frame's device work for a list of boxes: the classify pass and/or the march.
 // `classified` must hold plan.classified_bytes bytes; `cached` (optional) carries the host
 // prologue from the classify call of a frame to its march call.
@@ -361,8 +395,12 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const std::vector<avr::RunBlockDev>& run_blocks,
            const std::vector<avr::RunSpanDev>* run_spans, const avr::PieceMapDev& pieces,
            avr_scene* scene, int slot,
-           float* out_layers, uint64_t* samples_out, avr::FramePlan* cached) {
+           float* out_layers, uint64_t* samples_out, avr::FramePlan* cached,
+           const FrameChunks& chunks = FrameChunks{}) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
+  require(chunks.count >= 1 && chunks.count <= AVR_MAX_FRAME_CHUNKS, "invalid chunk count");
+  require(chunks.count == 1 || phases == kClassify || phases == kMarch,
+          "a chunked frame is classified and marched by separate calls");
   require(slot >= 0 && slot < AVR_CLASSIFIED_SLOTS, "classified slot out of range");
   avr::FramePlan local;
   avr::FramePlan& plan = cached ? *cached : local;
@@ -450,12 +488,44 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
              run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev) +
              (run_spans != nullptr ? run_spans->size() * sizeof(avr::RunSpanDev) : 0);
   }
+  // chunked: the positions of every chunk, and for the classify call the chunks' box lists (the
+  // local boxes in global layer order ARE the lists: chunk k is box_order[bounds[k] .. bounds[k+1]))
+  // with one prefix sum of classify workgroups per chunk
+  const bool chunked = chunks.count > 1;
+  std::vector<int> bounds;
+  std::vector<uint32_t> chunk_tile_begin;  // chunk k: entries bounds[k] + k .. bounds[k + 1] + k
+  if (chunked) {
+    require(n_order == 0 || box_order != nullptr, "null box_order");
+    for (int i = 0; i < n_order; ++i) {
+      require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
+    }
+    bounds = chunk_bounds(plan, box_order, n_order, chunks.count);
+    if (phases & kClassify) {
+      chunk_tile_begin.reserve(static_cast<size_t>(n_order + chunks.count));
+      for (int k = 0; k < chunks.count; ++k) {
+        uint32_t sum = 0;
+        chunk_tile_begin.push_back(0u);
+        for (int i = bounds[static_cast<size_t>(k)]; i < bounds[static_cast<size_t>(k) + 1]; ++i) {
+          const size_t b = static_cast<size_t>(box_order[i]);
+          sum += plan.classify_tile_begin[b + 1] - plan.classify_tile_begin[b];
+          chunk_tile_begin.push_back(sum);
+        }
+      }
+      bytes += chunk_tile_begin.size() * sizeof(uint32_t) + static_cast<size_t>(n_order) * 4;
+    }
+  }
   avr::StagingRing& staging = ctx->staging;
-  staging.begin(bytes, 9);
+  staging.begin(bytes, 11);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
+  const uint32_t* chunk_tile_begin_dev = nullptr;
+  const int32_t* chunk_box_list_dev = nullptr;
   if (phases & kClassify) {
     launch.tile_begin_dev =
         staging.add(plan.classify_tile_begin.data(), plan.classify_tile_begin.size());
+    if (chunked) {
+      chunk_tile_begin_dev = staging.add(chunk_tile_begin.data(), chunk_tile_begin.size());
+      chunk_box_list_dev = staging.add(box_order, static_cast<size_t>(n_order));
+    }
   }
   if (phases & kMarch) {
     launch.tables_dev = staging.add(plan.tables.data(), plan.tables.size());
@@ -483,6 +553,39 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     }
   }
   staging.commit(ctx->stream);
+  if (chunked) {
+    const uint32_t reserve = launch.classify_lds_pad;
+    for (int k = 0; k < chunks.count; ++k) {
+      const int first = bounds[static_cast<size_t>(k)], last = bounds[static_cast<size_t>(k) + 1];
+      if (phases & kClassify) {
+        if (last > first) {
+          launch.box_list_dev = chunk_box_list_dev + first;
+          launch.n_classify_boxes = last - first;
+          launch.tile_begin_dev = chunk_tile_begin_dev + first + k;
+          launch.n_classify_tiles = chunk_tile_begin[static_cast<size_t>(last + k)];
+          launch.classify_lds_pad = (k == 0 && chunks.first_alone) ? 0u : reserve;
+          const int status = avr::launch_classify(launch, ctx->stream);
+          if (status != AVR_OK) return status;
+        }
+        if (chunks.events != nullptr) {
+          avr::hip_check(hipEventRecord(chunks.events[k], ctx->stream), "hipEventRecord(chunk)");
+        }
+      } else {
+        if (chunks.events != nullptr) {
+          avr::hip_check(hipStreamWaitEvent(ctx->stream, chunks.events[k], 0), "hipStreamWaitEvent(chunk)");
+        }
+        // (the first launch stores every pixel of the runs' layers; the later ones resume them)
+        if (last > first || k == 0) {
+          launch.pos_begin = first;
+          launch.pos_end = last;
+          launch.resume = k > 0 ? 1 : 0;
+          const int status = avr::launch_march(launch, ctx->stream);
+          if (status != AVR_OK) return status;
+        }
+      }
+    }
+    return AVR_OK;
+  }
   if (phases & kClassify) {
     const int status = avr::launch_classify(launch, ctx->stream);
     if (status != AVR_OK) return status;
@@ -502,6 +605,7 @@ void context_set_classify_stream_stores(avr_context* ctx, bool stream) {
   ctx->classify_stream_stores = stream;
 }
 void context_set_lean_descriptors(avr_context* ctx, bool lean) { ctx->staging.set_lean(lean); }
+void context_set_fold_whole_grid(avr_context* ctx, bool whole) { ctx->fold_whole_grid = whole; }
 }  // namespace avr
 
 extern "C" {
@@ -937,10 +1041,12 @@ int avr_frame_plan_recv_block(const avr_frame_plan* plan, int global_run, int64_
 
 static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                       const avr_frame_plan* plan, int slot, float* send_buffer,
-                      uint64_t* samples_out) {
+                      uint64_t* samples_out, const FrameChunks& chunks = FrameChunks{}) {
   return guarded([&]() -> int {
     bind_device(ctx);
     require(scene != nullptr && plan != nullptr, "null argument");
+    require(chunks.count == 1 || !scene->cache_classification,
+            "a cached classification is not classified in chunks");
     require(static_cast<int>(scene->boxes.size()) == plan->info.n_local_boxes,
             "the scene does not hold this rank's boxes of the plan");
     if (plan->info.n_local_runs == 0) return AVR_OK;
@@ -951,7 +1057,7 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
                   ((phases & kMarch) && plan->tightened) ? &plan->send_spans : nullptr,
                   plan->pieces,
                   const_cast<avr_scene*>(scene), slot, send_buffer, samples_out,
-                  &const_cast<avr_frame_plan*>(plan)->prologue);
+                  &const_cast<avr_frame_plan*>(plan)->prologue, chunks);
   });
 }
 
@@ -985,6 +1091,24 @@ int avr_classify_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_
 int avr_march_plan(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan, int slot,
                    float* send_buffer, uint64_t* samples_out) {
   return plan_phase(ctx, kMarch, scene, plan, slot, send_buffer, samples_out);
+}
+
+int avr_classify_plan_chunked(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                              int slot, int n_chunks, void* const* chunk_events, int first_alone) {
+  FrameChunks chunks;
+  chunks.count = n_chunks;
+  chunks.events = reinterpret_cast<hipEvent_t const*>(chunk_events);
+  chunks.first_alone = first_alone != 0;
+  return plan_phase(ctx, kClassify, scene, plan, slot, nullptr, nullptr, chunks);
+}
+
+int avr_march_plan_chunked(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                           int slot, float* send_buffer, uint64_t* samples_out, int n_chunks,
+                           void* const* chunk_events) {
+  FrameChunks chunks;
+  chunks.count = n_chunks;
+  chunks.events = reinterpret_cast<hipEvent_t const*>(chunk_events);
+  return plan_phase(ctx, kMarch, scene, plan, slot, send_buffer, samples_out, chunks);
 }
 
 int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,
@@ -1044,7 +1168,9 @@ int fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_bu
     // waits for it: one workgroup per CU keeps it out of their way (0.997 -> 0.980 ms per frame).
     // A rank of several folds its piece on the stream that also carries the exchange and the
     // gather, five kernels per frame: there it should be through quickly.
-    launch.max_workgroups = plan->info.n_ranks == 1 ? 256 : 0;
+    // (A frame that found its renderer's pipeline empty has nothing to stay out of the way of,
+    // and somebody is waiting for it: the whole grid, 63 -> ~15 us for 2048^2.)
+    launch.max_workgroups = (plan->info.n_ranks == 1 && !ctx->fold_whole_grid) ? 256 : 0;
     {
       static const int forced = [] {  // A/B only (tools/ab_env_share.sh)
         const char* text = std::getenv("AVR_FOLD_WORKGROUPS");

@@ -260,6 +260,14 @@ struct RenderLaunch {
   uint32_t n_items;
   int only_mode;                        // the IndexMode shared by every box, or -1
   int workgroups_per_cu;                // resident march workgroups per CU (0 = uncapped)
+  // A frame in depth-ordered chunks (avr_classify_plan_chunked / avr_march_plan_chunked): the
+  // classify launch takes the n_classify_boxes boxes listed in box_list_dev (tile_begin_dev is
+  // then the chunk's prefix), the march launch the positions [pos_begin, pos_end) of the global
+  // layer order, its run accumulators resumed from what the launch before stored.
+  const int32_t* box_list_dev = nullptr;
+  int n_classify_boxes = 0;
+  int pos_begin = 0, pos_end = -1;      // pos_end < 0: n_order
+  int resume = 0;
 };
 // classify pass (cells -> table indices) and march; the march reads what the classify pass of
 // the same frame wrote into `classified`
@@ -401,6 +409,9 @@ void* context_stream(avr_context* ctx);
 // leaves no packet at all on the stream (by default its event is still recorded, which is what
 // keeps the host a few batches ahead of the GPU at most).
 void context_set_lean_descriptors(avr_context* ctx, bool lean);
+// One rank's fold normally takes one workgroup per CU (it runs beside the next frame's paint
+// kernels); `whole`: the next fold of this context takes the whole grid (nothing else is running).
+void context_set_fold_whole_grid(avr_context* ctx, bool whole);
 // Whether the context's classify passes stream their bricklets to memory (RenderLaunch).
 void context_set_classify_stream_stores(avr_context* ctx, bool stream);
 

@@ -483,7 +483,13 @@ render_runs_kernel(
     const int band_shift,  // >= 0: pieces are bands of 2^band_shift rows dealt round-robin
     const int tiles_x, const int tiles_y,
     const MarchItemDev* __restrict__ items, float* __restrict__ out,
-    unsigned long long* samples_out, unsigned long long* counters) {
+    unsigned long long* samples_out, unsigned long long* counters,
+    // A frame marched in several launches (depth-ordered chunks of the global layer order, so that
+    // a chunk is marched while the next one is still being classified): this launch takes the
+    // positions [pos_begin, pos_end) of `order`; resume != 0: the run accumulator starts from what
+    // the launch before stored (the left fold of DirectSendBase.cpp:413-426 is cut, not re-associated:
+    // the same blends in the same order on the same five floats).
+    const int pos_begin, const int pos_end, const int resume) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
@@ -541,9 +547,48 @@ render_runs_kernel(
   // divide because the reciprocal product sat near an integer, and samples per index mode
   unsigned near_hits = 0, mode_fetches[3] = {0u, 0u, 0u};
   {
-    const int end = run_end[run];
+    // Where this pixel of the run's layer is stored: only inside the run's screen rectangle, in
+    // the block of the DirectSend piece the pixel belongs to (nullptr: nowhere).
+    auto layer_pixel = [&]() -> float* {
+      if (!(live && px >= rect.x0 && px <= rect.x1 && py >= rect.y0 && py <= rect.y1)) return nullptr;
+      int64_t piece;
+      int row = py;  // the pixel's row in its piece's numbering (contiguous pieces: the image row)
+      if (band_shift >= 0) {  // kPiecesRowBands
+        const unsigned band = static_cast<unsigned>(py) >> band_shift;
+        const unsigned cycle = band / static_cast<unsigned>(n_pieces);
+        piece = band - cycle * static_cast<unsigned>(n_pieces);
+        row = static_cast<int>((cycle << band_shift) + (static_cast<unsigned>(py) & ((1u << band_shift) - 1u)));
+      } else {
+        const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
+        piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
+        if (piece > n_pieces - 1) piece = n_pieces - 1;
+      }
+      const RunBlockDev block = run_blocks[static_cast<int64_t>(run) * n_pieces + piece];
+      if (block.span_base >= 0) {
+        // tightened plan: the row stores only the run's conservative extent on screen; a pixel
+        // outside it is empty by construction (counted, should the construction ever be wrong)
+        const RunSpanDev span = run_spans[block.span_base + (row - block.first_row)];
+        if (px < static_cast<int>(span.x0) || px > static_cast<int>(span.x1)) return nullptr;
+        return out + block.offset + span.rel + static_cast<int64_t>(px - static_cast<int>(span.x0)) * 5;
+      }
+      return out + block.offset +
+             (static_cast<int64_t>(row - block.first_row) * (rect.x1 - rect.x0 + 1) + (px - rect.x0)) * 5;
+    };
+    const int run_begin = (run > 0) ? run_end[run - 1] : 0;
+    const int end = (run_end[run] < pos_end) ? run_end[run] : pos_end;
     Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};  // cleared layer pixel: exact blend identity
-    for (int position = (run > 0) ? run_end[run - 1] : 0; position < end; ++position) {
+    bool touched = resume == 0;  // a resumed pixel no box of this launch reaches is not stored again
+    if (resume != 0) {
+      const float* src = layer_pixel();
+      if (src != nullptr) {
+        acc.r = src[0];
+        acc.g = src[1];
+        acc.b = src[2];
+        acc.a = src[3];
+        acc.d = src[4];
+      }
+    }
+    for (int position = (run_begin > pos_begin) ? run_begin : pos_begin; position < end; ++position) {
       const BoxDev& box = boxes[order[position]];
       // wave-uniform cull against the box's conservative screen rectangle
       if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + (kWaveW - 1) || box.rect[3] < wave_y0 ||
@@ -594,39 +639,14 @@ render_runs_kernel(
         }
         if (STATS) mode_fetches[mode] += fetches - before;
         acc = blend_depthsort(acc, layer);
+        touched = true;
       }
     }
-    // The run's layer is stored only inside the run's screen rectangle, in the block of the
-    // DirectSend piece the pixel belongs to.
-    if (live && px >= rect.x0 && px <= rect.x1 && py >= rect.y0 && py <= rect.y1) {
-      int64_t piece;
-      int row = py;  // the pixel's row in its piece's numbering (contiguous pieces: the image row)
-      if (band_shift >= 0) {  // kPiecesRowBands
-        const unsigned band = static_cast<unsigned>(py) >> band_shift;
-        const unsigned cycle = band / static_cast<unsigned>(n_pieces);
-        piece = band - cycle * static_cast<unsigned>(n_pieces);
-        row = static_cast<int>((cycle << band_shift) + (static_cast<unsigned>(py) & ((1u << band_shift) - 1u)));
-      } else {
-        const int64_t piece_size = n_pixels / n_pieces;  // getPieceRange, DirectSendBase.cpp:59-74
-        piece = (piece_size > 0) ? (p / piece_size) : (n_pieces - 1);
-        if (piece > n_pieces - 1) piece = n_pieces - 1;
-      }
-      const RunBlockDev block = run_blocks[static_cast<int64_t>(run) * n_pieces + piece];
-      float* dst;
-      if (block.span_base >= 0) {
-        // tightened plan: the row stores only the run's conservative extent on screen; a pixel
-        // outside it is empty by construction (counted, should the construction ever be wrong)
-        const RunSpanDev span = run_spans[block.span_base + (row - block.first_row)];
-        if (px < static_cast<int>(span.x0) || px > static_cast<int>(span.x1)) {
-          if (STATS && counters != nullptr && acc.a != 0.0f) atomicAdd(counters + 4, 1ull);
-          dst = nullptr;
-        } else {
-          dst = out + block.offset + span.rel + static_cast<int64_t>(px - static_cast<int>(span.x0)) * 5;
-        }
-      } else {
-        dst = out + block.offset +
-              (static_cast<int64_t>(row - block.first_row) * (rect.x1 - rect.x0 + 1) +
-               (px - rect.x0)) * 5;
+    if (touched) {
+      float* const dst = layer_pixel();
+      if (STATS && counters != nullptr && dst == nullptr && acc.a != 0.0f && live && px >= rect.x0 &&
+          px <= rect.x1 && py >= rect.y0 && py <= rect.y1) {
+        atomicAdd(counters + 4, 1ull);  // a non-empty pixel outside its row's span: never
       }
       if (dst != nullptr) {
         dst[0] = acc.r;
@@ -694,7 +714,10 @@ template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
-    const int stream_stores) {
+    const int stream_stores,
+    // non-null: this launch classifies the boxes box_list[0 .. n_boxes) (one depth-ordered chunk of
+    // the frame; tile_begin is the chunk's prefix sum); null: boxes[0 .. n_boxes)
+    const int32_t* __restrict__ box_list) {
   __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
 
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
@@ -708,7 +731,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
       hi = mid;
     }
   }
-  const BoxDev& box = boxes[lo];
+  const BoxDev& box = boxes[box_list != nullptr ? box_list[lo] : lo];
   const int nx = box.nx, ny = box.ny, nz = box.nz;
   const int bricks_x = (nx + kBrickX - 1) >> 3;
   const int bricks_y = (ny + kBrickY - 1) >> 2;
@@ -1306,14 +1329,16 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   const bool simple = !fc.log_scale && fc.normalize && !fc.apply_clip && fc.range_min == 0.0f &&
                       fc.inverse_range == 1.0f;
   const size_t pad = L.classify_lds_pad;  // occupancy cap beside the march (avr_renderer)
+  // (a chunk of the frame: n_classify_boxes entries of box_list_dev under the chunk's own prefix)
+  const int n_listed = L.box_list_dev != nullptr ? L.n_classify_boxes : L.n_boxes;
   if (simple) {
     hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
-                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
-                       L.classify_stream_stores);
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
+                       L.classify_stream_stores, L.box_list_dev);
   } else {
     hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
-                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, L.n_boxes, L.classified,
-                       L.classify_stream_stores);
+                       stream, L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
+                       L.classify_stream_stores, L.box_list_dev);
   }
   return check_launch("classify_kernel");
 }
@@ -1348,7 +1373,8 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
                      L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, band_shift, tiles_x,    \
                      tiles_y,                                                                    \
                      L.items_dev,                                                                \
-                     L.out_layers, L.samples_out, L.counters)
+                     L.out_layers, L.samples_out, L.counters, L.pos_begin,                       \
+                     (L.pos_end < 0 ? L.n_order : L.pos_end), L.resume)
   if (L.only_mode == kPow2Multiply) {
     if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
   } else if (L.only_mode == kReciprocal) {

@@ -209,6 +209,18 @@ struct avr_renderer {
   hipEvent_t marched_event[AVR_CLASSIFIED_SLOTS] = {};     // march finished reading the volume
   hipEvent_t composed_event[AVR_CLASSIFIED_SLOTS] = {};    // stream X finished reading send[slot]
   hipEvent_t input_event = nullptr;
+  // A frame may be classified and marched in depth-ordered chunks, chunk k marched while chunk
+  // k + 1 is classified (avr_classify_plan_chunked) -- built for the frame that finds the pipeline
+  // empty (every frame of a caller who waits for each: the reference's Render() returns after ONE
+  // frame), whose classify pass and march otherwise run strictly one after the other.  Measured
+  // (profiles/r5_latency/): it does not pay on this GPU -- config-4's single frame 1.48 ms in one
+  // launch each, 1.50-1.55 in 2-4 chunks at any LDS reserve, 1.7-1.8 in 6-8: the two kernels
+  // stretch each other while they overlap (the first march launch takes as long as the three
+  // classify launches beside it) and a march in K launches costs 20 % more than in one.  So:
+  // frame_chunks -1 / 1 = one launch per kernel (default), k > 1 = every frame in k chunks.
+  int frame_chunks = -1;
+  hipEvent_t chunk_event[AVR_CLASSIFIED_SLOTS][AVR_MAX_FRAME_CHUNKS] = {};
+  int last_chunks = 1;  // what the last frame did (avr_renderer_corun_state / diagnostics)
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
   unsigned frame = 0;
 
@@ -258,6 +270,11 @@ struct avr_renderer {
     }
     for (hipEvent_t ev : composed_event) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
+    for (auto& events : chunk_event) {
+      for (hipEvent_t ev : events) {
+        if (ev != nullptr) (void)hipEventDestroy(ev);
+      }
     }
     if (input_event != nullptr) (void)hipEventDestroy(input_event);
     if (epoch != nullptr) (void)hipEventDestroy(epoch);
@@ -647,6 +664,17 @@ int avr_renderer_set_overlap(avr_renderer* r, int overlap_classify) {
     return AVR_OK;
   });
 }
+
+int avr_renderer_set_frame_chunks(avr_renderer* r, int chunks) {
+  return guarded_renderer(r, [&]() -> int {
+    require(chunks == -1 || (chunks >= 1 && chunks <= AVR_MAX_FRAME_CHUNKS),
+            "chunks must be -1 or in [1, AVR_MAX_FRAME_CHUNKS]");
+    r->frame_chunks = chunks;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_last_frame_chunks(const avr_renderer* r) { return r != nullptr ? r->last_chunks : -1; }
 
 int avr_renderer_set_deferred_gather(avr_renderer* r, int mode) {
   return guarded_renderer(r, [&]() -> int {
@@ -1118,15 +1146,34 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     ++r->frame;
 
-    // (the first frame after a drain classifies alone: no march to leave room for)
-    abi_ok(avr_context_set_classify_lds_reserve(classify_ctx,
-                                                (overlap && !r->pipeline_idle) ? reserve : 0));
+    // ---- one launch per kernel, or depth-ordered chunks (an idle pipeline: see frame_chunks) ----
+    // Chunks need the two kernels on two streams (side by side); a cached classification has no
+    // classify pass to cut.
+    const bool was_idle = r->pipeline_idle;
+    int n_chunks = 1;
+    if (overlap && !paired && !r->cache_classification && info.n_local_runs > 0) {
+      n_chunks = std::min(std::max(r->frame_chunks, 1), std::max(info.n_local_boxes, 1));
+    }
+    r->last_chunks = n_chunks;
+    void* chunk_events[AVR_MAX_FRAME_CHUNKS] = {};
+    for (int k = 0; k < n_chunks && n_chunks > 1; ++k) {
+      hipEvent_t& event = r->chunk_event[volume][k];
+      if (event == nullptr) event = make_event(false);
+      chunk_events[k] = event;
+    }
+    // (the first frame after a drain classifies alone -- its first chunk, if it is cut: no march
+    // to leave room for)
+    abi_ok(avr_context_set_classify_lds_reserve(
+        classify_ctx, (overlap && (!was_idle || n_chunks > 1)) ? reserve : 0));
     // Side by side the march that reads this frame's bricklets starts a frame later: they are
     // streamed to memory.  Back to back and paired it follows at once: they are stored plainly
     // (a rank of eight 0.143 against 0.149 ms).
     {
       static const char* forced = std::getenv("AVR_CLASSIFY_STREAM");  // A/B only
-      const bool stream = forced != nullptr ? std::atoi(forced) != 0 : (overlap && !paired);
+      // (a chunk's bricklets are marched right away, and so are those of a frame that found the
+      // pipeline empty: stored plainly, like back to back)
+      const bool stream = forced != nullptr ? std::atoi(forced) != 0
+                                            : (overlap && !paired && n_chunks == 1 && !was_idle);
       avr::context_set_classify_stream_stores(classify_ctx, stream);
     }
     r->last_overlap = overlap;
@@ -1163,7 +1210,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
-    abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
+    if (n_chunks > 1) {
+      abi_ok(avr_classify_plan_chunked(classify_ctx, r->scene, plan, volume, n_chunks, chunk_events,
+                                       was_idle ? 1 : 0));
+    } else {
+      abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
+    }
     hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[volume];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
     // (what the NEXT frame waits on must outlive this frame's timing events, which
@@ -1176,11 +1228,18 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(1);
     r->stage = "march";
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
-    if (overlap && !paired) {  // (paired: the march follows its classify pass on the same stream)
+    if (overlap && !paired && n_chunks == 1) {
+      // (paired: the march follows its classify pass on the same stream; chunked: every march
+      // launch waits for its own chunk's event)
       hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
-    abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
+    if (n_chunks > 1) {
+      abi_ok(avr_march_plan_chunked(march_ctx, r->scene, plan, volume, send, samples_out, n_chunks,
+                                    chunk_events));
+    } else {
+      abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
+    }
     // the tuner's window: the period of a few frames between two events after the march
     if (tuner.tuning()) {
       if (tuner.closing) {
@@ -1262,6 +1321,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     r->stage = "fold";
     // (one rank without antialiasing or wireframe: the fold writes the output file's rows itself)
     const bool fold_to_image = !many && early_rgb8 && !overlay_piece && is_root;
+    avr::context_set_fold_whole_grid(r->compose, was_idle);
     if (fold_to_image) {
       abi_ok(avr_fold_plan_image(r->compose, plan, received, piece, rgb8_out));
     } else {

@@ -487,6 +487,35 @@ class Scene:
             C.c_void_p(samples.data_ptr()) if samples is not None else None))
         return out
 
+    def classify_plan_chunked(self, ctx: "Context", plan, slot: int, n_chunks: int,
+                              events=None, first_alone: bool = False) -> None:
+        """avr_classify_plan_chunked: the frame's boxes in n_chunks depth-ordered chunks, one
+        classify launch each; events (torch.cuda.Event list or None) are recorded behind them."""
+        handles = None
+        if events is not None:
+            handles = (C.c_void_p * n_chunks)(*[C.c_void_p(e.cuda_event) for e in events])
+        _capi.check(_capi.lib().avr_classify_plan_chunked(
+            ctx._handle, self._handle, plan._handle, int(slot), int(n_chunks), handles,
+            int(bool(first_alone))))
+
+    def march_plan_chunked(self, ctx: "Context", plan, slot: int, out: torch.Tensor, n_chunks: int,
+                           samples: Optional[torch.Tensor] = None, events=None) -> torch.Tensor:
+        """avr_march_plan_chunked: one march launch per chunk, each resuming the run accumulators
+        the launch before stored (waits for events[k] before launch k when given)."""
+        ctx._check_tensor(out, torch.float32, "out")
+        if out.numel() < plan.send_floats:
+            raise ValueError("send buffer is too small")
+        if samples is not None:
+            ctx._check_tensor(samples, torch.int64, "samples")
+        handles = None
+        if events is not None:
+            handles = (C.c_void_p * n_chunks)(*[C.c_void_p(e.cuda_event) for e in events])
+        _capi.check(_capi.lib().avr_march_plan_chunked(
+            ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(out.data_ptr()),
+            C.c_void_p(samples.data_ptr()) if samples is not None else None, int(n_chunks),
+            handles))
+        return out
+
     def render_plan(self, plan, out: Optional[torch.Tensor] = None,
                     samples: Optional[torch.Tensor] = None,
                     sync_streams: bool = True) -> torch.Tensor:
@@ -783,6 +812,15 @@ class NativeRenderer:
         the same frame)."""
         _capi.check(_capi.lib().avr_renderer_synchronize(self._handle))
         self._held_outputs = None
+
+    def set_frame_chunks(self, chunks: int = -1) -> None:
+        """avr_renderer_set_frame_chunks: -1 / 1 one launch per kernel (default), k > 1 every
+        frame classified and marched in k depth-ordered chunks (measured not to pay:
+        profiles/r5_latency/)."""
+        _capi.check(_capi.lib().avr_renderer_set_frame_chunks(self._handle, int(chunks)))
+
+    def last_frame_chunks(self) -> int:
+        return int(_capi.lib().avr_renderer_last_frame_chunks(self._handle))
 
     def outputs_complete(self):
         """avr_renderer_outputs_complete: (frames whose outputs are written once stream X has

@@ -362,6 +362,25 @@ int avr_classify_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_
 int avr_march_plan(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan, int slot,
                    float *send_buffer, uint64_t *samples_out);
 
+/* ONE frame in n_chunks (2 .. AVR_MAX_FRAME_CHUNKS) depth-ordered chunks, for the caller who waits
+ * for every frame (the reference's Render() returns after one: VolumeRenderer.cpp:1103-1339): the
+ * rank's boxes are cut, in global layer order, into chunks of equal classify work; chunk k is
+ * classified by launch k of avr_classify_plan_chunked (which then records chunk_events[k],
+ * hipEvent_t as void*, on its stream) and marched by launch k of avr_march_plan_chunked (which
+ * first makes its stream wait for chunk_events[k]) -- so chunk k is marched while chunk k + 1 is
+ * still being classified and the frame's latency is one chunk's classify pass plus the march, not
+ * the whole pass plus the march.  The run accumulators are carried from launch to launch through
+ * the send buffer: the run's left fold (DirectSendBase.cpp:413-426) is cut, never re-associated,
+ * so the results equal avr_march_plan's bit for bit.  chunk_events may be NULL when both calls go
+ * to one stream.  first_alone != 0: nothing else runs beside chunk 0's classify launch, so it
+ * takes no LDS reserve (avr_context_set_classify_lds_reserve).  Not with a cached classification. */
+#define AVR_MAX_FRAME_CHUNKS 16
+int avr_classify_plan_chunked(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                              int slot, int n_chunks, void *const *chunk_events, int first_alone);
+int avr_march_plan_chunked(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                           int slot, float *send_buffer, uint64_t *samples_out, int n_chunks,
+                           void *const *chunk_events);
+
 /* Receiver side of composeLayered (DirectSendBase.cpp:400-446) for this rank's piece: folds
  * the runs in global order from the received buffer (recv_floats floats; with one rank the send
  * buffer itself) into out_piece[(piece_end - piece_begin) * 5]; pixels no run covers become the
@@ -669,6 +688,15 @@ int avr_renderer_reference_sample_distance(const avr_renderer *renderer, float *
  *   the caller's rgb8_out buffer must stay valid until then.  Frames with want_image or
  *   antialiasing gather at once as before.  0: every frame gathers at once. */
 int avr_renderer_set_deferred_gather(avr_renderer *renderer, int mode);
+/* How a frame's two paint kernels are launched.  -1 / 1 (default): one launch each.  k in
+ * [2, AVR_MAX_FRAME_CHUNKS]: every frame in k depth-ordered chunks, chunk i marched while chunk
+ * i + 1 is classified (avr_classify_plan_chunked; only where the two kernels run on two streams,
+ * never with a cached classification).  Built to shorten the frame of a caller who waits for every
+ * frame -- the reference's call shape, one Render() per frame
+ * (VolumeRenderer/VolumeRenderer.cpp:1103-1339) -- and measured not to on this GPU
+ * (profiles/r5_latency/), hence off by default.  Scheduling only: never changes results. */
+int avr_renderer_set_frame_chunks(avr_renderer *renderer, int chunks);
+int avr_renderer_last_frame_chunks(const avr_renderer *renderer); /* what the last frame took */
 int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
 int avr_renderer_set_corun_coordination(avr_renderer *renderer, int mode);
 const char *avr_renderer_failure(const avr_renderer *renderer);
