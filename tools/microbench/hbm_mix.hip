@@ -1,5 +1,5 @@
 // What random line-sized reads cost a saturating HBM stream beside them, by the size of the
-// contiguous piece each read fetches (profiles/r5_prefetch_wave/README.md, section 3).
+// contiguous piece each read fetches (profiles/r5_corun_gap/README.md, section 3).
 //   S: streams 2.95 GB of f64 once (16 B per lane, non-temporal) and writes 1/8 of that as a stream
 //      -- the classify pass's traffic
 //   R: reads `total` bytes of a 1 GB buffer in contiguous pieces of `piece` bytes at pseudo-random
@@ -45,7 +45,9 @@ __device__ __forceinline__ unsigned hash(unsigned x) {
 // one wave fetches `piece` contiguous bytes per trip: piece / 64 bytes per lane
 template <int LANE_BYTES>
 __global__ __launch_bounds__(256) void random_kernel(const unsigned char* __restrict__ buffer, size_t bytes,
-                                                     int trips, int spin, unsigned seed, float* sink) {
+                                                     int trips, int spin, unsigned seed, float* sink,
+                                                     unsigned long long* clocks) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const unsigned lane = threadIdx.x & 63;
   constexpr size_t kPiece = static_cast<size_t>(LANE_BYTES) * 64;
@@ -61,6 +63,10 @@ __global__ __launch_bounds__(256) void random_kernel(const unsigned char* __rest
     for (int s = 0; s < spin; ++s) acc = acc * 1.0000001f + 0.5f;
   }
   if (acc == 12345.678f) *sink = acc;
+  if (lane == 0 && (wave & 63u) == 0) {  // shader clock cycles and 100 MHz ticks this wave lived
+    atomicAdd(clocks, clock64() - c0);
+    atomicAdd(clocks + 1, wall_clock64() - w0);
+  }
 }
 
 int main(int argc, char** argv) {
@@ -73,6 +79,7 @@ int main(int argc, char** argv) {
   d2_t* in; u2_t* out; unsigned char* buffer; float* sink;
   CK(hipMalloc(&in, stream_bytes)); CK(hipMalloc(&out, stream_bytes / 8 + 4096)); CK(hipMalloc(&buffer, random_bytes));
   CK(hipMalloc(&sink, 4));
+  unsigned long long* clocks; CK(hipMalloc(&clocks, 16));
   CK(hipMemset(in, 0, stream_bytes)); CK(hipMemset(buffer, 1, random_bytes));
   hipStream_t a, b; CK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
   int least, greatest; CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -87,10 +94,10 @@ int main(int argc, char** argv) {
     const dim3 grid(waves / 4), block(256);
     ++seed;
     switch (lane_bytes) {
-      case 2: hipLaunchKernelGGL(random_kernel<2>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink); break;
-      case 4: hipLaunchKernelGGL(random_kernel<4>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink); break;
-      case 8: hipLaunchKernelGGL(random_kernel<8>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink); break;
-      default: hipLaunchKernelGGL(random_kernel<16>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink); break;
+      case 2: hipLaunchKernelGGL(random_kernel<2>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink, clocks); break;
+      case 4: hipLaunchKernelGGL(random_kernel<4>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink, clocks); break;
+      case 8: hipLaunchKernelGGL(random_kernel<8>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink, clocks); break;
+      default: hipLaunchKernelGGL(random_kernel<16>, grid, block, 0, s, buffer, random_bytes, trips, spin, seed, sink, clocks); break;
     }
   };
   auto timed = [&](bool with_s, int lane_bytes, float* ms_s, float* ms_r) {
@@ -114,9 +121,17 @@ int main(int argc, char** argv) {
   std::printf("R fetches %.0f MB per launch out of %zu MB, %d waves, %d multiply-adds between pieces; S alone %.3f ms (%.2f TB/s read)\n",
               total_mb, random_bytes >> 20, waves, spin, s_alone, stream_bytes / s_alone / 1e9);
   for (int lane_bytes : {2, 4, 8, 16}) {
+    unsigned long long host[2];
+    CK(hipMemset(clocks, 0, 16));
     timed(false, lane_bytes, &unused, &r_alone);
+    CK(hipMemcpy(host, clocks, 16, hipMemcpyDeviceToHost));
+    const double mhz_alone = host[1] ? 100.0 * static_cast<double>(host[0]) / static_cast<double>(host[1]) : 0.0;
+    CK(hipMemset(clocks, 0, 16));
     timed(true, lane_bytes, &s_both, &r_both);
-    std::printf("piece %5d B: R alone %.3f ms; side by side S %.3f ms, R %.3f ms\n", lane_bytes * 64, r_alone, s_both, r_both);
+    CK(hipMemcpy(host, clocks, 16, hipMemcpyDeviceToHost));
+    const double mhz_both = host[1] ? 100.0 * static_cast<double>(host[0]) / static_cast<double>(host[1]) : 0.0;
+    std::printf("piece %5d B: R alone %.3f ms (shader clock %.0f MHz); side by side S %.3f ms, R %.3f ms (%.0f MHz)\n",
+                lane_bytes * 64, r_alone, mhz_alone, s_both, r_both, mhz_both);
   }
   return 0;
 }
