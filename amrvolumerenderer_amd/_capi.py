@@ -235,6 +235,7 @@ SIGNATURES = {
     "avr_renderer_prepare": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip]),
     "avr_renderer_synchronize": (C.c_int, [_vp]),
     "avr_renderer_set_frame_chunks": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_corun_balance": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_last_frame_chunks": (C.c_int, [_vp]),
     "avr_renderer_outputs_complete": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "avr_renderer_stream": (_vp, [_vp, C.c_int]),

@@ -51,7 +51,17 @@ struct CoRunTuner {
   // winner.  (No early exit: over the reserve the period is flat, dips and rises again, and for
   // the short kernels of an N-rank share the dip lies at the far end -- a search that stopped
   // on the flat stretch missed it.)
-  enum Phase { kSearch, kRefine, kVerify, kHold } phase = kSearch;
+  // kBalance (round 5, one rank's side-by-side frames): not a search at all.  Side by side the two
+  // kernels trade one resource linearly (profiles/r5_corun_gap/: c + m = 1.34 in solo-speed units on
+  // every reserve), so the frame is shortest where they take equally long, and which of them is the
+  // longer one is read off any single frame -- each kernel's own duration, timed by two events on its
+  // stream, responds to a new reserve at once, where the PERIOD only shows it after the classify
+  // stream's lead of two frames has run out (what the finalists' 40 settling frames are for).  The
+  // classify pass's duration rises and the march's falls with the reserve: a bisection over the 29
+  // reserves, kBalanceSettle + kBalanceFrames frames per step, five or six steps and the last two reserves once more -- some 85
+  // frames instead of 640 -- then straight to kHold, whose re-timing still falls back to the full search
+  // (kSearch) if the held candidate's period drifts.
+  enum Phase { kSearch, kRefine, kVerify, kHold, kBalance } phase = kSearch;
   int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
   int candidate = kBackToBack;
   int best = kBackToBack, best_beside = 0, second_beside = -1;
@@ -98,6 +108,93 @@ struct CoRunTuner {
     return std::min(std::max(frames, 2), kWindowFrames);  // 1 ms -> 8, 35 ms -> 2, 0.2 ms -> 40
   }
 
+  // ---- kBalance -------------------------------------------------------------------------------
+  static constexpr int kBalanceSettle = 3;   // reports ignored after a change of reserve
+  static constexpr int kBalanceFrames = 4;   // reports averaged per reserve
+  static constexpr int kBalanceSeed = 12;    // 24 KiB: where config-4's one-rank frame balances
+  static constexpr float kClassifyGapMs = 0.014f, kMarchGapMs = 0.028f;  // between two kernels of a stream
+  static constexpr float kBalanceMinMs = 0.35f;  // shorter frames take the full search (the paired
+                                                 // layout and back to back are candidates there)
+  bool balance_allowed = false;  // set_balance(): one rank, nothing fixed by the caller
+  bool balance_failed = false;   // this renderer's frames are too short for it: full search
+  int b_lo = 0, b_hi = 0;        // the reserve where both take equally long lies in [b_lo, b_hi]
+  float b_ms[kLastCandidate + 1] = {};  // max(classify, march) measured at a reserve (0: not yet)
+  bool b_final = false;                 // the bracket has closed: its two ends are being re-timed
+  int b_reports = 0;
+  float b_classify = 0.0f, b_march = 0.0f;
+  void set_balance(bool allowed) {
+    if (allowed == balance_allowed) return;
+    balance_allowed = allowed;
+    restart();
+  }
+  bool balancing() const { return phase == kBalance; }
+  // One frame's kernel durations (events on the two streams), in frame order, with the candidate
+  // the frame was queued under; frames of an older candidate are still in flight after a change.
+  void report_durations(int frame_candidate, float classify_ms, float march_ms) {
+    if (phase != kBalance || frame_candidate != candidate) return;
+    if (++b_reports <= kBalanceSettle) return;
+    b_classify += classify_ms;
+    b_march += march_ms;
+    if (b_reports < kBalanceSettle + kBalanceFrames) return;
+    // Each stream's period is its kernel plus what lies between two of its kernels: the classify
+    // stream runs its passes back to back (14 us), a march also waits for its classify pass's
+    // event on the other stream and for its descriptors (28 us) -- measured: config-2 at 51200
+    // 0.3643 / 0.3658 ms -> period 0.394, at 53248 0.367 / 0.350 -> 0.381; config-3 at 36864
+    // 0.4627 / 0.4616 -> 0.488, at 38912 0.4714 / 0.4486 -> 0.487; config-4 at 24576 0.983 / 0.975
+    // -> 1.002.  The frame's period is the longer of the two.
+    const float classify = b_classify / kBalanceFrames + kClassifyGapMs;
+    const float march = b_march / kBalanceFrames + kMarchGapMs;
+    const float longer = std::max(classify, march);
+    ++windows;
+    last_period_ms = longer;
+    static const bool trace = std::getenv("AVR_CORUN_TRACE") != nullptr;
+    if (trace) {
+      std::fprintf(stderr, "corun: balance candidate %d classify %.4f march %.4f ms (with the streams' gaps) [%d, %d]\n",
+                   candidate, classify, march, b_lo, b_hi);
+    }
+    if (longer < kBalanceMinMs) {  // short frames: the layouts themselves are in question
+      balance_failed = true;
+      restart();
+      return;
+    }
+    b_ms[candidate] = longer;
+    if (candidate != b_lo && candidate != b_hi) {  // (an end of the bracket is only measured)
+      if (classify < march) {  // the march is the longer one: hold the classify pass back further
+        b_lo = candidate;
+      } else {
+        b_hi = candidate;
+      }
+    }
+    if (b_hi - b_lo <= 1) {
+      // The two reserves left are timed afresh, one after the other, before one of them is held:
+      // the bracket's older end was measured steps ago -- the seed right after start-up, when both
+      // kernels still read 10-15 % long -- and the reserve next to the best one is 3-4 % slower.
+      if (!b_final) {
+        b_final = true;
+        b_ms[b_lo] = b_ms[b_hi] = 0.0f;
+      }
+      // (an end never measured before is the scale's end: the balance lies beyond it)
+      if (b_ms[b_lo] == 0.0f) {
+        begin_balance_step(b_lo);
+      } else if (b_ms[b_hi] == 0.0f) {
+        begin_balance_step(b_hi);
+      } else {
+        best = candidate = (b_ms[b_hi] < b_ms[b_lo]) ? b_hi : b_lo;
+        best_beside = best;
+        best_ms = 0.0f;  // (a period, not a duration: the first window of the hold sets it)
+        phase = kHold;
+        interrupt();
+      }
+      return;
+    }
+    begin_balance_step((b_lo + b_hi) / 2);
+  }
+  void begin_balance_step(int next) {
+    candidate = next;
+    b_reports = 0;
+    b_classify = b_march = 0.0f;
+  }
+
   // Where the search starts is what a caller keeps who never renders enough frames back to back
   // for a window to complete (bursts of a few frames between synchronisations): side by side
   // without a reserve for one rank (there back to back is 1.29 ms against 1.05), back to back
@@ -115,6 +212,17 @@ struct CoRunTuner {
   void restart() {
     phase = kSearch;
     candidate = best = (start_beside && last >= 0) ? std::max(first, 0) : first;
+    // the whole side-by-side scale is open to one rank that has not been found too short for it
+    if (balance_allowed && !balance_failed && !coordinated && start_beside && first <= 0 &&
+        last >= kLastCandidate) {
+      phase = kBalance;
+      b_lo = 0;
+      b_hi = kLastCandidate;
+      for (float& ms : b_ms) ms = 0.0f;
+      b_final = false;
+      begin_balance_step(kBalanceSeed);
+      best = candidate;
+    }
     best_beside = 0;
     second_beside = -1;
     best_ms = best_beside_ms = second_beside_ms = 0.0f;
@@ -137,6 +245,10 @@ struct CoRunTuner {
   void drained() {  // a window whose last frame was already queued stays valid
     if (coordinated) {  // (the frame counts are the ranks' common clock: only the window suffers)
       if (open) window_void = true;
+      return;
+    }
+    if (phase == kBalance) {  // (the frames after a drain are not the steady state: settle again)
+      begin_balance_step(candidate);
       return;
     }
     if (!closing) {
@@ -192,7 +304,7 @@ struct CoRunTuner {
   // event: what to record on the march stream now.
   enum Action { kNothing, kOpenWindow, kCloseWindow };
   Action frame() {
-    if (closing) return kNothing;
+    if (closing || phase == kBalance) return kNothing;
     ++frames_at_candidate;
     // After a change of candidate the two streams take a while to find their steady phase (side
     // by side: tens of frames; a window timed right after the change read 3-5 % slow, which was
@@ -245,12 +357,14 @@ struct CoRunTuner {
     }
     repeated = 0;
     if (phase == kHold) {
+      if (best_ms == 0.0f) best_ms = period_ms;  // (held after kBalance: the first period seen)
       // (a rank of several shares its period with the other ranks' exchange: twice the margin)
       if (period_ms > best_ms * (start_beside ? kDrift : 2.0f * kDrift - 1.0f)) {
         // one slow window (a hiccup of the exchange, another process on the node) is not a
         // drift: the candidate is timed once more right away, and only a second slow window
         // starts a new search (whose ~30 candidates include much slower ones)
         if (drift_suspected) {
+          balance_failed = true;  // (whatever was held, it drifted: the full search this time)
           restart();
         } else {
           drift_suspected = true;

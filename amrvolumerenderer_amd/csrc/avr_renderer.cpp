@@ -219,6 +219,7 @@ struct avr_renderer {
   // classify launches beside it) and a march in K launches costs 20 % more than in one.  So:
   // frame_chunks -1 / 1 = one launch per kernel (default), k > 1 = every frame in k chunks.
   int frame_chunks = -1;
+  int balance = -1;  // avr_renderer_set_corun_balance: 0 = always the full search
   hipEvent_t chunk_event[AVR_CLASSIFIED_SLOTS][AVR_MAX_FRAME_CHUNKS] = {};
   int last_chunks = 1;  // what the last frame did (avr_renderer_corun_state / diagnostics)
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
@@ -231,6 +232,15 @@ struct avr_renderer {
   bool timing = false;
   hipEvent_t epoch = nullptr;
   std::vector<FrameEvents> timed;
+  // CoRunTuner::kBalance: the two kernels' own durations of the frames in flight (a ring of timing
+  // events, read back a few frames later, in frame order)
+  struct Probe {
+    FrameEvents events;
+    int candidate = 0;
+  };
+  static constexpr unsigned kProbes = 8;
+  Probe probes[kProbes];
+  unsigned probe_head = 0, probe_tail = 0;  // [tail, head) are in flight
 
   // How the two kernels of a frame share the GPU (CoRunTuner below): the caller's wishes ...
   int share_fixed = -1;   // >= 0: the caller's LDS reserve (avr_renderer_set_classify_share)
@@ -261,6 +271,12 @@ struct avr_renderer {
     clear_timing();
     for (hipEvent_t ev : {window_begin, window_end}) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
+    }
+    for (Probe& probe : probes) {
+      for (hipEvent_t ev : {probe.events.classify_begin, probe.events.classify_end,
+                            probe.events.march_begin, probe.events.march_end}) {
+        if (ev != nullptr) (void)hipEventDestroy(ev);
+      }
     }
     for (hipEvent_t ev : classified_event) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
@@ -328,6 +344,7 @@ struct avr_renderer {
     }
     pipeline_idle = true;
     paired_previous = nullptr;  // nothing is in flight: nothing to order the next classify pass after
+    probe_tail = probe_head;    // (their frames ran into the drain: not the steady state)
     tuner.drained();
   }
 };
@@ -670,6 +687,15 @@ int avr_renderer_set_frame_chunks(avr_renderer* r, int chunks) {
     require(chunks == -1 || (chunks >= 1 && chunks <= AVR_MAX_FRAME_CHUNKS),
             "chunks must be -1 or in [1, AVR_MAX_FRAME_CHUNKS]");
     r->frame_chunks = chunks;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_set_corun_balance(avr_renderer* r, int mode) {
+  return guarded_renderer(r, [&]() -> int {
+    require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
+    r->drain_all();
+    r->balance = mode;
     return AVR_OK;
   });
 }
@@ -1049,6 +1075,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         }
       }
       tuner.restrict_to(first, last, r->n_ranks == 1);
+      // one rank with nothing fixed: the balance of the two kernels is read off their durations
+      tuner.set_balance(r->n_ranks == 1 && r->balance != 0);
       // ranks of several search together (avr_corun.h): the same candidate in the same frames,
       // every window's period the maximum over the ranks
       tuner.set_coordinated(many && r->comm != nullptr && r->coordinate != 0);
@@ -1137,6 +1165,17 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     } timed_guard;
     FrameEvents& timed = timed_guard.events;
+    // kBalance: this frame's kernels are timed through a slot of the probe ring (if one is free)
+    avr_renderer::Probe* probe = nullptr;
+    if (tuner.balancing() && overlap && !paired && !r->pipeline_idle &&
+        r->probe_head - r->probe_tail < avr_renderer::kProbes) {
+      probe = &r->probes[r->probe_head % avr_renderer::kProbes];
+      for (hipEvent_t* ev : {&probe->events.classify_begin, &probe->events.classify_end,
+                             &probe->events.march_begin, &probe->events.march_end}) {
+        if (*ev == nullptr) *ev = make_event(true);
+      }
+      probe->candidate = tuner.candidate;
+    }
     if (r->timing) {
       timed.classify_begin = make_event(true);
       timed.classify_end = make_event(true);
@@ -1210,12 +1249,14 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       }
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
+    if (probe != nullptr) hip_ok(hipEventRecord(probe->events.classify_begin, stream_c), "hipEventRecord");
     if (n_chunks > 1) {
       abi_ok(avr_classify_plan_chunked(classify_ctx, r->scene, plan, volume, n_chunks, chunk_events,
                                        was_idle ? 1 : 0));
     } else {
       abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
     }
+    if (probe != nullptr) hip_ok(hipEventRecord(probe->events.classify_end, stream_c), "hipEventRecord");
     hipEvent_t classified = r->timing ? timed.classify_end : r->classified_event[volume];
     if (overlap || r->timing) hip_ok(hipEventRecord(classified, stream_c), "hipEventRecord");
     // (what the NEXT frame waits on must outlive this frame's timing events, which
@@ -1234,11 +1275,32 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       hip_ok(hipStreamWaitEvent(stream_m, classified, 0), "hipStreamWaitEvent");
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
+    if (probe != nullptr) hip_ok(hipEventRecord(probe->events.march_begin, stream_m), "hipEventRecord");
     if (n_chunks > 1) {
       abi_ok(avr_march_plan_chunked(march_ctx, r->scene, plan, volume, send, samples_out, n_chunks,
                                     chunk_events));
     } else {
       abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
+    }
+    if (probe != nullptr) {
+      hip_ok(hipEventRecord(probe->events.march_end, stream_m), "hipEventRecord");
+      ++r->probe_head;
+    }
+    // kBalance: the durations of the frames that are through by now, in frame order
+    while (r->probe_tail != r->probe_head) {
+      avr_renderer::Probe& done = r->probes[r->probe_tail % avr_renderer::kProbes];
+      if (hipEventQuery(done.events.march_end) != hipSuccess ||
+          hipEventQuery(done.events.classify_end) != hipSuccess) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+        break;
+      }
+      float classify_ms = 0.0f, march_ms = 0.0f;
+      hip_ok(hipEventElapsedTime(&classify_ms, done.events.classify_begin, done.events.classify_end),
+             "hipEventElapsedTime");
+      hip_ok(hipEventElapsedTime(&march_ms, done.events.march_begin, done.events.march_end),
+             "hipEventElapsedTime");
+      ++r->probe_tail;
+      tuner.report_durations(done.candidate, classify_ms, march_ms);
     }
     // the tuner's window: the period of a few frames between two events after the march
     if (tuner.tuning()) {

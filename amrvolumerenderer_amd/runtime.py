@@ -819,6 +819,11 @@ class NativeRenderer:
         profiles/r5_latency/)."""
         _capi.check(_capi.lib().avr_renderer_set_frame_chunks(self._handle, int(chunks)))
 
+    def set_corun_balance(self, mode: int = -1) -> None:
+        """avr_renderer_set_corun_balance: -1 / 1 one rank balances its two kernels by their
+        durations (a bisection of ~70 frames), 0 always the full search of every candidate."""
+        _capi.check(_capi.lib().avr_renderer_set_corun_balance(self._handle, int(mode)))
+
     def last_frame_chunks(self) -> int:
         return int(_capi.lib().avr_renderer_last_frame_chunks(self._handle))
 

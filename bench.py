@@ -73,6 +73,10 @@ def parse_args():
                     help="test hook: this rank stops rendering after the settling frames and sleeps "
                          "(a peer that hangs): the others must run into AVR_FRAME_TIMEOUT_MS, say "
                          "where, and the launch must end non-zero")
+    ap.add_argument("--corun-full-search", action="store_true",
+                    help="A/B only: one rank times every candidate of the co-run search (rounds 2-4) "
+                         "instead of balancing the two kernels by their durations "
+                         "(avr_renderer_set_corun_balance)")
     ap.add_argument("--no-coordination", action="store_true",
                     help="N > 1, A/B only: every rank runs the co-run search on its own (round 3) "
                          "instead of all ranks as one system (avr_renderer_set_corun_coordination)")
@@ -392,6 +396,8 @@ def run(args, state):
                              stream_priorities=tuple(int(v) for v in args.priorities.split(",")),
                              cache_classification=args.cache_classification)
     state["renderer"] = renderer
+    if renderer.native is not None and args.corun_full_search:
+        renderer.native.set_corun_balance(0)
     if renderer.native is not None and args.no_coordination:
         renderer.native.set_corun_coordination(0)
     if renderer.native is not None and args.classify_share >= 0:
@@ -503,12 +509,11 @@ def run(args, state):
     # Untimed setup (optional): pick the march occupancy cap for this workload
     if args.autotune and world == 1:
         renderer.autotune(rparams, cameras[0], frames=30)
-    # Untimed setup, like the sample counting above: about a third of a second of frames brings
-    # the GPU to its working clocks and fills the allocator pools, so that a run timing very few
-    # steps (the driver's --steps 20 is a 20 ms timed region) measures the steady state a
-    # 200-step run does -- and the C++ frame driver finishes measuring how this rank's two
-    # kernels share the GPU (avr_renderer_corun_state; bounded at 2 s); then the W warm-up steps
-    # of the contract.
+    # Untimed setup, like the sample counting above: the frames in which the C++ frame driver
+    # settles how this rank's two kernels share the GPU (avr_renderer_corun_state; bounded at 2 s)
+    # -- they also bring the GPU to its working clocks and fill the allocator pools, so that a run
+    # timing very few steps (the driver's --steps 20 is a 20 ms timed region) measures the steady
+    # state a 200-step run does; then the W warm-up steps of the contract.
     burst_begin = time.perf_counter()
     burst = 0
 
@@ -528,7 +533,9 @@ def run(args, state):
         if fixed_burst is not None:
             done = burst >= fixed_burst
         else:
-            done = burst >= 32 and elapsed >= 0.35 and (elapsed >= 2.0 or settled())
+            # (one rank: the driver balances its two kernels within ~85 frames,
+            # avr_renderer_set_corun_balance; the full search of rounds 2-4 took 600-1500)
+            done = burst >= 32 and (elapsed >= 2.0 or settled())
         if done:
             break
         # (No synchronise in here for the C++ driver: its queue is a few frames deep at most

@@ -85,7 +85,103 @@ float eighth(int c) {
 
 }  // namespace
 
+// kBalance: a model GPU answers every frame with the two kernels' durations under the candidate
+// the frame was queued with, `lag` frames later.  classify rises, march falls with the reserve.
+using Durations = std::function<void(int, float*, float*)>;
+struct BalanceRun {
+  int frames = 0, candidate = 0;
+  long steps = 0;
+};
+BalanceRun play_balance(CoRunTuner& tuner, const Durations& model, int limit, int lag = 3,
+                        int drain_every = 0) {
+  BalanceRun run;
+  std::vector<int> in_flight;  // candidates of the frames whose events are still pending
+  for (int frame = 1; frame <= limit && tuner.balancing(); ++frame) {
+    if (drain_every > 0 && frame % drain_every == 0) {
+      in_flight.clear();
+      tuner.drained();
+    }
+    in_flight.push_back(tuner.candidate);
+    (void)tuner.frame();
+    while (static_cast<int>(in_flight.size()) > lag) {
+      float classify = 0.0f, march = 0.0f;
+      model(in_flight.front(), &classify, &march);
+      tuner.report_durations(in_flight.front(), classify, march);
+      in_flight.erase(in_flight.begin());
+    }
+    run.frames = frame;
+  }
+  run.candidate = tuner.candidate;
+  run.steps = tuner.windows;
+  return run;
+}
+
+// config-4 (profiles/r5_corun_gap/README.md, section 4, DEPTH 1): the two trade one resource
+void config4_durations(int c, float* classify, float* march) {
+  const float kib = 2.0f * static_cast<float>(c);
+  // c + m = 1.34 in solo-speed units; the classify pass's share falls with the reserve
+  const float share = kib <= 16.0f ? 0.665f : std::max(0.36f, 0.665f - (kib - 16.0f) * 0.0145f);
+  *classify = 0.527f / share;
+  *march = 0.681f / (1.34f - share);
+}
+
 int main() {
+  {  // kBalance: one rank bisects to where the two kernels take equally long, in tens of frames
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, /*beside_first=*/true);
+    t.set_balance(true);
+    expect(t.balancing() && !t.settled() && t.candidate == CoRunTuner::kBalanceSeed,
+           "one rank starts balancing from the seed reserve");
+    const BalanceRun run = play_balance(t, config4_durations, 400);
+    expect(t.settled() && t.phase == CoRunTuner::kHold, "the balance is held");
+    float classify = 0.0f, march = 0.0f;
+    config4_durations(run.candidate, &classify, &march);
+    expect(std::fabs(classify - march) < 0.08f, "both kernels take about equally long at the held "
+           "reserve, got candidate " + std::to_string(run.candidate));
+    expect(run.frames <= 96, "the balance is found within 96 frames, took " + std::to_string(run.frames));
+    // a caller who drains every 10 frames still gets there (a drain restarts only the step)
+    CoRunTuner d;
+    d.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    d.set_balance(true);
+    const BalanceRun drained = play_balance(d, config4_durations, 2000, 3, 10);
+    expect(d.settled() && std::abs(drained.candidate - run.candidate) <= 1,
+           "drains only delay the balance, got " + std::to_string(drained.candidate));
+    // the held candidate's period is taken from the first window of the hold, a drift of it goes
+    // to the FULL search
+    const Run held = play(t, one_rank, 2000, 2, 0, false);
+    expect(t.settled() && held.windows > run.steps, "the hold re-times the balanced candidate");
+    expect(!t.balance_failed, "no drift, no search");
+  }
+  {  // kBalance at the ends of the scale: a classify pass that is always longer (the opaque regime)
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    t.set_balance(true);
+    const BalanceRun run = play_balance(t, [](int c, float* cl, float* m) { *cl = 0.6f + 0.01f * c; *m = 0.2f; }, 400);
+    expect(t.settled() && run.candidate == 0, "a classify-bound frame holds no reserve, got " +
+                                                  std::to_string(run.candidate));
+    CoRunTuner u;
+    u.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    u.set_balance(true);
+    const BalanceRun far = play_balance(u, [](int c, float* cl, float* m) { *cl = 0.4f; *m = 0.9f - 0.001f * c; }, 400);
+    expect(u.settled() && far.candidate == CoRunTuner::kLastCandidate,
+           "a march-bound frame holds the whole reserve, got " + std::to_string(far.candidate));
+  }
+  {  // kBalance is not for short frames (layouts in question) nor for ranks of several
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    t.set_balance(true);
+    (void)play_balance(t, [](int, float* cl, float* m) { *cl = 0.1f; *m = 0.12f; }, 400);
+    expect(!t.balancing() && t.balance_failed && t.phase == CoRunTuner::kSearch && !t.settled(),
+           "short frames take the full search");
+    CoRunTuner several;
+    several.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, false);
+    several.set_balance(true);
+    expect(!several.balancing(), "ranks of several search");
+    CoRunTuner fixed;
+    fixed.restrict_to(0, 0, true);
+    fixed.set_balance(true);
+    expect(!fixed.balancing() && fixed.settled(), "a fixed reserve is not balanced");
+  }
   {  // one rank: starts side by side, never tries back to back before the end, finds the dip
     CoRunTuner t;
     t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, /*beside_first=*/true);

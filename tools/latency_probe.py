@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--burst", type=int, default=100)
     ap.add_argument("--repeat-camera", action="store_true",
                     help="single frames of ONE camera (the plan is cached after the first)")
+    ap.add_argument("--full-search", action="store_true", help="avr_renderer_set_corun_balance(0)")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
 
@@ -58,8 +59,11 @@ def main():
                                antialiasing=args.antialiasing, draw_bounds=False)
 
     def fresh():
-        return FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
-                             spec.scalar_range, 0, 1, None)
+        renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
+                                 spec.scalar_range, 0, 1, None)
+        if args.full_search:
+            renderer.native.set_corun_balance(0)
+        return renderer
 
     # ---- single synchronised frames ---------------------------------------------------------
     renderer = fresh()
