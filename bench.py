@@ -43,8 +43,11 @@ def parse_args():
                              "block"])
     ap.add_argument("--antialiasing", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0,
-                    help="target CPU time of the bounded cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0,
+                    help="cap of the cpu_baseline leg's CPU time (config-4 needs ~35 s for its "
+                         "whole, unextrapolated frame; what does not fit is extrapolated and says so)")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the untimed single-frame / first-100-frames figures (`latency`)")
     ap.add_argument("--orbit", type=int, default=0, help="average over this many orbit views")
     ap.add_argument("--fly-through", action="store_true",
                     help="every frame of the timed region (and of the warm-up) has a camera the "
@@ -114,12 +117,13 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
     renderSingleTrial times three stages (reportStageTime, VolumeRenderer.cpp:1121-1136):
     per-box rendering (:1200-1219: VolumePainter::paint into one full-frame layer per box),
     compositing (:1231-1253: composeLayered) and gather + write; the reference is serial per rank
-    (AMReX_OMP OFF) and parallel over MPI ranks.  Here, inside ~`seconds` of CPU time: every 4th
-    box of the level-major list is painted at full resolution on T threads (OpenMP over image
-    rows stands in for T ranks painting their own boxes), every 16th also on one thread (= one
-    reference rank); the painted layers are folded by orc_compose_layered on one thread (what one
-    rank does for its piece, times the ranks); the result is converted to bytes.  Stage times of
-    the whole frame are extrapolated by samples (paint) and by layers (compose) and say so."""
+    (AMReX_OMP OFF) and parallel over MPI ranks.  Unextrapolated wherever the budget allows (it
+    does for config-1 to config-4): EVERY box is painted at full resolution on T threads (OpenMP
+    over image rows stands in for T ranks painting their own boxes) and, as one reference rank,
+    again on one thread; ALL full-frame layers are folded by orc_compose_layered on one thread (what
+    one rank does for its piece, times the ranks); the result is converted to bytes.  `seconds`
+    caps the CPU time (config-5's 1856 layers of 1.34 GB cannot be held): what did
+    not fit is extrapolated by samples (paint) and by layers (compose), and the line says so."""
     import numpy as np
     from oracle import oracle as O
     threads = min(os.cpu_count() or 1, 16)
@@ -133,28 +137,38 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
                        renderer.reference_sample_distance, spec.bounds.min_corner,
                        spec.bounds.max_corner)
     n = len(local_boxes)
-    stride = 4 if n >= 16 else 1
-    picks = list(range(0, n, stride))
-    budget_end = time.perf_counter() + seconds
+    layer_bytes = params.width * params.height * 20
+    # (the layers are kept for the fold: at most ~24 GB of them)
+    keep = max(8, min(n, int(24e9 // layer_bytes)))
+    begin = time.perf_counter()
+    deadline = begin + seconds
     layers, hints = [], []
     paint_s = paint_samples = 0
     serial_s = serial_samples = 0
-    for count, i in enumerate(picks):
+    painted = 0
+    o_boxes = []
+    for i in range(n):
+        if i >= keep or (time.perf_counter() > deadline * 0.5 + begin * 0.5 and painted >= 8):
+            break   # (half the budget belongs to the one-rank pass and the fold)
         box = local_boxes[i]
         ob = O.make_box(box.values.cpu().numpy(), box.min_corner, box.max_corner)
+        o_boxes.append(ob)
         t0 = time.perf_counter()
         layer, ns = O.paint_box(ob, otr, op, ocam, threads=threads)
         paint_s += time.perf_counter() - t0
         paint_samples += ns
         layers.append(layer)
         hints.append(O.box_depth_hint(ob, ocam))
-        if count % 4 == 0 and time.perf_counter() < budget_end:   # one reference rank
-            t0 = time.perf_counter()
-            _, ns1 = O.paint_box(ob, otr, op, ocam, threads=1)
-            serial_s += time.perf_counter() - t0
-            serial_samples += ns1
-        if time.perf_counter() > budget_end and len(layers) >= 8:
+        painted += 1
+    serial_boxes = 0
+    for ob in o_boxes:   # one reference rank: the same boxes on one thread
+        if time.perf_counter() > deadline and serial_boxes >= 4:
             break
+        t0 = time.perf_counter()
+        _, ns1 = O.paint_box(ob, otr, op, ocam, threads=1)
+        serial_s += time.perf_counter() - t0
+        serial_samples += ns1
+        serial_boxes += 1
     used = len(layers)
     t0 = time.perf_counter()
     image, _, _ = O.compose_layered(layers, hints, [0] * used, list(range(used)), 1)
@@ -162,8 +176,10 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
     t0 = time.perf_counter()
     O.quantize_rgb8(image, params.width, params.height)
     bytes_s = time.perf_counter() - t0
-    # the whole frame: paint scales with the samples, the fold with the layers
     total = float(frame_samples)
+    whole = used == n and serial_boxes == n
+    # the whole frame (identity where every box was painted): paint scales with the samples, the
+    # fold with the layers
     paint_frame = paint_s * total / max(paint_samples, 1)
     paint_serial = serial_s * total / max(serial_samples, 1)
     compose_serial = compose_s * n / used
@@ -173,6 +189,7 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
     return {
         "value": round(total / frame / 1e6, 3), "unit": "Mray-samples/s", "cores": threads,
         "kind": "port", "frames_per_s": round(1.0 / frame, 4),
+        "extrapolated": not whole,
         "stages_s": {"per_box_rendering": round(paint_frame, 3),
                      "compositing": round(compose_ranks, 3),
                      "gather_and_bytes": round(bytes_s, 3)},
@@ -183,17 +200,71 @@ def cpu_baseline(spec, local_boxes, renderer, rparams, camera, seconds, frame_sa
                                   "gather_and_bytes": round(bytes_s, 3)}},
         "sample": f"oracle frame in the reference's stages (VolumeRenderer.cpp:1121-1136) at "
                   f"{params.width}x{params.height}, same camera and transfer function: "
-                  f"VolumePainter::paint of {used} of the {n} boxes (every {stride}th of the "
-                  f"level-major list, {paint_samples} samples in {paint_s:.2f} s on {threads} "
-                  f"OpenMP threads over image rows; {serial_samples} samples in {serial_s:.2f} s "
-                  f"on one thread = one reference rank), orc_compose_layered of those {used} "
-                  f"full-frame layers on one thread ({compose_s:.2f} s; divided by {threads} for "
-                  f"{threads} ranks folding their own pieces), 8-bit conversion {bytes_s:.3f} s; "
-                  f"stage times extrapolated to the frame's {int(total)} samples / {n} layers",
+                  f"VolumePainter::paint of {used} of the {n} boxes ({paint_samples} of the frame's "
+                  f"{int(total)} samples in {paint_s:.2f} s on {threads} OpenMP threads over image "
+                  f"rows) and of {serial_boxes} of them on one thread = one reference rank "
+                  f"({serial_samples} samples in {serial_s:.2f} s), orc_compose_layered of those "
+                  f"{used} full-frame layers on one thread ({compose_s:.2f} s; divided by {threads} "
+                  f"for {threads} ranks folding their own pieces), 8-bit conversion {bytes_s:.3f} s; "
+                  + ("nothing extrapolated" if whole else
+                     "stage times extrapolated to the whole frame by samples / layers "
+                     "(the --cpu-seconds budget)"),
     }
 
 
-PMC_SUMMARY = os.path.join("profiles", "r4_final", "pmc_summary.txt")
+def latency(ctx, spec, all_boxes, local_boxes, rparams, cameras):
+    """What a drop-in caller of Render() gets, beside the pipelined headline (untimed, after it):
+    the reference renders ONE frame per call and returns (VolumeRenderer.cpp:1103-1339,
+    Examples/RenderFromMultiFab.cpp:17-62, module.cpp:252-255).  single_frame_ms: a FRESH renderer,
+    a camera it has never seen per frame, render + synchronize on the host clock (plan + classify +
+    march + fold, nothing overlapped with another frame), median of 10 after the frame that
+    allocates; first_100: another fresh renderer, 100 frames of one camera queued back to back --
+    their mean period and the frame at which the driver reported its co-run layout settled."""
+    import statistics
+    import torch
+    from amrvolumerenderer_amd import scenes
+    from amrvolumerenderer_amd.renderer import FrameRenderer
+
+    def fresh():
+        return FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
+                             spec.scalar_range, 0, 1, None)
+
+    renderer = fresh()
+    singles = []
+    for i in range(11):
+        cam = scenes.orbit_camera(7 * i + 3, 3600)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        renderer.render(rparams, cam)
+        renderer.synchronize()
+        singles.append((time.perf_counter() - t0) * 1e3)
+    del renderer
+    renderer = fresh()
+    settled_at = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(100):
+        renderer.render(rparams, cameras[0])
+        if settled_at is None and renderer.native.corun_state()["settled"]:
+            settled_at = i + 1
+    renderer.synchronize()
+    mean_100 = (time.perf_counter() - t0) * 1e3 / 100
+    while settled_at is None and i < 2000:   # (bounded: the full search takes ~700 frames)
+        i += 1
+        renderer.render(rparams, cameras[0])
+        if renderer.native.corun_state()["settled"]:
+            settled_at = i + 1
+    renderer.synchronize()
+    corun = renderer.native.corun_state()
+    del renderer
+    return {"single_frame_ms": round(statistics.median(singles[1:]), 4),
+            "single_frame_ms_min_max": [round(min(singles[1:]), 4), round(max(singles[1:]), 4)],
+            "first_frame_with_allocations_ms": round(singles[0], 3),
+            "first_100_frames_mean_ms": round(mean_100, 4),
+            "frames_to_settle": settled_at, "settled_on": corun}
+
+
+PMC_DIR = os.path.join("profiles", "r5_final")
 PMC_SOURCES = ("avr_kernels.hip", "avr_device.h", "avr_renderer.cpp")
 
 
@@ -208,26 +279,41 @@ def kernel_sources_sha256():
     return digest.hexdigest()
 
 
+def workload_key(args, world):
+    """Names the workloads whose PMC summaries are committed (profiles/r5_final/pmc_<key>.txt):
+    one rank, the smooth field, the default camera, the configuration's own image size."""
+    if (world != 1 or args.field != "smooth" or args.width or args.height or args.orbit
+            or args.fly_through or args.cache_classification):
+        return None
+    if args.antialiasing != (4 if args.config == "config5" else 1):
+        return None
+    regime = {0.97: "translucent", 0.0: "opaque"}.get(args.transparency)
+    if regime is None or args.config not in ("config2", "config3", "config4", "config5"):
+        return None
+    return f"{args.config}_{regime}"
+
+
 def profiled_traffic(args, world):
-    """HBM bytes per paint-stage launch from the committed rocprofv3 PMC summary of THIS command
+    """HBM bytes per paint-stage launch from the committed rocprofv3 PMC summary of THIS workload
     (separate --pmc passes, tools/pmc_passes.sh) -- only if that summary was taken on the kernels
     of this tree: its first line carries the sha256 of the kernel and driver sources, and a tree
     whose sources differ gets (None, "stale ...") instead of somebody else's bytes.  FETCH_SIZE and
     WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane)
     coalesced stream, so the classify kernel's reads are doubled and the march's byte gathers
-    are not (MI355X_MICROARCH.md, HBM).  Only valid for the default single-GPU workload."""
-    default = (world == 1 and args.config == "config4" and args.field == "smooth"
-               and args.transparency == 0.97 and not args.width and not args.height
-               and args.antialiasing == 1 and args.orbit == 0 and not args.fly_through)
-    path = os.path.join(ROOT, PMC_SUMMARY)
-    if not default:
+    are not (MI355X_MICROARCH.md, HBM)."""
+    key = workload_key(args, world)
+    if key is None:
         return None, None
+    summary = os.path.join(PMC_DIR, f"pmc_{key}.txt")
+    path = os.path.join(ROOT, summary)
     if not os.path.exists(path):
-        return None, f"no PMC summary ({PMC_SUMMARY})"
+        return None, f"no PMC summary ({summary})"
     counters, kernel, recorded = {}, None, None
     for line in open(path):
         if line.startswith("# sources sha256:"):
             recorded = line.split(":", 1)[1].split()[0]
+            continue
+        if line.startswith("#"):
             continue
         if not line.startswith(" "):
             kernel = line.strip()
@@ -236,7 +322,7 @@ def profiled_traffic(args, world):
         if len(parts) >= 3 and parts[-1].startswith("mean="):
             counters[(kernel, parts[0])] = float(parts[-1][5:])
     if recorded != kernel_sources_sha256():
-        return None, (f"stale: {PMC_SUMMARY} was taken on other kernel sources "
+        return None, (f"stale: {summary} was taken on other kernel sources "
                       f"({(recorded or 'no digest')[:12]}...): rerun tools/pmc_passes.sh")
     try:
         kib = (2.0 * counters[("classify_kernel", "FETCH_SIZE")]
@@ -244,8 +330,8 @@ def profiled_traffic(args, world):
                + counters[("render_runs_kernel", "FETCH_SIZE")]
                + counters[("render_runs_kernel", "WRITE_SIZE")])
     except KeyError:
-        return None, f"{PMC_SUMMARY} lacks FETCH_SIZE / WRITE_SIZE"
-    return int(kib * 1024), PMC_SUMMARY
+        return None, f"{summary} lacks FETCH_SIZE / WRITE_SIZE"
+    return int(kib * 1024), summary
 
 
 def launcher_command(n_ranks, port, argv):
@@ -734,6 +820,14 @@ def run(args, state):
         },
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and not args.no_latency and native:
+        # (the headline's renderer goes first: a second set of classified volumes beside it is
+        # 1.1 GB for config-4, 11 GB for config-5)
+        state.pop("renderer", None)
+        del renderer
+        out["latency"] = latency(ctx, spec, all_boxes, local_boxes, rparams, cameras)
+        renderer = FrameRenderer(ctx, all_boxes, local_boxes, spec.transform, spec.bounds,
+                                 spec.scalar_range, rank, world, group)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, local_boxes, renderer, rparams, cameras[0],
                                            args.cpu_seconds, frame_samples[0])
