@@ -165,6 +165,7 @@ SIGNATURES = {
     "avr_march_plan": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_classify_plan_chunked": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp), C.c_int]),
     "avr_march_plan_chunked": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "avr_render_plan_culled": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_own": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_image": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -235,6 +236,7 @@ SIGNATURES = {
     "avr_renderer_prepare": (C.c_int, [_vp, C.POINTER(RenderParams), C.POINTER(Camera), _ip]),
     "avr_renderer_synchronize": (C.c_int, [_vp]),
     "avr_renderer_set_frame_chunks": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_set_occlusion_culling": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_corun_balance": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_last_frame_chunks": (C.c_int, [_vp]),
     "avr_renderer_outputs_complete": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

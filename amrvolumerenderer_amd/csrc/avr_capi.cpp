@@ -358,6 +358,11 @@ struct FrameChunks {
   int count = 1;
   hipEvent_t const* events = nullptr;  // count events, or null (both calls on one stream)
   bool first_alone = false;            // classify: chunk 0 has the GPU to itself (no LDS reserve)
+  // avr_render_plan_culled: ONE call queues classify 0, march 0, classify 1, march 1 ... on the
+  // context's stream; march k flags the boxes behind chunk k that a ray may still sample in
+  // visibility[k * n_order + position] (count * n_order bytes, cleared by the call), classify
+  // k + 1 leaves out the boxes of its chunk whose flag is 0.
+  uint8_t* visibility = nullptr;
 };
 
 // Positions [bounds[k], bounds[k + 1]) of the global layer order for chunk k: equal shares of the
@@ -399,8 +404,8 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const FrameChunks& chunks = FrameChunks{}) {
   require(n_runs >= 0 && n_order >= 0 && n_pieces >= 1, "invalid run description");
   require(chunks.count >= 1 && chunks.count <= AVR_MAX_FRAME_CHUNKS, "invalid chunk count");
-  require(chunks.count == 1 || phases == kClassify || phases == kMarch,
-          "a chunked frame is classified and marched by separate calls");
+  require(chunks.count == 1 || phases == kClassify || phases == kMarch || chunks.visibility != nullptr,
+          "a chunked frame is classified and marched by separate calls (or by avr_render_plan_culled)");
   require(slot >= 0 && slot < AVR_CLASSIFIED_SLOTS, "classified slot out of range");
   avr::FramePlan local;
   avr::FramePlan& plan = cached ? *cached : local;
@@ -555,9 +560,18 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   staging.commit(ctx->stream);
   if (chunked) {
     const uint32_t reserve = launch.classify_lds_pad;
+    if (chunks.visibility != nullptr) {
+      avr::hip_check(hipMemsetAsync(chunks.visibility, 0,
+                                    static_cast<size_t>(chunks.count) * static_cast<size_t>(n_order),
+                                    ctx->stream), "hipMemsetAsync(visibility)");
+    }
     for (int k = 0; k < chunks.count; ++k) {
       const int first = bounds[static_cast<size_t>(k)], last = bounds[static_cast<size_t>(k) + 1];
       if (phases & kClassify) {
+        // (what the march launch of the chunk before found still visible of this chunk's boxes)
+        launch.visible_in = (chunks.visibility != nullptr && k > 0)
+                                ? chunks.visibility + static_cast<size_t>(k - 1) * n_order + first
+                                : nullptr;
         if (last > first) {
           launch.box_list_dev = chunk_box_list_dev + first;
           launch.n_classify_boxes = last - first;
@@ -570,12 +584,18 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
         if (chunks.events != nullptr) {
           avr::hip_check(hipEventRecord(chunks.events[k], ctx->stream), "hipEventRecord(chunk)");
         }
-      } else {
-        if (chunks.events != nullptr) {
+      }
+      if (phases & kMarch) {
+        launch.visible_out = (chunks.visibility != nullptr && k + 1 < chunks.count)
+                                 ? chunks.visibility + static_cast<size_t>(k) * n_order
+                                 : nullptr;
+        if (chunks.events != nullptr && !(phases & kClassify)) {
           avr::hip_check(hipStreamWaitEvent(ctx->stream, chunks.events[k], 0), "hipStreamWaitEvent(chunk)");
         }
         // (the first launch stores every pixel of the runs' layers; the later ones resume them)
-        if (last > first || k == 0) {
+        // (with occlusion culling every chunk's march is launched: it is what flags the boxes of
+        // the chunks behind it -- flags left at 0 would mean "nobody samples them")
+        if (last > first || k == 0 || chunks.visibility != nullptr) {
           launch.pos_begin = first;
           launch.pos_end = last;
           launch.resume = k > 0 ? 1 : 0;
@@ -1109,6 +1129,19 @@ int avr_march_plan_chunked(avr_context* ctx, const avr_scene* scene, const avr_f
   chunks.count = n_chunks;
   chunks.events = reinterpret_cast<hipEvent_t const*>(chunk_events);
   return plan_phase(ctx, kMarch, scene, plan, slot, send_buffer, samples_out, chunks);
+}
+
+int avr_render_plan_culled(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                           int slot, float* send_buffer, uint64_t* samples_out, int n_chunks,
+                           uint8_t* visibility) {
+  return guarded([&]() -> int {
+    require(visibility != nullptr && n_chunks >= 2, "a culled frame needs chunks and a visibility buffer");
+    FrameChunks chunks;
+    chunks.count = n_chunks;
+    chunks.visibility = visibility;
+    chunks.first_alone = true;
+    return plan_phase(ctx, kClassify | kMarch, scene, plan, slot, send_buffer, samples_out, chunks);
+  });
 }
 
 int avr_fold_plan(avr_context* ctx, const avr_frame_plan* plan, const float* recv_buffer,

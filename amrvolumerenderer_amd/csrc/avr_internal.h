@@ -268,6 +268,11 @@ struct RenderLaunch {
   int n_classify_boxes = 0;
   int pos_begin = 0, pos_end = -1;      // pos_end < 0: n_order
   int resume = 0;
+  // occlusion culling between the chunks (avr_render_plan_culled): the march launch of chunk k
+  // flags the boxes behind it that a ray may still sample (indexed by position in the global layer
+  // order), the classify launch of chunk k + 1 leaves out the others (indexed like its box list)
+  uint8_t* visible_out = nullptr;
+  const uint8_t* visible_in = nullptr;
 };
 // classify pass (cells -> table indices) and march; the march reads what the classify pass of
 // the same frame wrote into `classified`

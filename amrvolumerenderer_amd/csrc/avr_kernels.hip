@@ -489,7 +489,11 @@ render_runs_kernel(
     // positions [pos_begin, pos_end) of `order`; resume != 0: the run accumulator starts from what
     // the launch before stored (the left fold of DirectSendBase.cpp:413-426 is cut, not re-associated:
     // the same blends in the same order on the same five floats).
-    const int pos_begin, const int pos_end, const int resume) {
+    const int pos_begin, const int pos_end, const int resume,
+    // non-null (a frame in depth-ordered chunks with occlusion culling, avr_render_plan_culled):
+    // visible_out[position] is set to 1 for every box behind this launch's that some ray may still
+    // sample -- see the end of the kernel; the caller cleared it.
+    uint8_t* __restrict__ visible_out) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
@@ -642,6 +646,45 @@ render_runs_kernel(
         touched = true;
       }
     }
+    // ---- which of the boxes BEHIND this launch's can still be sampled ---------------------------
+    // The march skips a box at a pixel whose run accumulator is opaque and in front of the box's
+    // entry point (above: the blend would return the accumulator unchanged).  A box that EVERY ray
+    // skips is never read -- so it need not be classified (the classify launch of the next chunk
+    // leaves out the boxes whose flag stays 0: the f64 cells of occluded boxes are not even read;
+    // the reference's default boxTransparency = 0 saturates most rays in the first boxes,
+    // VolumePainter.cpp:837).  Exactly the march's own test, evaluated now for the boxes to come,
+    // in order, with one more bit per pixel: once a box is NOT skipped at a pixel it is marched and
+    // may change the accumulator there (even an opaque one: a layer in front of it gives
+    // a + 1 * (1 - a), which need not round to 1), so every later box the pixel's ray hits counts
+    // as visible.  By induction a box flagged invisible finds, at every pixel that hits it, the
+    // accumulator this launch left -- and is skipped.
+    if (visible_out != nullptr) {
+      bool open = false;  // an earlier box to come is marched at this pixel
+      // (the run's boxes behind this launch's; a run that only starts behind them: all of its boxes)
+      for (int position = (end > run_begin) ? end : run_begin; position < run_end[run]; ++position) {
+        const BoxDev& box = boxes[order[position]];
+        if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + (kWaveW - 1) || box.rect[3] < wave_y0 ||
+            box.rect[1] > wave_y0 + (kWaveH - 1)) {
+          continue;
+        }
+        float tmin = -AVR_INF;
+        float tmax = AVR_INF;
+        slab_axis(ray.ox, ray.dx, inv_dx, box.minc[0], box.maxc[0], tmin, tmax);
+        slab_axis(ray.oy, ray.dy, inv_dy, box.minc[1], box.maxc[1], tmin, tmax);
+        slab_axis(ray.oz, ray.dz, inv_dz, box.minc[2], box.maxc[2], tmin, tmax);
+        bool visible = live && (tmax >= tmin);
+        if (visible && !open && acc.a == 1.0f) {
+          const float ex = ray.ox + ray.dx * tmin;
+          const float ey = ray.oy + ray.dy * tmin;
+          const float ez = ray.oz + ray.dz * tmin;
+          const float entry_depth = (ex - fc.eye[0]) * fc.fwd[0] + (ey - fc.eye[1]) * fc.fwd[1] +
+                                    (ez - fc.eye[2]) * fc.fwd[2];
+          if (acc.d <= entry_depth) visible = false;
+        }
+        open = open || visible;
+        if (__builtin_amdgcn_ballot_w64(visible) != 0 && lane == 0) visible_out[position] = 1;
+      }
+    }
     if (touched) {
       float* const dst = layer_pixel();
       if (STATS && counters != nullptr && dst == nullptr && acc.a != 0.0f && live && px >= rect.x0 &&
@@ -717,7 +760,10 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     const int stream_stores,
     // non-null: this launch classifies the boxes box_list[0 .. n_boxes) (one depth-ordered chunk of
     // the frame; tile_begin is the chunk's prefix sum); null: boxes[0 .. n_boxes)
-    const int32_t* __restrict__ box_list) {
+    const int32_t* __restrict__ box_list,
+    // non-null: visible[i] == 0 means no ray samples box box_list[i] this frame (the march's flags,
+    // render_runs_kernel): it is not classified
+    const uint8_t* __restrict__ visible) {
   __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
 
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
@@ -731,6 +777,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
       hi = mid;
     }
   }
+  if (visible != nullptr && visible[lo] == 0) return;  // (wave-uniform; before any barrier)
   const BoxDev& box = boxes[box_list != nullptr ? box_list[lo] : lo];
   const int nx = box.nx, ny = box.ny, nz = box.nz;
   const int bricks_x = (nx + kBrickX - 1) >> 3;
@@ -1334,11 +1381,11 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   if (simple) {
     hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
-                       L.classify_stream_stores, L.box_list_dev);
+                       L.classify_stream_stores, L.box_list_dev, L.visible_in);
   } else {
     hipLaunchKernelGGL(classify_kernel<false>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
-                       L.classify_stream_stores, L.box_list_dev);
+                       L.classify_stream_stores, L.box_list_dev, L.visible_in);
   }
   return check_launch("classify_kernel");
 }
@@ -1374,7 +1421,7 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
                      tiles_y,                                                                    \
                      L.items_dev,                                                                \
                      L.out_layers, L.samples_out, L.counters, L.pos_begin,                       \
-                     (L.pos_end < 0 ? L.n_order : L.pos_end), L.resume)
+                     (L.pos_end < 0 ? L.n_order : L.pos_end), L.resume, L.visible_out)
   if (L.only_mode == kPow2Multiply) {
     if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
   } else if (L.only_mode == kReciprocal) {

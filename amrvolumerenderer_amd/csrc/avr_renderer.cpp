@@ -220,6 +220,17 @@ struct avr_renderer {
   // frame_chunks -1 / 1 = one launch per kernel (default), k > 1 = every frame in k chunks.
   int frame_chunks = -1;
   int balance = -1;  // avr_renderer_set_corun_balance: 0 = always the full search
+  // Occlusion culling between depth-ordered chunks (avr_render_plan_culled; one rank): k >= 2 =
+  // every frame in k chunks on one stream, each classify launch leaving out the boxes no ray can
+  // still sample; -1 / 0 = never (the default).  Exact and tested, but not faster on the
+  // configurations measured (profiles/r5_opaque/): config-4 with the reference's default
+  // boxTransparency = 0 goes from 0.70 ms (pipelined pair of kernels) to 0.82 / 0.93 ms in 2 / 4
+  // chunks -- with this field and the default map a ray crosses one to two 128-cell boxes before
+  // its accumulator rounds to 1, so only half of the classify pass's work is culled (0.52 -> 0.26
+  // ms), while a march in four launches costs 0.66 ms instead of 0.38 (every launch walks every
+  // tile and evaluates the boxes behind it), on one stream with nothing beside it.
+  int occlusion_chunks = -1;
+  DeviceBuffer visible_flags[AVR_CLASSIFIED_SLOTS];
   hipEvent_t chunk_event[AVR_CLASSIFIED_SLOTS][AVR_MAX_FRAME_CHUNKS] = {};
   int last_chunks = 1;  // what the last frame did (avr_renderer_corun_state / diagnostics)
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
@@ -260,7 +271,8 @@ struct avr_renderer {
       // Everything on the device is leaked; the process is expected to report the error and exit.
       forget_plans();
       for (DeviceBuffer* buffer : {&send[0], &send[1], &send[2], &recv, &piece, &piece_rgb8, &piece_rgb8_odd,
-                                   &full_rgb8, &full_image, &assembled_image, &small_image}) {
+                                   &full_rgb8, &full_image, &assembled_image, &small_image,
+                                   &visible_flags[0], &visible_flags[1], &visible_flags[2]}) {
         buffer->ptr = nullptr;  // (hipFree waits for the device)
       }
       return;
@@ -691,6 +703,16 @@ int avr_renderer_set_frame_chunks(avr_renderer* r, int chunks) {
   });
 }
 
+int avr_renderer_set_occlusion_culling(avr_renderer* r, int chunks) {
+  return guarded_renderer(r, [&]() -> int {
+    require(chunks == -1 || chunks == 0 || (chunks >= 2 && chunks <= AVR_MAX_FRAME_CHUNKS),
+            "chunks must be -1, 0 or in [2, AVR_MAX_FRAME_CHUNKS]");
+    r->drain_all();
+    r->occlusion_chunks = chunks;
+    return AVR_OK;
+  });
+}
+
 int avr_renderer_set_corun_balance(avr_renderer* r, int mode) {
   return guarded_renderer(r, [&]() -> int {
     require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
@@ -985,6 +1007,17 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     auto bytes_of = [](int64_t count, int each) {
       return static_cast<size_t>(std::max<int64_t>(count, 1)) * static_cast<size_t>(each);
     };
+    // ---- occlusion culling (one rank): the frame in depth-ordered chunks on ONE stream, every
+    // chunk's classify launch leaving out the boxes its predecessors' marches found hidden
+    int cull = 0;
+    if (!many && !r->cache_classification && info.n_local_runs > 0 && info.n_local_boxes >= 8) {
+      cull = std::min(std::max(r->occlusion_chunks, 0), info.n_local_boxes);
+    }
+    uint8_t* visibility = nullptr;
+    if (cull >= 2) {
+      visibility = static_cast<uint8_t*>(r->visible_flags[slot].reserve(
+          bytes_of(static_cast<int64_t>(cull) * info.n_local_boxes, 1), drain));
+    }
     float* send = static_cast<float*>(r->send[slot].reserve(bytes_of(info.send_floats, 4), drain));
     float* recv = many ? static_cast<float*>(r->recv.reserve(bytes_of(info.recv_floats, 4), drain))
                        : nullptr;
@@ -1074,6 +1107,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
           last = (first == CoRunTuner::kBackToBack) ? 0 : first;
         }
       }
+      if (cull >= 2) first = last = CoRunTuner::kBackToBack;  // (one stream: nothing to place)
       tuner.restrict_to(first, last, r->n_ranks == 1);
       // one rank with nothing fixed: the balance of the two kernels is read off their durations
       tuner.set_balance(r->n_ranks == 1 && r->balance != 0);
@@ -1250,7 +1284,9 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     if (r->timing) hip_ok(hipEventRecord(timed.classify_begin, stream_c), "hipEventRecord");
     if (probe != nullptr) hip_ok(hipEventRecord(probe->events.classify_begin, stream_c), "hipEventRecord");
-    if (n_chunks > 1) {
+    if (cull >= 2) {
+      // (classified chunk by chunk between the march launches, below)
+    } else if (n_chunks > 1) {
       abi_ok(avr_classify_plan_chunked(classify_ctx, r->scene, plan, volume, n_chunks, chunk_events,
                                        was_idle ? 1 : 0));
     } else {
@@ -1276,7 +1312,10 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     if (r->timing) hip_ok(hipEventRecord(timed.march_begin, stream_m), "hipEventRecord");
     if (probe != nullptr) hip_ok(hipEventRecord(probe->events.march_begin, stream_m), "hipEventRecord");
-    if (n_chunks > 1) {
+    if (cull >= 2) {
+      abi_ok(avr_render_plan_culled(march_ctx, r->scene, plan, volume, send, samples_out, cull, visibility));
+      r->last_chunks = cull;
+    } else if (n_chunks > 1) {
       abi_ok(avr_march_plan_chunked(march_ctx, r->scene, plan, volume, send, samples_out, n_chunks,
                                     chunk_events));
     } else {

@@ -516,6 +516,26 @@ class Scene:
             handles))
         return out
 
+    def render_plan_culled(self, ctx: "Context", plan, slot: int, out: torch.Tensor, n_chunks: int,
+                           samples: Optional[torch.Tensor] = None,
+                           visibility: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_render_plan_culled: the frame in n_chunks depth-ordered chunks, boxes no ray can
+        still sample left out of the classify pass.  Returns the visibility flags (uint8,
+        [n_chunks, n_local_boxes]: row k = what march k found visible behind chunk k)."""
+        ctx._check_tensor(out, torch.float32, "out")
+        if out.numel() < plan.send_floats:
+            raise ValueError("send buffer is too small")
+        if samples is not None:
+            ctx._check_tensor(samples, torch.int64, "samples")
+        n = max(len(self.boxes), 1)
+        if visibility is None:
+            visibility = torch.empty((n_chunks, n), dtype=torch.uint8, device=ctx.device)
+        _capi.check(_capi.lib().avr_render_plan_culled(
+            ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(out.data_ptr()),
+            C.c_void_p(samples.data_ptr()) if samples is not None else None, int(n_chunks),
+            C.c_void_p(visibility.data_ptr())))
+        return visibility
+
     def render_plan(self, plan, out: Optional[torch.Tensor] = None,
                     samples: Optional[torch.Tensor] = None,
                     sync_streams: bool = True) -> torch.Tensor:
@@ -818,6 +838,12 @@ class NativeRenderer:
         frame classified and marched in k depth-ordered chunks (measured not to pay:
         profiles/r5_latency/)."""
         _capi.check(_capi.lib().avr_renderer_set_frame_chunks(self._handle, int(chunks)))
+
+    def set_occlusion_culling(self, chunks: int = -1) -> None:
+        """avr_renderer_set_occlusion_culling: k >= 2 every frame in k depth-ordered chunks whose
+        classify launches leave out the boxes no ray can still sample; -1 / 0 never (default:
+        exact but not faster, profiles/r5_opaque/)."""
+        _capi.check(_capi.lib().avr_renderer_set_occlusion_culling(self._handle, int(chunks)))
 
     def set_corun_balance(self, mode: int = -1) -> None:
         """avr_renderer_set_corun_balance: -1 / 1 one rank balances its two kernels by their

@@ -76,6 +76,9 @@ def parse_args():
                     help="test hook: this rank stops rendering after the settling frames and sleeps "
                          "(a peer that hangs): the others must run into AVR_FRAME_TIMEOUT_MS, say "
                          "where, and the launch must end non-zero")
+    ap.add_argument("--occlusion-culling", type=int, default=-1,
+                    help="avr_renderer_set_occlusion_culling: -1 / 0 off (the driver's default), "
+                         "k >= 2: every frame in k culled chunks")
     ap.add_argument("--corun-full-search", action="store_true",
                     help="A/B only: one rank times every candidate of the co-run search (rounds 2-4) "
                          "instead of balancing the two kernels by their durations "
@@ -482,6 +485,8 @@ def run(args, state):
                              stream_priorities=tuple(int(v) for v in args.priorities.split(",")),
                              cache_classification=args.cache_classification)
     state["renderer"] = renderer
+    if renderer.native is not None and args.occlusion_culling >= 0:
+        renderer.native.set_occlusion_culling(args.occlusion_culling)
     if renderer.native is not None and args.corun_full_search:
         renderer.native.set_corun_balance(0)
     if renderer.native is not None and args.no_coordination:

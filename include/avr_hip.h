@@ -381,6 +381,20 @@ int avr_march_plan_chunked(avr_context *ctx, const avr_scene *scene, const avr_f
                            int slot, float *send_buffer, uint64_t *samples_out, int n_chunks,
                            void *const *chunk_events);
 
+/* The same frame with OCCLUSION CULLING between its chunks, one call: classify 0, march 0,
+ * classify 1, march 1 ... on the context's stream.  The march skips a box at every pixel whose run
+ * accumulator is opaque and in front of the box (the blend would return the accumulator unchanged:
+ * the reference's early exit `accumA < 1`, VolumePainter.cpp:837, carried from box to box); the
+ * march launch of chunk k evaluates that same test for every box behind it and flags the boxes
+ * some ray may still sample (visibility: device, n_chunks * n_local_boxes bytes of scratch), and
+ * the classify launch of chunk k + 1 leaves out the others -- their f64 cells are not even read.
+ * With the reference's default boxTransparency = 0 most rays saturate in the first boxes, and a
+ * frame reads a fraction of its cells.  Results equal avr_render_plan's bit for bit: a box is left
+ * out only where the march provably never reads it (proof with the kernel, avr_kernels.hip). */
+int avr_render_plan_culled(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                           int slot, float *send_buffer, uint64_t *samples_out, int n_chunks,
+                           uint8_t *visibility);
+
 /* Receiver side of composeLayered (DirectSendBase.cpp:400-446) for this rank's piece: folds
  * the runs in global order from the received buffer (recv_floats floats; with one rank the send
  * buffer itself) into out_piece[(piece_end - piece_begin) * 5]; pixels no run covers become the
@@ -696,6 +710,12 @@ int avr_renderer_set_deferred_gather(avr_renderer *renderer, int mode);
  * (VolumeRenderer/VolumeRenderer.cpp:1103-1339) -- and measured not to on this GPU
  * (profiles/r5_latency/), hence off by default.  Scheduling only: never changes results. */
 int avr_renderer_set_frame_chunks(avr_renderer *renderer, int chunks);
+/* Occlusion culling (avr_render_plan_culled; one rank).  k in [2, AVR_MAX_FRAME_CHUNKS]: every
+ * frame is classified and marched in k depth-ordered chunks on one stream, each classify launch
+ * leaving out the boxes no ray can still sample (the reference's default boxTransparency = 0,
+ * VolumeRenderer.hpp:36, saturates rays early).  -1 / 0 (default): never -- exact, but measured
+ * not to pay on the configurations of BASELINE.json (profiles/r5_opaque/).  Never changes results. */
+int avr_renderer_set_occlusion_culling(avr_renderer *renderer, int chunks);
 int avr_renderer_last_frame_chunks(const avr_renderer *renderer); /* what the last frame took */
 int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
 /* One rank (default -1 = on): instead of timing every candidate of the co-run search, the driver

@@ -89,9 +89,10 @@ def test_profiled_traffic_is_only_quoted_for_the_kernels_it_was_measured_on(tmp_
     makes the line say "stale" instead of quoting the old bytes."""
     bench = load_bench()
     args = types.SimpleNamespace(config="config4", field="smooth", transparency=0.97, width=0,
-                                 height=0, antialiasing=1, orbit=0, fly_through=False)
-    summary = tmp_path / "pmc_summary.txt"
-    monkeypatch.setattr(bench, "PMC_SUMMARY", str(summary))
+                                 height=0, antialiasing=1, orbit=0, fly_through=False,
+                                 cache_classification=False)
+    monkeypatch.setattr(bench, "PMC_DIR", str(tmp_path))
+    summary = tmp_path / "pmc_config4_translucent.txt"
     body = ("classify_kernel\n  FETCH_SIZE    n=5 mean=1000\n  WRITE_SIZE    n=5 mean=100\n"
             "render_runs_kernel\n  FETCH_SIZE    n=5 mean=200\n  WRITE_SIZE    n=5 mean=30\n")
     assert bench.profiled_traffic(args, 1)[0] is None              # no summary at all
@@ -103,5 +104,15 @@ def test_profiled_traffic_is_only_quoted_for_the_kernels_it_was_measured_on(tmp_
     assert traffic is None and source.startswith("stale")
     summary.write_text(body)                                       # a summary without a digest
     assert bench.profiled_traffic(args, 1)[0] is None
-    args.config = "config2"                                        # not the profiled workload
+    # every workload the sheet quotes has a summary of its own, found by its key
+    assert bench.workload_key(args, 1) == "config4_translucent"
+    args.transparency = 0.0
+    assert bench.workload_key(args, 1) == "config4_opaque"
+    args.config, args.transparency = "config2", 0.97
+    assert bench.workload_key(args, 1) == "config2_translucent"
+    assert bench.profiled_traffic(args, 1)[0] is None              # (none written for it here)
+    args.config, args.antialiasing = "config5", 4
+    assert bench.workload_key(args, 1) == "config5_translucent"
+    args.orbit = 16                                                # not a profiled workload
     assert bench.profiled_traffic(args, 1) == (None, None)
+    assert bench.workload_key(args, 2) is None

@@ -144,3 +144,53 @@ def test_frames_of_a_caller_who_waits_equal_pipelined_frames(ctx, transparency):
         w_image, w_rgb8 = want[f % len(cams)]
         assert torch.equal(image.view(torch.int32), w_image.view(torch.int32)), f
         assert torch.equal(rgb8, w_rgb8), f
+
+
+@pytest.mark.parametrize("n_ranks,policy,transparency", [
+    (1, "morton", 0.0), (1, "morton", 0.3), (1, "morton", 0.97), (3, "round_robin", 0.0),
+    (4, "level_pairs", 0.1)])
+def test_culled_frame_equals_the_single_launch(ctx, n_ranks, policy, transparency):
+    """avr_render_plan_culled: boxes that no ray can still sample are left out of the classify pass
+    -- decided by the march's own skip test, so the run layers and the sample count are the
+    single-launch frame's bit for bit; an opaque transfer function really leaves boxes out, and a
+    box that is left out is one the march never reads (its bricklets are poisoned here)."""
+    W, H = 190, 140
+    spec = scenes.make_amr_scene(64, 3, 16, "smooth")
+    cells = [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+    scenes.assign_owners(spec, n_ranks, policy)
+    meta = [scenes.metadata_box(spec, i) for i in range(len(spec.boxes))]
+    ref = runtime.reference_sample_distance(meta, spec.bounds.min_corner, spec.bounds.max_corner)
+    params = make_params(W, H, spec.scalar_range, transparency, ref, spec.bounds)
+    culled_somewhere = False
+    for view in (0, 5, 11):
+        cam = scenes.orbit_camera(view, 16)
+        for r in range(n_ranks):
+            plan = FramePlan(meta, params, cam, r, n_ranks)
+            scene = _local_scene(ctx, spec, cells, r)
+            n = max(plan.send_floats, 1)
+            want = torch.full((n,), float("nan"), device=ctx.device)
+            want_samples = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+            scene.classify_plan(ctx, plan, 0)
+            scene.march_plan(ctx, plan, 0, want, want_samples)
+            ctx.synchronize()
+            for chunks in (2, 4, 9):
+                # classified volume 1 first holds OTHER table indices for every cell (the same
+                # scene under another scalar range): whatever the culled frame does not classify
+                # stays wrong, and a march that read it would show
+                other = FramePlan(meta, make_params(W, H, (0.2, 0.6), 0.5, ref, spec.bounds),
+                                  scenes.orbit_camera(view + 3, 16), r, n_ranks)
+                scratch = torch.empty(max(other.send_floats, 1), device=ctx.device)
+                scene.classify_plan(ctx, other, 1)
+                got = torch.full((n,), float("nan"), device=ctx.device)
+                got_samples = torch.zeros(1, dtype=torch.int64, device=ctx.device)
+                flags = scene.render_plan_culled(ctx, plan, 1, got, chunks, got_samples)
+                ctx.synchronize()
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (view, r, chunks)
+                assert int(got_samples.item()) == int(want_samples.item()), (view, r, chunks)
+                # (row k: boxes behind chunk k still visible; the last row is never written)
+                visible = flags[:chunks - 1].cpu().numpy()
+                if visible.shape[1] and (visible[-1] == 0).any() and plan.n_local_runs > 0:
+                    culled_somewhere = True
+                del scratch
+    if transparency == 0.0:
+        assert culled_somewhere, "an opaque frame left no box out"
