@@ -81,10 +81,6 @@ __device__ __forceinline__ int table_index(double raw, const FrameConsts& fc) {
 // where the reference's int cast truncates: tools/ubench/cvt_pk_u8.hip.)
 template <bool SIMPLE>
 __device__ __forceinline__ uint32_t table_index_pair(double a, double b, const FrameConsts& fc) {
-#if defined(AVR_EXP_CLASSIFY_NO_MATH)  // experiment: the pass's memory traffic without its VALU
-  return (static_cast<uint32_t>(__double2loint(a)) ^ static_cast<uint32_t>(__double2hiint(b))) &
-         0xffffu;
-#endif
   if (SIMPLE) {
     const float at_zero =
         __builtin_amdgcn_fmed3f(static_cast<float>((0.0 - fc.norm_min) * fc.inv_norm_span), 0.0f,

@@ -148,3 +148,42 @@ def test_ranks_in_different_control_rounds_are_told_apart(avr_lib):
     assert all(kind == "error" and "the ranks' calls differ" in text for kind, text in got), got
     for c in comms:
         avr_lib.avr_comm_destroy(c)
+
+
+def test_a_callers_allgather_that_hangs_ends_at_the_deadline(avr_lib):
+    """avr_comm_set_control: the caller's own allgather (MPI in the reference's host, gloo in
+    bench.py) runs under the deadline of every other wait of a frame -- a peer that never arrives
+    inside THAT collective must not leave the rank waiting for as long as the caller's library does
+    (gloo: 30 minutes).  The callback is run on a helper thread over copies of the buffers; past the
+    deadline the call returns the error (and the helper is left behind)."""
+    comms = local_comms(avr_lib, 2)
+    release = threading.Event()
+    calls = []
+
+    @_capi.CONTROL_ALLGATHER_FN
+    def allgather(_user, mine, out, size):
+        calls.append(size)
+        if len(calls) == 1:   # the first round works: every rank "says" what this one says
+            C.memmove(out, mine, size)
+            C.memmove(out + size, mine, size)
+            return 0
+        release.wait(20)       # the second one hangs (a peer died inside the collective)
+        return 0
+
+    _capi.check(avr_lib.avr_comm_set_control(comms[0], allgather, None))
+    everybody = C.create_string_buffer(16)
+    _capi.check(avr_lib.avr_comm_control_allgather(comms[0], None, b"12345678", everybody, 8))
+    assert everybody.raw == b"1234567812345678"
+    _capi.check(avr_lib.avr_set_frame_timeout_ms(300))
+    try:
+        begin = time.monotonic()
+        with pytest.raises(_capi.AvrError) as failure:
+            _capi.check(avr_lib.avr_comm_control_allgather(comms[0], None, b"12345678", everybody, 8))
+        assert "AVR_FRAME_TIMEOUT_MS" in str(failure.value) and "caller's allgather" in str(failure.value)
+        assert 0.25 < time.monotonic() - begin < 3.0
+    finally:
+        release.set()          # (lets the helper thread go before the callback object dies)
+        time.sleep(0.2)
+        _capi.check(avr_lib.avr_set_frame_timeout_ms(-1))
+        for c in comms:
+            avr_lib.avr_comm_destroy(c)
