@@ -361,13 +361,21 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
       // (r, g) += (s.x, s.y) * w;  (b, a) += (s.z * w, w)  -- six instructions, each half the
       // reference's own operation.
       float_pair rg = {acc_r, acc_g}, ba = {acc_b, acc_a};
+      // (the weight w is the HIGH half of the pair (z * w, w) that is added to (b, a); the packed
+      // multiply of (x, y) takes it from there -- op_sel: both halves of the second operand read
+      // its high half -- instead of from a copy in the low half of another register pair: one
+      // v_mov_b32 per sample less, 4 % of the march's vector instructions)
 #define AVR_STEP(sample)                                                          \
       {                                                                           \
         const float w_ = (sample).w * (1.0f - ba.y);                              \
         const float_pair color_ = {(sample).x, (sample).y};                       \
         const float_pair zw_ = {(sample).z * w_, w_};                             \
+        float_pair weighted_;                                                     \
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]"                \
+            : "=v"(weighted_)                                                     \
+            : "v"(color_), "v"(zw_));                                             \
         ba = ba + zw_;                                                            \
-        rg = rg + color_ * w_;                                                    \
+        rg = rg + weighted_;                                                      \
         asm volatile("" : "+v"(rg));                                              \
       }
       AVR_STEP(s1)
