@@ -704,6 +704,15 @@ class FrameDriver {
     check(avr_renderer_prepare(renderer_, &params, &camera, group_order));
   }
   void synchronize() { check(avr_renderer_synchronize(renderer_)); }
+  // How many of the frames rendered so far have their outputs written once the compositing stream
+  // has passed what is queued now (ranks of several: the last frame's bytes travel with the next
+  // frame's round, avr_renderer_set_deferred_gather) -- for a caller that orders its own stream
+  // after avr_renderer_stream(get(), 2) instead of calling the collective synchronize().
+  uint64_t outputs_complete() const {
+    uint64_t complete = 0;
+    check(avr_renderer_outputs_complete(renderer_, &complete, nullptr));
+    return complete;
+  }
   // NULL, or what did not finish within the deadline (avr_set_frame_timeout_ms): the renderer is
   // then failed for good -- report it (MPI_Abort in the reference's main, main.cpp:27-33) and exit.
   const char* failure() const { return avr_renderer_failure(renderer_); }
