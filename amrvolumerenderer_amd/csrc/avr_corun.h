@@ -51,16 +51,14 @@ struct CoRunTuner {
   // winner.  (No early exit: over the reserve the period is flat, dips and rises again, and for
   // the short kernels of an N-rank share the dip lies at the far end -- a search that stopped
   // on the flat stretch missed it.)
-  // kBalance (round 5, one rank's side-by-side frames): not a search at all.  Side by side the two
-  // kernels trade one resource linearly (profiles/r5_corun_gap/: c + m = 1.34 in solo-speed units on
-  // every reserve), so the frame is shortest where they take equally long, and which of them is the
-  // longer one is read off any single frame -- each kernel's own duration, timed by two events on its
-  // stream, responds to a new reserve at once, where the PERIOD only shows it after the classify
-  // stream's lead of two frames has run out (what the finalists' 40 settling frames are for).  The
-  // classify pass's duration rises and the march's falls with the reserve: a bisection over the 29
-  // reserves, kBalanceSettle + kBalanceFrames frames per step, five or six steps and the last two reserves once more -- some 85
-  // frames instead of 640 -- then straight to kHold, whose re-timing still falls back to the full search
-  // (kSearch) if the held candidate's period drifts.
+  // kBalance (round 5, one rank's side-by-side frames): decided on the two kernels' own DURATIONS,
+  // not on timed windows of the frame's period.  Each kernel is timed by two events on its stream;
+  // a duration answers a new reserve within a few frames, where the period only shows it after the
+  // classify stream's lead of two frames has run out (what the full search's 40 settling frames
+  // per finalist are for); the frame's period is the longer of the two streams' (kernel + what lies
+  // between two kernels of the stream).  A bisection, then five finalists (below): ~90 frames
+  // instead of 600-1500, then kHold, whose re-timing falls back to the full search (kSearch) if the
+  // held reserve's period drifts.
   enum Phase { kSearch, kRefine, kVerify, kHold, kBalance } phase = kSearch;
   int first = kBackToBack, last = kLastCandidate;  // the candidates the caller allows
   int candidate = kBackToBack;
@@ -109,17 +107,34 @@ struct CoRunTuner {
   }
 
   // ---- kBalance -------------------------------------------------------------------------------
-  static constexpr int kBalanceSettle = 3;   // reports ignored after a change of reserve
-  static constexpr int kBalanceFrames = 4;   // reports averaged per reserve
+  // Two stages.  (1) A bisection over the 29 reserves on WHICH stream's period is the longer one:
+  // the classify pass's duration rises and the march's falls with the reserve, and away from the
+  // balance the sign is robust -- also against the pipeline's memory of the reserve before (after a
+  // jump across the scale the classify stream, which runs up to two frames ahead, takes tens of
+  // frames to settle: comparing reserves by their timed COST across such jumps was tried and holds
+  // the wrong one five times out of six).  (2) What a CU admits is a packing of both kernels'
+  // workgroups into its LDS, wave slots and registers, so near the balance the period is a
+  // staircase with pockets (config-4: 24 KiB 0.965 / 0.965 ms, 26 KiB 1.02 / 1.09 -- both kernels
+  // slower -- 28 KiB 1.03 / 0.98) and the bisection closes a step or two beside the best reserve
+  // every third time -- above it, as a rule, and also when the seed, timed right after start-up
+  // with both kernels still 10-15 % long, sent it the wrong way.  So the five reserves from two
+  // below the closed bracket to one above it are then timed afresh in ascending order (neighbours:
+  // small jumps) and the one with the shortest period is held.
+  static constexpr int kBalanceSettle = 2;      // reports ignored after a change of reserve (bisection)
+  static constexpr int kBalanceStepFrames = 2;  // reports averaged per step of the bisection
+  static constexpr int kFinalistSettle = 3;     // ... ignored / averaged per finalist
+  static constexpr int kFinalistFrames = 4;
+  static constexpr int kFirstFinalistSettle = 6;  // (the first one follows a jump across the bracket)
   static constexpr int kBalanceSeed = 12;    // 24 KiB: where config-4's one-rank frame balances
-  static constexpr float kClassifyGapMs = 0.014f, kMarchGapMs = 0.028f;  // between two kernels of a stream
   static constexpr float kBalanceMinMs = 0.35f;  // shorter frames take the full search (the paired
                                                  // layout and back to back are candidates there)
+  static constexpr float kClassifyGapMs = 0.014f, kMarchGapMs = 0.028f;  // between two kernels of a stream
   bool balance_allowed = false;  // set_balance(): one rank, nothing fixed by the caller
   bool balance_failed = false;   // this renderer's frames are too short for it: full search
   int b_lo = 0, b_hi = 0;        // the reserve where both take equally long lies in [b_lo, b_hi]
-  float b_ms[kLastCandidate + 1] = {};  // max(classify, march) measured at a reserve (0: not yet)
-  bool b_final = false;                 // the bracket has closed: its two ends are being re-timed
+  bool b_final = false;          // the bracket has closed: the finalists are being timed
+  int finalists[5] = {0, 0, 0, 0, 0}, n_finalists = 0, b_final_at = 0;
+  float finalist_ms[5] = {0, 0, 0, 0, 0};
   int b_reports = 0;
   float b_classify = 0.0f, b_march = 0.0f;
   void set_balance(bool allowed) {
@@ -128,71 +143,78 @@ struct CoRunTuner {
     restart();
   }
   bool balancing() const { return phase == kBalance; }
+  void begin_balance_step(int next) {
+    candidate = next;
+    b_reports = 0;
+    b_classify = b_march = 0.0f;
+  }
   // One frame's kernel durations (events on the two streams), in frame order, with the candidate
   // the frame was queued under; frames of an older candidate are still in flight after a change.
   void report_durations(int frame_candidate, float classify_ms, float march_ms) {
     if (phase != kBalance || frame_candidate != candidate) return;
-    if (++b_reports <= kBalanceSettle) return;
+    const int settle = !b_final ? kBalanceSettle : (b_final_at == 0 ? kFirstFinalistSettle : kFinalistSettle);
+    const int frames = b_final ? kFinalistFrames : kBalanceStepFrames;
+    if (++b_reports <= settle) return;
     b_classify += classify_ms;
     b_march += march_ms;
-    if (b_reports < kBalanceSettle + kBalanceFrames) return;
+    if (b_reports < settle + frames) return;
     // Each stream's period is its kernel plus what lies between two of its kernels: the classify
     // stream runs its passes back to back (14 us), a march also waits for its classify pass's
     // event on the other stream and for its descriptors (28 us) -- measured: config-2 at 51200
     // 0.3643 / 0.3658 ms -> period 0.394, at 53248 0.367 / 0.350 -> 0.381; config-3 at 36864
     // 0.4627 / 0.4616 -> 0.488, at 38912 0.4714 / 0.4486 -> 0.487; config-4 at 24576 0.983 / 0.975
     // -> 1.002.  The frame's period is the longer of the two.
-    const float classify = b_classify / kBalanceFrames + kClassifyGapMs;
-    const float march = b_march / kBalanceFrames + kMarchGapMs;
+    const float classify = b_classify / static_cast<float>(frames) + kClassifyGapMs;
+    const float march = b_march / static_cast<float>(frames) + kMarchGapMs;
     const float longer = std::max(classify, march);
     ++windows;
     last_period_ms = longer;
     static const bool trace = std::getenv("AVR_CORUN_TRACE") != nullptr;
     if (trace) {
-      std::fprintf(stderr, "corun: balance candidate %d classify %.4f march %.4f ms (with the streams' gaps) [%d, %d]\n",
-                   candidate, classify, march, b_lo, b_hi);
+      std::fprintf(stderr, "corun: balance candidate %d classify %.4f march %.4f ms (with the streams' gaps) [%d, %d]%s\n",
+                   candidate, classify, march, b_lo, b_hi, b_final ? " finalist" : "");
     }
     if (longer < kBalanceMinMs) {  // short frames: the layouts themselves are in question
       balance_failed = true;
       restart();
       return;
     }
-    b_ms[candidate] = longer;
-    if (candidate != b_lo && candidate != b_hi) {  // (an end of the bracket is only measured)
-      if (classify < march) {  // the march is the longer one: hold the classify pass back further
-        b_lo = candidate;
-      } else {
-        b_hi = candidate;
+    if (b_final) {
+      finalist_ms[b_final_at] = longer;
+      if (++b_final_at < n_finalists) {
+        begin_balance_step(finalists[b_final_at]);
+        return;
       }
-    }
-    if (b_hi - b_lo <= 1) {
-      // The two reserves left are timed afresh, one after the other, before one of them is held:
-      // the bracket's older end was measured steps ago -- the seed right after start-up, when both
-      // kernels still read 10-15 % long -- and the reserve next to the best one is 3-4 % slower.
-      if (!b_final) {
-        b_final = true;
-        b_ms[b_lo] = b_ms[b_hi] = 0.0f;
+      int chosen = 0;
+      for (int i = 1; i < n_finalists; ++i) {
+        if (finalist_ms[i] < finalist_ms[chosen]) chosen = i;
       }
-      // (an end never measured before is the scale's end: the balance lies beyond it)
-      if (b_ms[b_lo] == 0.0f) {
-        begin_balance_step(b_lo);
-      } else if (b_ms[b_hi] == 0.0f) {
-        begin_balance_step(b_hi);
-      } else {
-        best = candidate = (b_ms[b_hi] < b_ms[b_lo]) ? b_hi : b_lo;
-        best_beside = best;
-        best_ms = 0.0f;  // (a period, not a duration: the first window of the hold sets it)
-        phase = kHold;
-        interrupt();
-      }
+      best = candidate = finalists[chosen];
+      best_beside = best;
+      best_ms = 0.0f;  // (a period, not a duration: the first window of the hold sets it)
+      phase = kHold;
+      interrupt();
       return;
     }
-    begin_balance_step((b_lo + b_hi) / 2);
-  }
-  void begin_balance_step(int next) {
-    candidate = next;
-    b_reports = 0;
-    b_classify = b_march = 0.0f;
+    if (classify < march) {  // the march's stream is the longer one: hold the classify pass back further
+      b_lo = candidate;
+    } else {
+      b_hi = candidate;
+    }
+    // (an end of the scale that every step pointed beyond is where the bracket closes)
+    const int next = (b_lo + b_hi) / 2;
+    if (b_hi - b_lo > 1 || (b_hi - b_lo == 1 && ((b_lo == 0 && candidate != 0) ||
+                                                 (b_hi == kLastCandidate && candidate != kLastCandidate)))) {
+      begin_balance_step(b_hi - b_lo > 1 ? next : (b_lo == 0 ? 0 : kLastCandidate));
+      return;
+    }
+    b_final = true;
+    b_final_at = 0;
+    n_finalists = 0;
+    for (int c = b_lo - 2; c <= b_hi + 1; ++c) {
+      if (c >= 0 && c <= kLastCandidate && n_finalists < 5) finalists[n_finalists++] = c;
+    }
+    begin_balance_step(finalists[0]);
   }
 
   // Where the search starts is what a caller keeps who never renders enough frames back to back
@@ -218,7 +240,6 @@ struct CoRunTuner {
       phase = kBalance;
       b_lo = 0;
       b_hi = kLastCandidate;
-      for (float& ms : b_ms) ms = 0.0f;
       b_final = false;
       begin_balance_step(kBalanceSeed);
       best = candidate;

@@ -805,8 +805,48 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
   // 16-byte loads (two cells per lane) need every row to start 16-byte aligned
   const bool paired = ((reinterpret_cast<uintptr_t>(box.cells) & 15u) == 0) &&
                       ((jstride & 1u) == 0) && ((kstride & 1u) == 0) && jstride < (1u << 27);
-  if (paired && nx >= 2) {
-    typedef double double2_t __attribute__((ext_vector_type(2)));
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+  // ---- the tile that lies wholly inside its box (nearly all of them: every tile of a box whose
+  // sides are multiples of 128 x 4 x 4 cells): no lane or plane is masked, so the pass is straight
+  // line code -- per pair of cells two f64 subtractions and multiplications, two conversions, two
+  // scalings, two truncations, one pack, and ONE wave-wide test for a non-finite cell instead of a
+  // select per cell (the vector instructions of this pass are a fifth of the frame's, and the
+  // frame is bound by their issue: DESIGN.md section 4).
+  const bool whole_tile = SIMPLE && paired && (chunk + 1) * kClassifyChunk <= nx &&
+                          (bj + 1) * kBrickY <= ny && (bk + 1) * kBrickZ <= nz;
+  if (whole_tile) {
+    const int jj = t >> 6;
+    const int xi = (t & 63) * 2;
+    const uint32_t lane_bytes = (static_cast<uint32_t>(chunk * kClassifyChunk + xi) +
+                                 static_cast<uint32_t>(bj * kBrickY + jj) * jstride) * 8u;
+    const __amdgpu_buffer_rsrc_t resource = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(box.cells), 0, 0x7fffffff, kRawBufferFlags);
+    double2_t raw[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const uint32_t plane_bytes = static_cast<uint32_t>(bk * kBrickZ + pass) * kstride * 8u;
+      raw[pass] = __builtin_bit_cast(
+          double2_t, __builtin_amdgcn_raw_buffer_load_b128(resource, lane_bytes, plane_bytes, kStreamingLoad));
+    }
+    char* const staged_at = reinterpret_cast<char*>(staged) + (xi >> 3) * (kStagedStride * 4) + jj * 8 + (xi & 7);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const double a = raw[pass].x, b = raw[pass].y;
+      float sa = __builtin_amdgcn_fmed3f(static_cast<float>((a - fc.norm_min) * fc.inv_norm_span), 0.0f, 1.0f) * 255.0f;
+      float sb = __builtin_amdgcn_fmed3f(static_cast<float>((b - fc.norm_min) * fc.inv_norm_span), 0.0f, 1.0f) * 255.0f;
+      // sanitizeScalarSample (VolumeTypes.hpp:33-38): a non-finite cell counts as 0.0 -- rare, so
+      // tested for the whole wave at once
+      const bool odd = !__builtin_isfinite(a) || !__builtin_isfinite(b);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
+        const float at_zero =
+            __builtin_amdgcn_fmed3f(static_cast<float>((0.0 - fc.norm_min) * fc.inv_norm_span), 0.0f, 1.0f) * 255.0f;
+        sa = __builtin_isfinite(a) ? sa : at_zero;
+        sb = __builtin_isfinite(b) ? sb : at_zero;
+      }
+      const uint32_t two = static_cast<uint32_t>(static_cast<int>(sa)) | (static_cast<uint32_t>(static_cast<int>(sb)) << 8);
+      *reinterpret_cast<uint16_t*>(staged_at + pass * 32) = static_cast<uint16_t>(two);
+    }
+  } else if (paired && nx >= 2) {
     // One j-row per wave, one k-plane per pass, two x-cells (one 16-byte load) per lane.  The
     // lane's byte offset inside the plane is the same in all four passes, so the addresses are a
     // wave-uniform base per pass plus one 32-bit lane offset (global_load ... saddr: no vector

@@ -721,7 +721,7 @@ int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
 /* One rank (default -1 = on): instead of timing every candidate of the co-run search, the driver
  * reads off each frame's two kernel durations which of the two is the longer one side by side and
  * bisects the LDS reserve to where they take equally long -- where the frame is shortest, because
- * the two trade one resource linearly (profiles/r5_corun_gap/) -- then holds it: some 85 frames
+ * the two trade one resource linearly (profiles/r5_corun_gap/) -- then holds it: some 100 frames
  * instead of 640.  Frames shorter than 0.35 ms, a held candidate that drifts, and mode 0 take the
  * full search.  Scheduling only. */
 int avr_renderer_set_corun_balance(avr_renderer *renderer, int mode);
