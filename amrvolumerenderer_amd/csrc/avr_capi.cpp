@@ -297,6 +297,7 @@ struct avr_context {
   avr::StagingRing staging;
   avr_scene scratch_scene;         // classified storage of avr_paint_box
   std::vector<avr::MarchItemDev> march_items;  // host scratch of render()
+  std::vector<int32_t> order_rects;            // ... (the boxes' screen rectangles in layer order)
   int priority = 0;                            // 1: own stream in the highest priority class
   int march_workgroups_per_cu = 0;             // 0 = uncapped
   uint32_t classify_lds_pad = 0;               // avr_context_set_classify_lds_reserve
@@ -489,6 +490,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
       plan.march_items_ready = keep_items;
     }
     bytes += plan.tables.size() * sizeof(float) + static_cast<size_t>(n_order + n_runs) * 4 +
+             static_cast<size_t>(n_order) * 16 +
              items.size() * sizeof(avr::MarchItemDev) +
              run_rects.size() * sizeof(avr::RunRectDev) + run_blocks.size() * sizeof(avr::RunBlockDev) +
              (run_spans != nullptr ? run_spans->size() * sizeof(avr::RunSpanDev) : 0);
@@ -520,7 +522,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     }
   }
   avr::StagingRing& staging = ctx->staging;
-  staging.begin(bytes, 11);
+  staging.begin(bytes, 12);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
   const uint32_t* chunk_tile_begin_dev = nullptr;
   const int32_t* chunk_box_list_dev = nullptr;
@@ -536,6 +538,16 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.tables_dev = staging.add(plan.tables.data(), plan.tables.size());
     launch.n_tables = plan.n_tables;
     launch.order_dev = staging.add(box_order, static_cast<size_t>(n_order));
+    {
+      // the boxes' screen rectangles in that order: what the march's cull reads 64 at a time
+      std::vector<int32_t>& rects = ctx->order_rects;
+      rects.resize(static_cast<size_t>(n_order) * 4);
+      for (int i = 0; i < n_order; ++i) {
+        const avr::BoxDev& dev = plan.boxes[static_cast<size_t>(box_order[i])];
+        std::copy(dev.rect, dev.rect + 4, rects.begin() + static_cast<std::ptrdiff_t>(i) * 4);
+      }
+      launch.order_rects_dev = staging.add(rects.data(), rects.size());
+    }
     launch.run_end_dev = staging.add(run_end, static_cast<size_t>(n_runs));
     launch.n_order = n_order;
     launch.n_runs = n_runs;

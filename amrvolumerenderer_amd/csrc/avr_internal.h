@@ -239,6 +239,7 @@ struct RenderLaunch {
   const float* tables_dev;      // n_tables * 1024 floats
   int n_tables;
   const int32_t* order_dev;     // box indices in global layer order
+  const int32_t* order_rects_dev;  // their conservative screen rectangles (x0, y0, x1, y1), same order
   const int32_t* run_end_dev;   // one-past-last position per run
   int n_order, n_runs, n_pieces;
   const RunRectDev* run_rects_dev;    // n_runs

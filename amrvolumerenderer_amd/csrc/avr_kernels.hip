@@ -485,7 +485,8 @@ __global__ __launch_bounds__(kBlockThreads, 6) void
 render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
-    const int n_tables, const int32_t* __restrict__ order, const int32_t* __restrict__ run_end,
+    const int n_tables, const int32_t* __restrict__ order, const int4* __restrict__ order_rects,
+    const int32_t* __restrict__ run_end,
     const int n_runs, const int n_pieces, const RunRectDev* __restrict__ run_rects,
     const RunBlockDev* __restrict__ run_blocks, const RunSpanDev* __restrict__ run_spans,
     const int band_shift,  // >= 0: pieces are bands of 2^band_shift rows dealt round-robin
@@ -589,10 +590,6 @@ render_runs_kernel(
     const int run_begin = (run > 0) ? run_end[run - 1] : 0;
     const int end = (run_end[run] < pos_end) ? run_end[run] : pos_end;
     Layer5 acc = {0.0f, 0.0f, 0.0f, 0.0f, AVR_INF};  // cleared layer pixel: exact blend identity
-    // (a resumed pixel that no box of this launch reaches is not stored again.  A per-lane COUNTER,
-    // not a flag: a flag lives in a scalar mask that every trip of the box loop, also the ones that
-    // only cull, would have to merge -- config-5's 1856 boxes per tile: + 15 % on the march.)
-    unsigned blended = 0;
     if (resume != 0) {
       const float* src = layer_pixel();
       if (src != nullptr) {
@@ -603,13 +600,24 @@ render_runs_kernel(
         acc.d = src[4];
       }
     }
-    for (int position = (run_begin > pos_begin) ? run_begin : pos_begin; position < end; ++position) {
-      const BoxDev& box = boxes[order[position]];
-      // wave-uniform cull against the box's conservative screen rectangle
-      if (box.rect[2] < wave_x0 || box.rect[0] > wave_x0 + (kWaveW - 1) || box.rect[3] < wave_y0 ||
-          box.rect[1] > wave_y0 + (kWaveH - 1)) {
-        continue;
+    // The boxes whose conservative screen rectangle misses the wave's 8 x 8 pixels are culled 64 at
+    // a time: lane l tests the rectangle of position base + l (one coalesced 16-byte load per lane
+    // from the rectangles in global layer order), a ballot leaves the candidates as a bit mask, and
+    // only those are visited, in order.  (One box per trip -- two dependent scalar loads, four
+    // compares and a branch for every box of the run, of which a tile meets a tenth -- was 10 % of
+    // config-4's march and most of config-5's, whose tiles see 1856 boxes.)
+    for (int base = (run_begin > pos_begin) ? run_begin : pos_begin; base < end; base += 64) {
+      bool candidate = false;
+      if (base + lane < end) {
+        const int4 r = order_rects[base + lane];
+        candidate = !(r.z < wave_x0 || r.x > wave_x0 + (kWaveW - 1) || r.w < wave_y0 ||
+                      r.y > wave_y0 + (kWaveH - 1));
       }
+      unsigned long long pending = __builtin_amdgcn_ballot_w64(candidate);
+      while (pending != 0) {
+      const int position = base + __builtin_ctzll(pending);
+      pending &= pending - 1;
+      const BoxDev& box = boxes[order[position]];
       float tmin = -AVR_INF;
       float tmax = AVR_INF;
       slab_axis(ray.ox, ray.dx, inv_dx, box.minc[0], box.maxc[0], tmin, tmax);
@@ -654,7 +662,7 @@ render_runs_kernel(
         }
         if (STATS) mode_fetches[mode] += fetches - before;
         acc = blend_depthsort(acc, layer);
-        blended += 1u;
+      }
       }
     }
     // ---- which of the boxes BEHIND this launch's can still be sampled ---------------------------
@@ -696,7 +704,10 @@ render_runs_kernel(
         if (__builtin_amdgcn_ballot_w64(visible) != 0 && lane == 0) visible_out[position] = 1;
       }
     }
-    if (resume == 0 || blended != 0u) {
+    // (a resumed launch stores every pixel again, reached or not: keeping "was it reached" per lane
+    // costs the register that decides between 7 and 6 waves per SIMD, and as a flag a scalar mask
+    // that every trip of the box loop merges -- config-5: + 15 % on the march)
+    {
       float* const dst = layer_pixel();
       if (STATS && counters != nullptr && dst == nullptr && acc.a != 0.0f && live && px >= rect.x0 &&
           px <= rect.x1 && py >= rect.y0 && py <= rect.y1) {
@@ -1467,7 +1478,8 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
 #define AVR_LAUNCH(STATS, ONLY)                                                                 \
   hipLaunchKernelGGL((render_runs_kernel<STATS, ONLY>), dim3(blocks), dim3(kBlockThreads),      \
                      lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,      \
-                     L.n_tables, L.order_dev, L.run_end_dev, L.n_runs, L.n_pieces,              \
+                     L.n_tables, L.order_dev, reinterpret_cast<const int4*>(L.order_rects_dev),  \
+                     L.run_end_dev, L.n_runs, L.n_pieces,                                        \
                      L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, band_shift, tiles_x,    \
                      tiles_y,                                                                    \
                      L.items_dev,                                                                \
