@@ -1209,8 +1209,11 @@ void run_gather(avr_context* ctx, avr_comm* comm, const avr_gather_op& op, bool 
           const size_t bytes = static_cast<size_t>(e - b) * static_cast<size_t>(bytes_per_pixel);
           if (s == me) {
             if (copy_own) {
+              // (a device-to-device hipMemcpy may return before it has run, and the context's
+              // stream is non-blocking: what follows on it would not wait for the null stream)
               avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, piece, bytes, hipMemcpyDeviceToDevice),
                           "hipMemcpy(gather)");
+              avr::hip_ok(hipStreamSynchronize(nullptr), "hipStreamSynchronize(gather)");
             }
           } else {
             avr::hip_ok(hipMemcpy(dst + b * bytes_per_pixel, world.region(s), bytes, hipMemcpyHostToDevice),

@@ -230,6 +230,10 @@ ncclResult_t ncclGroupEnd() {
       status = ncclUnhandledCudaError;
     }
   }
+  // (a device-to-device hipMemcpy may return before the copy has run, and the ranks' streams are
+  // non-blocking: they do not order themselves after the null stream it runs on -- the kernels that
+  // read what was received would race with it)
+  if (hipStreamSynchronize(nullptr) != hipSuccess) status = ncclUnhandledCudaError;
   // every send of mine must have been wanted: count the peers' receives from me
   for (int p = 0; p < world.n; ++p) {
     size_t sends = 0, wanted = 0;
