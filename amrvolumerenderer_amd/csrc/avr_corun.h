@@ -135,6 +135,9 @@ struct CoRunTuner {
   bool b_final = false;          // the bracket has closed: the finalists are being timed
   int finalists[5] = {0, 0, 0, 0, 0}, n_finalists = 0, b_final_at = 0;
   float finalist_ms[5] = {0, 0, 0, 0, 0};
+  static constexpr float kPlayoffWithin = 1.06f;
+  bool b_playoff = false;        // the two best finalists are being timed once more
+  float playoff_first_ms[2] = {0, 0};
   int b_reports = 0;
   float b_classify = 0.0f, b_march = 0.0f;
   void set_balance(bool allowed) {
@@ -185,9 +188,32 @@ struct CoRunTuner {
         begin_balance_step(finalists[b_final_at]);
         return;
       }
-      int chosen = 0;
+      int chosen = 0, second = -1;
       for (int i = 1; i < n_finalists; ++i) {
         if (finalist_ms[i] < finalist_ms[chosen]) chosen = i;
+      }
+      for (int i = 0; i < n_finalists; ++i) {
+        if (i != chosen && (second < 0 || finalist_ms[i] < finalist_ms[second])) second = i;
+      }
+      // A close call (four frames after three are good to a few per cent; the pockets beside the
+      // best reserve are 4-8 % slower): the two are timed once more, in ascending order, and the
+      // sums decide -- once.
+      if (!b_playoff && second >= 0 && finalist_ms[second] < finalist_ms[chosen] * kPlayoffWithin) {
+        b_playoff = true;
+        const int lo = std::min(chosen, second), hi = std::max(chosen, second);
+        const int pair[2] = {finalists[lo], finalists[hi]};
+        const float pair_ms[2] = {finalist_ms[lo], finalist_ms[hi]};
+        n_finalists = 2;
+        for (int i = 0; i < 2; ++i) {
+          finalists[i] = pair[i];
+          playoff_first_ms[i] = pair_ms[i];
+        }
+        b_final_at = 0;
+        begin_balance_step(finalists[0]);
+        return;
+      }
+      if (b_playoff) {
+        chosen = (finalist_ms[0] + playoff_first_ms[0] <= finalist_ms[1] + playoff_first_ms[1]) ? 0 : 1;
       }
       best = candidate = finalists[chosen];
       best_beside = best;
@@ -240,7 +266,7 @@ struct CoRunTuner {
       phase = kBalance;
       b_lo = 0;
       b_hi = kLastCandidate;
-      b_final = false;
+      b_final = b_playoff = false;
       begin_balance_step(kBalanceSeed);
       best = candidate;
     }

@@ -138,7 +138,8 @@ int main() {
     config4_durations(run.candidate, &classify, &march);
     expect(std::fabs(classify - march) < 0.08f, "both kernels take about equally long at the held "
            "reserve, got candidate " + std::to_string(run.candidate));
-    expect(run.frames <= 96, "the balance is found within 96 frames, took " + std::to_string(run.frames));
+    // (the model's neighbours lie within the play-off's 6 %: the two best finalists are timed twice)
+    expect(run.frames <= 112, "the balance is found within 112 frames, took " + std::to_string(run.frames));
     // a caller who drains every 25 frames still gets there (a drain restarts only the step)
     CoRunTuner d;
     d.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
@@ -151,6 +152,24 @@ int main() {
     const Run held = play(t, one_rank, 2000, 2, 0, false);
     expect(t.settled() && held.windows > run.steps, "the hold re-times the balanced candidate");
     expect(!t.balance_failed, "no drift, no search");
+  }
+  {  // kBalance, a close call among the finalists: a pocket beside the best reserve (6 % slower) that
+     // reads 3 % fast the first time it is timed -- the play-off's second reading decides
+    CoRunTuner t;
+    t.restrict_to(CoRunTuner::kBackToBack, CoRunTuner::kLastCandidate, true);
+    t.set_balance(true);
+    int pocket_reports = 0;
+    const BalanceRun run = play_balance(t, [&](int c, float* cl, float* m) {
+      config4_durations(c, cl, m);
+      if (c == 13 && t.b_final) {
+        const float scale = (++pocket_reports <= CoRunTuner::kFinalistSettle + CoRunTuner::kFinalistFrames) ? 0.92f : 1.06f;
+        *cl *= scale;
+        *m *= scale;
+      }
+    }, 400);
+    expect(t.settled() && t.b_playoff, "a close call is played off");
+    expect(run.candidate != 13, "one fast reading of the pocket does not win, got " +
+                                    std::to_string(run.candidate));
   }
   {  // kBalance at the ends of the scale: a classify pass that is always longer (the opaque regime)
     CoRunTuner t;
