@@ -67,6 +67,12 @@ class ColormapPoint(C.Structure):
                 ("blue", C.c_float), ("alpha", C.c_float)]
 
 
+class Speculation(C.Structure):
+    """avr_speculation (include/avr_hip.h): device pointers of a speculative frame's flags."""
+    _fields_ = [("classified", C.c_void_p), ("visited", C.c_void_p), ("missed", C.c_void_p),
+                ("miss_count", C.c_void_p), ("host_miss_flag", C.c_void_p), ("gate", C.c_void_p)]
+
+
 class PaintParams(C.Structure):
     _fields_ = [
         ("width", C.c_int32),
@@ -166,6 +172,8 @@ SIGNATURES = {
     "avr_classify_plan_chunked": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(_vp), C.c_int]),
     "avr_march_plan_chunked": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "avr_render_plan_culled": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "avr_classify_plan_flagged": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "avr_march_plan_speculative": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_own": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_image": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -239,6 +247,9 @@ SIGNATURES = {
     "avr_renderer_set_occlusion_culling": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_set_corun_balance": (C.c_int, [_vp, C.c_int]),
     "avr_renderer_last_frame_chunks": (C.c_int, [_vp]),
+    "avr_renderer_set_visibility_speculation": (C.c_int, [_vp, C.c_int]),
+    "avr_renderer_speculation_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "avr_renderer_debug_set_speculation_threshold": (C.c_int, [_vp, C.c_float]),
     "avr_renderer_outputs_complete": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "avr_renderer_stream": (_vp, [_vp, C.c_int]),
     "avr_renderer_plan_info": (C.c_int, [_vp, C.POINTER(FramePlanInfo)]),

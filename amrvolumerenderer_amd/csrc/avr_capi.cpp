@@ -364,6 +364,12 @@ struct FrameChunks {
   // visibility[k * n_order + position] (count * n_order bytes, cleared by the call), classify
   // k + 1 leaves out the boxes of its chunk whose flag is 0.
   uint8_t* visibility = nullptr;
+  // A speculative frame (avr_classify_plan_flagged / avr_march_plan_speculative; count == 1):
+  // the classify pass takes only the positions of the layer order whose flag is set (and, with a
+  // gate, does nothing at all unless *gate != 0: the repair pass), the march checks and records.
+  const uint8_t* classify_flags = nullptr;
+  const uint32_t* classify_gate = nullptr;
+  const avr_speculation* speculation = nullptr;
 };
 
 // Positions [bounds[k], bounds[k + 1]) of the global layer order for chunk k: equal shares of the
@@ -521,8 +527,26 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
       bytes += chunk_tile_begin.size() * sizeof(uint32_t) + static_cast<size_t>(n_order) * 4;
     }
   }
+  // a flagged classify pass: the local boxes in layer order as ONE list under its own prefix sum
+  std::vector<uint32_t> listed_tile_begin;
+  const bool flagged = (phases & kClassify) && chunks.classify_flags != nullptr;
+  if (flagged) {
+    require(chunks.count == 1, "a flagged classify pass is not cut into chunks");
+    require(n_order == 0 || box_order != nullptr, "null box_order");
+    listed_tile_begin.reserve(static_cast<size_t>(n_order) + 1);
+    uint32_t sum = 0;
+    listed_tile_begin.push_back(0u);
+    for (int i = 0; i < n_order; ++i) {
+      require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
+      const size_t b = static_cast<size_t>(box_order[i]);
+      sum += plan.classify_tile_begin[b + 1] - plan.classify_tile_begin[b];
+      listed_tile_begin.push_back(sum);
+    }
+    bytes += listed_tile_begin.size() * sizeof(uint32_t) + static_cast<size_t>(n_order) * 4;
+  }
+  if ((phases & kMarch) && chunks.speculation != nullptr) bytes += sizeof(avr::MarchSpecDev);
   avr::StagingRing& staging = ctx->staging;
-  staging.begin(bytes, 12);
+  staging.begin(bytes, 16);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
   const uint32_t* chunk_tile_begin_dev = nullptr;
   const int32_t* chunk_box_list_dev = nullptr;
@@ -532,6 +556,14 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     if (chunked) {
       chunk_tile_begin_dev = staging.add(chunk_tile_begin.data(), chunk_tile_begin.size());
       chunk_box_list_dev = staging.add(box_order, static_cast<size_t>(n_order));
+    }
+    if (flagged) {
+      launch.tile_begin_dev = staging.add(listed_tile_begin.data(), listed_tile_begin.size());
+      launch.box_list_dev = staging.add(box_order, static_cast<size_t>(n_order));
+      launch.n_classify_boxes = n_order;
+      launch.n_classify_tiles = listed_tile_begin.back();
+      launch.visible_in = chunks.classify_flags;
+      launch.classify_gate = chunks.classify_gate;
     }
   }
   if (phases & kMarch) {
@@ -561,6 +593,21 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     launch.out_layers = out_layers;
     launch.samples_out = reinterpret_cast<unsigned long long*>(samples_out);
     launch.counters = reinterpret_cast<unsigned long long*>(ctx->march_counters);
+    if (chunks.speculation != nullptr) {
+      require(chunks.count == 1 && samples_out == nullptr,
+              "a speculative march is one launch and counts no samples");
+      const avr_speculation& given = *chunks.speculation;
+      require(given.classified == nullptr || (given.missed != nullptr && given.miss_count != nullptr),
+              "a speculative march that checks flags needs somewhere to report misses");
+      avr::MarchSpecDev spec{};
+      spec.classified = given.classified;
+      spec.visited = given.visited;
+      spec.missed = given.missed;
+      spec.miss_count = given.miss_count;
+      spec.host_miss_flag = given.host_miss_flag;
+      spec.gate = given.gate;
+      launch.spec_dev = staging.add(&spec, 1);
+    }
     launch.items_dev = staging.add(items.data(), items.size());
     launch.n_items = static_cast<uint32_t>(items.size());
     launch.workgroups_per_cu = ctx->march_workgroups_per_cu;
@@ -1079,6 +1126,8 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
     require(scene != nullptr && plan != nullptr, "null argument");
     require(chunks.count == 1 || !scene->cache_classification,
             "a cached classification is not classified in chunks");
+    require(chunks.classify_flags == nullptr || !scene->cache_classification,
+            "a cached classification is not classified by flags");
     require(static_cast<int>(scene->boxes.size()) == plan->info.n_local_boxes,
             "the scene does not hold this rank's boxes of the plan");
     if (plan->info.n_local_runs == 0) return AVR_OK;
@@ -1141,6 +1190,27 @@ int avr_march_plan_chunked(avr_context* ctx, const avr_scene* scene, const avr_f
   chunks.count = n_chunks;
   chunks.events = reinterpret_cast<hipEvent_t const*>(chunk_events);
   return plan_phase(ctx, kMarch, scene, plan, slot, send_buffer, samples_out, chunks);
+}
+
+int avr_classify_plan_flagged(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                              int slot, const uint8_t* flags, const uint32_t* gate) {
+  return guarded([&]() -> int {
+    require(flags != nullptr, "null flags");
+    FrameChunks chunks;
+    chunks.classify_flags = flags;
+    chunks.classify_gate = gate;
+    return plan_phase(ctx, kClassify, scene, plan, slot, nullptr, nullptr, chunks);
+  });
+}
+
+int avr_march_plan_speculative(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                               int slot, float* send_buffer, const avr_speculation* speculation) {
+  return guarded([&]() -> int {
+    require(speculation != nullptr, "null speculation");
+    FrameChunks chunks;
+    chunks.speculation = speculation;
+    return plan_phase(ctx, kMarch, scene, plan, slot, send_buffer, nullptr, chunks);
+  });
 }
 
 int avr_render_plan_culled(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,

@@ -52,6 +52,17 @@ struct alignas(16) BoxDev {
 };
 static_assert(sizeof(BoxDev) == 144, "BoxDev is read with scalar loads: keep it a multiple of 16 bytes");
 
+// A speculative frame's bookkeeping on the device (render_runs_kernel; all arrays by position in
+// the global layer order).
+struct MarchSpecDev {
+  const uint8_t* classified;  // != 0: this frame's classify pass covered the box; nullptr: every box
+  uint8_t* visited;           // out: set for every box some wave marched; nullptr: not recorded
+  uint8_t* missed;            // out: boxes a ray needed that `classified` left out
+  uint32_t* miss_count;       // out: one per (wave, box) miss
+  uint32_t* host_miss_flag;   // out, host-mapped or nullptr: set to 1 on a miss
+  const uint32_t* gate;       // nullptr, or: the launch does nothing unless *gate != 0
+};
+
 // Frame constants (camera basis, scalar mapping); passed to kernels by value (kernarg -> SGPRs).
 struct FrameConsts {
   int32_t width, height;
@@ -240,6 +251,8 @@ struct RenderLaunch {
   int n_tables;
   const int32_t* order_dev;     // box indices in global layer order
   const int32_t* order_rects_dev;  // their conservative screen rectangles (x0, y0, x1, y1), same order
+  const MarchSpecDev* spec_dev = nullptr;  // a speculative frame's bookkeeping (staged per launch)
+  const uint32_t* classify_gate = nullptr;  // launch_classify: the gated small-grid kernel
   const int32_t* run_end_dev;   // one-past-last position per run
   int n_order, n_runs, n_pieces;
   const RunRectDev* run_rects_dev;    // n_runs

@@ -480,7 +480,9 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
 // kind of spacing), so only that march variant is compiled in; -1 dispatches per box.
 // <= 80 SGPRs: 256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgpr/16)*16 + 16))
 // (MI355X_MICROARCH.md, "Residency"), i.e. 8 per CU only up to 80 SGPRs, 6 at 98+.
-template <bool STATS, int ONLY_MODE>
+// SPEC: the speculative frame's bookkeeping is compiled in (one vector register more: six waves per
+// SIMD instead of seven, so it is its own instantiation; never together with STATS).
+template <bool STATS, int ONLY_MODE, bool SPEC = false>
 __global__ __launch_bounds__(kBlockThreads, 6) void
 render_runs_kernel(
     const FrameConsts fc, const BoxDev* __restrict__ boxes,
@@ -502,8 +504,19 @@ render_runs_kernel(
     // non-null (a frame in depth-ordered chunks with occlusion culling, avr_render_plan_culled):
     // visible_out[position] is set to 1 for every box behind this launch's that some ray may still
     // sample -- see the end of the kernel; the caller cleared it.
-    uint8_t* __restrict__ visible_out) {
+    uint8_t* __restrict__ visible_out,
+    // non-null: a SPECULATIVE frame (MarchSpecDev, avr_internal.h) -- this frame's classify pass left
+    // out the boxes no ray sampled in an earlier frame of the same plan.  The march meets a box it
+    // needs and finds it unclassified: it flags the box, leaves it out and goes on (with a less
+    // opaque accumulator it can only meet MORE boxes than the true frame does, so the flags cover
+    // everything the true frame needs); a gated second classify + march, queued behind this launch,
+    // then redo the frame with those boxes classified -- and do nothing when no flag was raised.
+    const MarchSpecDev* __restrict__ spec) {
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
+  if (SPEC && spec != nullptr) {
+    const uint32_t* const gate = spec->gate;
+    if (gate != nullptr && *gate == 0) return;  // (uniform over the grid)
+  }
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
   // Work item = one super-tile (2 x 2 workgroups in Morton order) of one run.  Workgroups are
@@ -614,8 +627,17 @@ render_runs_kernel(
                       r.y > wave_y0 + (kWaveH - 1));
       }
       unsigned long long pending = __builtin_amdgcn_ballot_w64(candidate);
+      unsigned long long unclassified = 0;  // (speculative frames: candidates the classify pass left out)
+      if (SPEC && spec != nullptr) {
+        const uint8_t* const covered = spec->classified;
+        if (covered != nullptr) {
+          const bool missing = candidate && covered[base + lane] == 0;
+          unclassified = __builtin_amdgcn_ballot_w64(missing);
+        }
+      }
       while (pending != 0) {
-      const int position = base + __builtin_ctzll(pending);
+      const int bit = __builtin_ctzll(pending);
+      const int position = base + bit;
       pending &= pending - 1;
       const BoxDev& box = boxes[order[position]];
       float tmin = -AVR_INF;
@@ -636,6 +658,20 @@ render_runs_kernel(
         if (acc.d <= entry_depth) hit = false;
       }
       if (!__builtin_amdgcn_ballot_w64(hit)) continue;  // whole wave missed or terminated
+      if (SPEC && spec != nullptr) {
+        if ((unclassified >> bit) & 1ull) {
+          if (lane == 0) {
+            spec->missed[position] = 1;
+            atomicAdd(spec->miss_count, 1u);
+            if (spec->host_miss_flag != nullptr) {
+              __hip_atomic_store(spec->host_miss_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+          }
+          continue;
+        }
+        uint8_t* const visited = spec->visited;
+        if (visited != nullptr && lane == 0) visited[position] = 1;
+      }
       if (hit) {
         const float4* table = lds_tables + box.lut * kTableSize;
         Layer5 layer;
@@ -775,9 +811,10 @@ constexpr int kRawBufferFlags = 0x00020000;  // word 3 of a raw (untyped) gfx9 b
 // (0, nt, sc1, nt|sc1, sc0|sc1|nt: 1.049-1.063 ms per frame, profiles/experiments_rounds_1_to_3.md section 3).
 constexpr int kStreamingLoad = 2;
 
+// One tile (4 planes x 4 rows x 128 cells) of the classify pass; `staged`: 16 bricklets of LDS.
 template <bool SIMPLE>
-__global__ __launch_bounds__(kBlockThreads) void classify_kernel(
-    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+__device__ __forceinline__ void classify_tile(
+    const FrameConsts& fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
     const int stream_stores,
     // non-null: this launch classifies the boxes box_list[0 .. n_boxes) (one depth-ordered chunk of
@@ -785,11 +822,8 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     const int32_t* __restrict__ box_list,
     // non-null: visible[i] == 0 means no ray samples box box_list[i] this frame (the march's flags,
     // render_runs_kernel): it is not classified
-    const uint8_t* __restrict__ visible) {
-  __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
-
+    const uint8_t* __restrict__ visible, const uint32_t tile, uint32_t* const staged) {
   // which box does this workgroup belong to (wave-uniform binary search over the prefix sums)
-  const uint32_t tile = blockIdx.x;
   int lo = 0, hi = n_boxes;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -973,6 +1007,34 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
     } else {
       *target = v;
     }
+  }
+}
+
+template <bool SIMPLE>
+__global__ __launch_bounds__(kBlockThreads) void classify_kernel(
+    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+    const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
+    const int stream_stores, const int32_t* __restrict__ box_list,
+    const uint8_t* __restrict__ visible) {
+  __shared__ uint32_t staged[16 * kStagedStride];  // 16 bricklets
+  classify_tile<SIMPLE>(fc, boxes, tile_begin, n_boxes, classified, stream_stores, box_list, visible,
+                        blockIdx.x, staged);
+}
+
+// The boxes a speculative frame's march found missing (render_runs_kernel, MarchSpecDev): a small
+// grid that walks the listed boxes' tiles and does nothing at all unless *gate != 0 -- the usual
+// case, which must not cost the dispatch of a workgroup per tile.
+template <bool SIMPLE>
+__global__ __launch_bounds__(kBlockThreads) void classify_gated_kernel(
+    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+    const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
+    const int32_t* __restrict__ box_list, const uint8_t* __restrict__ visible,
+    const uint32_t* __restrict__ gate, const uint32_t n_tiles) {
+  __shared__ uint32_t staged[16 * kStagedStride];
+  if (*gate == 0) return;  // (uniform over the grid)
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    classify_tile<SIMPLE>(fc, boxes, tile_begin, n_boxes, classified, 0, box_list, visible, tile, staged);
+    __syncthreads();  // (the next tile re-uses the staging area)
   }
 }
 
@@ -1440,6 +1502,20 @@ int launch_classify(const RenderLaunch& L, void* stream_v) {
   const size_t pad = L.classify_lds_pad;  // occupancy cap beside the march (avr_renderer)
   // (a chunk of the frame: n_classify_boxes entries of box_list_dev under the chunk's own prefix)
   const int n_listed = L.box_list_dev != nullptr ? L.n_classify_boxes : L.n_boxes;
+  if (L.classify_gate != nullptr) {
+    // (a speculative frame's repair pass: nothing to do as a rule, so not a workgroup per tile)
+    const unsigned grid = std::min<unsigned>(L.n_classify_tiles, 2048u);
+    if (simple) {
+      hipLaunchKernelGGL(classify_gated_kernel<true>, dim3(grid), dim3(kBlockThreads), 0, stream,
+                         L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
+                         L.box_list_dev, L.visible_in, L.classify_gate, L.n_classify_tiles);
+    } else {
+      hipLaunchKernelGGL(classify_gated_kernel<false>, dim3(grid), dim3(kBlockThreads), 0, stream,
+                         L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
+                         L.box_list_dev, L.visible_in, L.classify_gate, L.n_classify_tiles);
+    }
+    return check_launch("classify_gated_kernel");
+  }
   if (simple) {
     hipLaunchKernelGGL(classify_kernel<true>, dim3(L.n_classify_tiles), dim3(kBlockThreads), pad,
                        stream, L.consts, L.boxes_dev, L.tile_begin_dev, n_listed, L.classified,
@@ -1484,7 +1560,32 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
                      tiles_y,                                                                    \
                      L.items_dev,                                                                \
                      L.out_layers, L.samples_out, L.counters, L.pos_begin,                       \
-                     (L.pos_end < 0 ? L.n_order : L.pos_end), L.resume, L.visible_out)
+                     (L.pos_end < 0 ? L.n_order : L.pos_end), L.resume, L.visible_out, L.spec_dev)
+  if (L.spec_dev != nullptr) {
+    if (stats) {
+      set_error("render_runs_kernel: a speculative frame cannot count samples");
+      return AVR_ERR_INVALID_ARGUMENT;
+    }
+#define AVR_LAUNCH_SPEC(ONLY)                                                                    \
+  hipLaunchKernelGGL((render_runs_kernel<false, ONLY, true>), dim3(blocks), dim3(kBlockThreads),  \
+                     lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,       \
+                     L.n_tables, L.order_dev, reinterpret_cast<const int4*>(L.order_rects_dev),  \
+                     L.run_end_dev, L.n_runs, L.n_pieces,                                        \
+                     L.run_rects_dev, L.run_blocks_dev, L.run_spans_dev, band_shift, tiles_x,    \
+                     tiles_y,                                                                    \
+                     L.items_dev,                                                                \
+                     L.out_layers, L.samples_out, L.counters, L.pos_begin,                       \
+                     (L.pos_end < 0 ? L.n_order : L.pos_end), L.resume, L.visible_out, L.spec_dev)
+    if (L.only_mode == kPow2Multiply) {
+      AVR_LAUNCH_SPEC(kPow2Multiply);
+    } else if (L.only_mode == kReciprocal) {
+      AVR_LAUNCH_SPEC(kReciprocal);
+    } else {
+      AVR_LAUNCH_SPEC(-1);
+    }
+#undef AVR_LAUNCH_SPEC
+    return check_launch("render_runs_kernel (speculative)");
+  }
   if (L.only_mode == kPow2Multiply) {
     if (stats) AVR_LAUNCH(true, kPow2Multiply); else AVR_LAUNCH(false, kPow2Multiply);
   } else if (L.only_mode == kReciprocal) {

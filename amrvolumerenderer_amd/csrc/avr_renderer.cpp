@@ -186,6 +186,7 @@ struct avr_renderer {
     plans.clear();
     plan = nullptr;
     have_plan = false;
+    spec.plan = nullptr;  // (flags of a plan that is gone)
   }
 
   DeviceBuffer send[AVR_CLASSIFIED_SLOTS], recv, piece, piece_rgb8, full_rgb8, full_image, assembled_image, small_image;
@@ -233,6 +234,42 @@ struct avr_renderer {
   DeviceBuffer visible_flags[AVR_CLASSIFIED_SLOTS];
   hipEvent_t chunk_event[AVR_CLASSIFIED_SLOTS][AVR_MAX_FRAME_CHUNKS] = {};
   int last_chunks = 1;  // what the last frame did (avr_renderer_corun_state / diagnostics)
+
+  // ---- visibility speculation (avr_classify_plan_flagged / avr_march_plan_speculative; one rank) --
+  // A frame of the plan the frames before it had classifies only the boxes the march of the frame
+  // TWO before sampled (that march has certainly finished when the classify pass starts: the
+  // classify stream waits for its event); the march checks every box it needs against those flags
+  // and two gated launches behind it repair the frame when the guess was wrong -- results never
+  // change.  With the reference's default boxTransparency = 0 config-4's rays sample 58 of its 176
+  // boxes: the classify pass goes from 0.57 to 0.24 ms.  Decided per plan: the second frame of a
+  // plan copies its flags to the host; at most spec_worth_it of the boxes sampled -> speculate.
+  int speculation = -1;  // avr_renderer_set_visibility_speculation: -1 = auto (one rank), 0 = never
+  struct Speculating {
+    enum State { kObserving, kDeciding, kActive, kRejected, kBackoff };
+    const avr_frame_plan* plan = nullptr;  // whose flags these are
+    State state = kObserving;
+    int seen = 0;                          // consecutive frames of `plan` (a camera that never repeats
+                                           // records nothing: the recording march holds a wave less)
+    int frames_of_plan = 0;                // consecutive frames of `plan` that recorded their flags
+    int backoff = 0;                       // kBackoff: plain frames left
+    hipEvent_t copied = nullptr;           // recorded behind the deciding frame's copy to the host
+    DeviceBuffer visited[AVR_CLASSIFIED_SLOTS];  // by frame % 3: what that frame's march sampled
+    DeviceBuffer missed[AVR_CLASSIFIED_SLOTS];   // ... needed and found unclassified, then a counter
+    uint8_t* host_flags = nullptr;         // pinned: the deciding frame's flags
+    uint8_t* host_flags_dev = nullptr;     // (its device address)
+    size_t host_flags_capacity = 0;
+    uint32_t* host_miss = nullptr;         // pinned, device-visible: set by a march that missed
+    uint32_t* host_miss_dev = nullptr;
+    long active_frames = 0, repaired_frames = 0;
+    float sampled_fraction = -1.0f;        // of the deciding frame (-1: not decided)
+    ~Speculating() {
+      if (host_flags != nullptr) (void)hipHostFree(host_flags);
+      if (host_miss != nullptr) (void)hipHostFree(host_miss);
+      if (copied != nullptr) (void)hipEventDestroy(copied);
+    }
+  } spec;
+  float spec_worth_it = 0.85f;  // (avr_renderer_debug_set_speculation_threshold: tests)
+  static constexpr int kSpecBackoffFrames = 64;
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
   unsigned frame = 0;
 
@@ -275,6 +312,10 @@ struct avr_renderer {
                                    &visible_flags[0], &visible_flags[1], &visible_flags[2]}) {
         buffer->ptr = nullptr;  // (hipFree waits for the device)
       }
+      for (int i = 0; i < AVR_CLASSIFIED_SLOTS; ++i) spec.visited[i].ptr = spec.missed[i].ptr = nullptr;
+      spec.host_flags = nullptr;  // (hipHostFree waits as well)
+      spec.host_miss = nullptr;
+      spec.copied = nullptr;
       return;
     }
     for (avr_context* ctx : {classify, march, compose, pair_b}) {
@@ -713,6 +754,42 @@ int avr_renderer_set_occlusion_culling(avr_renderer* r, int chunks) {
   });
 }
 
+int avr_renderer_set_visibility_speculation(avr_renderer* r, int mode) {
+  return guarded_renderer(r, [&]() -> int {
+    require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
+    r->drain_all();
+    if ((r->speculation != 0) != (mode != 0) && r->spec.state == avr_renderer::Speculating::kActive) {
+      r->tuner.restart();  // (the classify pass changes its length)
+    }
+    r->speculation = mode;
+    r->spec.plan = nullptr;  // (whatever was decided is decided again)
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_debug_set_speculation_threshold(avr_renderer* r, float sampled_fraction) {
+  return guarded_renderer(r, [&]() -> int {
+    require(sampled_fraction >= 0.0f && sampled_fraction <= 1.0f, "the fraction must be in [0, 1]");
+    r->drain_all();
+    r->spec_worth_it = sampled_fraction;
+    r->spec.plan = nullptr;
+    return AVR_OK;
+  });
+}
+
+int avr_renderer_speculation_state(const avr_renderer* r, int* state, int64_t* speculative_frames,
+                                   int64_t* repaired_frames, float* sampled_fraction) {
+  if (r == nullptr) return AVR_ERR_INVALID_ARGUMENT;
+  const avr_renderer::Speculating& sp = r->spec;
+  if (state != nullptr) {
+    *state = (r->speculation == 0 || r->n_ranks > 1) ? -1 : static_cast<int>(sp.state);
+  }
+  if (speculative_frames != nullptr) *speculative_frames = sp.active_frames;
+  if (repaired_frames != nullptr) *repaired_frames = sp.repaired_frames;
+  if (sampled_fraction != nullptr) *sampled_fraction = sp.sampled_fraction;
+  return AVR_OK;
+}
+
 int avr_renderer_set_corun_balance(avr_renderer* r, int mode) {
   return guarded_renderer(r, [&]() -> int {
     require(mode >= -1 && mode <= 1, "mode must be -1, 0 or 1");
@@ -1018,6 +1095,60 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       visibility = static_cast<uint8_t*>(r->visible_flags[slot].reserve(
           bytes_of(static_cast<int64_t>(cull) * info.n_local_boxes, 1), drain));
     }
+    // ---- visibility speculation (one rank): this frame's flag buffers; what the frame does with
+    // them is settled below, when its layout is known
+    avr_renderer::Speculating& sp = r->spec;
+    bool spec_considered = !many && r->speculation != 0 && cull < 2 && !r->cache_classification &&
+                           info.n_local_runs > 0 && info.n_local_boxes >= 8 && samples_out == nullptr;
+    const size_t spec_bytes = (static_cast<size_t>(std::max(info.n_local_boxes, 1)) + 15) / 16 * 16;
+    uint8_t* spec_visited = nullptr;
+    uint8_t* spec_missed = nullptr;
+    uint32_t* spec_count = nullptr;
+    if (!many && r->speculation != 0) {
+      if (sp.plan != plan) {
+        sp.plan = plan;
+        sp.state = avr_renderer::Speculating::kObserving;
+        sp.seen = sp.frames_of_plan = 0;
+        sp.sampled_fraction = -1.0f;
+      }
+      ++sp.seen;
+    }
+    if (spec_considered && (sp.seen < 2 || sp.state == avr_renderer::Speculating::kRejected)) {
+      spec_considered = false;
+    }
+    if (spec_considered) {
+      const void* before[2] = {sp.visited[slot].ptr, sp.missed[slot].ptr};
+      spec_visited = static_cast<uint8_t*>(sp.visited[slot].reserve(spec_bytes, drain));
+      spec_missed = static_cast<uint8_t*>(sp.missed[slot].reserve(spec_bytes + 16, drain));
+      spec_count = reinterpret_cast<uint32_t*>(spec_missed + spec_bytes);
+      if (before[0] != spec_visited || before[1] != spec_missed) sp.frames_of_plan = 0;  // (new buffers: no flags yet)
+      if (sp.host_flags_capacity < spec_bytes) {
+        drain();  // (a copy into the old block may be in flight)
+        if (sp.host_flags != nullptr) (void)hipHostFree(sp.host_flags);
+        sp.host_flags = nullptr;
+        sp.host_flags_capacity = 0;
+        void* block = nullptr;
+        void* mapped = nullptr;
+        hip_ok(hipHostMalloc(&block, spec_bytes * 2, hipHostMallocMapped), "hipHostMalloc(speculation flags)");
+        sp.host_flags = static_cast<uint8_t*>(block);
+        hip_ok(hipHostGetDevicePointer(&mapped, block, 0), "hipHostGetDevicePointer");
+        sp.host_flags_dev = static_cast<uint8_t*>(mapped);
+        sp.host_flags_capacity = spec_bytes * 2;
+        if (sp.state == avr_renderer::Speculating::kDeciding) {
+          sp.state = avr_renderer::Speculating::kObserving;
+          sp.frames_of_plan = 0;
+        }
+      }
+      if (sp.host_miss == nullptr) {
+        void* block = nullptr;
+        void* mapped = nullptr;
+        hip_ok(hipHostMalloc(&block, 64, hipHostMallocMapped), "hipHostMalloc(speculation miss flag)");
+        std::memset(block, 0, 64);
+        sp.host_miss = static_cast<uint32_t*>(block);
+        hip_ok(hipHostGetDevicePointer(&mapped, block, 0), "hipHostGetDevicePointer");
+        sp.host_miss_dev = static_cast<uint32_t*>(mapped);
+      }
+    }
     float* send = static_cast<float*>(r->send[slot].reserve(bytes_of(info.send_floats, 4), drain));
     float* recv = many ? static_cast<float*>(r->recv.reserve(bytes_of(info.recv_floats, 4), drain))
                        : nullptr;
@@ -1228,6 +1359,45 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       n_chunks = std::min(std::max(r->frame_chunks, 1), std::max(info.n_local_boxes, 1));
     }
     r->last_chunks = n_chunks;
+    // ---- visibility speculation: what this frame does (0 nothing, 1 records the boxes its march
+    // samples, 2 classifies only what the frame two before sampled, checks, repairs)
+    int spec_mode = 0;
+    {
+      using S = avr_renderer::Speculating;
+      if (spec_considered && n_chunks == 1 && !paired) {
+        if (*static_cast<volatile uint32_t*>(sp.host_miss) != 0) {  // a march of an earlier frame missed
+          *static_cast<volatile uint32_t*>(sp.host_miss) = 0;
+          ++sp.repaired_frames;
+          if (sp.state == S::kActive) {
+            sp.state = S::kBackoff;
+            sp.backoff = avr_renderer::kSpecBackoffFrames;
+            tuner.restart();  // (the classify pass is the whole pass again)
+          }
+        }
+        if (sp.state == S::kBackoff && --sp.backoff <= 0) {
+          sp.state = S::kActive;
+          tuner.restart();
+        }
+        if (sp.state == S::kDeciding && hipEventQuery(sp.copied) == hipSuccess) {
+          int sampled = 0;
+          for (int i = 0; i < info.n_local_boxes; ++i) sampled += sp.host_flags[i] != 0 ? 1 : 0;
+          sp.sampled_fraction = static_cast<float>(sampled) / static_cast<float>(std::max(info.n_local_boxes, 1));
+          if (sp.sampled_fraction <= r->spec_worth_it) {
+            sp.state = S::kActive;
+            tuner.restart();  // (a classify pass of a fraction of the boxes: another balance)
+          } else {
+            sp.state = S::kRejected;
+          }
+        } else if (sp.state == S::kDeciding) {
+          (void)hipGetLastError();  // hipErrorNotReady is not an error here
+        }
+        if (sp.state != S::kRejected) {
+          spec_mode = (sp.state == S::kActive && sp.frames_of_plan >= 2) ? 2 : 1;
+        }
+      } else if (sp.plan == plan) {
+        sp.frames_of_plan = 0;  // (a frame of the plan that records nothing breaks the chain)
+      }
+    }
     void* chunk_events[AVR_MAX_FRAME_CHUNKS] = {};
     for (int k = 0; k < n_chunks && n_chunks > 1; ++k) {
       hipEvent_t& event = r->chunk_event[volume][k];
@@ -1289,6 +1459,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     } else if (n_chunks > 1) {
       abi_ok(avr_classify_plan_chunked(classify_ctx, r->scene, plan, volume, n_chunks, chunk_events,
                                        was_idle ? 1 : 0));
+    } else if (spec_mode == 2) {
+      // only the boxes the march of the frame two before sampled (it is through when this starts)
+      const int from = (volume + 1) % AVR_CLASSIFIED_SLOTS;
+      if (r->marched_pending[from]) wait_unless_done(stream_c, r->marched_event[from]);
+      abi_ok(avr_classify_plan_flagged(classify_ctx, r->scene, plan, volume,
+                                       static_cast<const uint8_t*>(sp.visited[from].ptr), nullptr));
     } else {
       abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
     }
@@ -1305,6 +1481,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(1);
     r->stage = "march";
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
+    if (spec_mode != 0) {  // (cleared while the classify pass still runs)
+      hip_ok(hipMemsetAsync(spec_visited, 0, spec_bytes, stream_m), "hipMemsetAsync(speculation)");
+      if (spec_mode == 2) {
+        hip_ok(hipMemsetAsync(spec_missed, 0, spec_bytes + 16, stream_m), "hipMemsetAsync(speculation)");
+      }
+    }
     if (overlap && !paired && n_chunks == 1) {
       // (paired: the march follows its classify pass on the same stream; chunked: every march
       // launch waits for its own chunk's event)
@@ -1318,6 +1500,34 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     } else if (n_chunks > 1) {
       abi_ok(avr_march_plan_chunked(march_ctx, r->scene, plan, volume, send, samples_out, n_chunks,
                                     chunk_events));
+    } else if (spec_mode != 0) {
+      using S = avr_renderer::Speculating;
+      avr_speculation first{};
+      first.visited = spec_visited;
+      if (spec_mode == 2) {
+        first.classified = static_cast<const uint8_t*>(sp.visited[(volume + 1) % AVR_CLASSIFIED_SLOTS].ptr);
+        first.missed = spec_missed;
+        first.miss_count = spec_count;
+        first.host_miss_flag = sp.host_miss_dev;
+      }
+      abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &first));
+      if (spec_mode == 2) {
+        // the repair, queued unconditionally: both launches do nothing unless the march missed
+        abi_ok(avr_classify_plan_flagged(march_ctx, r->scene, plan, volume, spec_missed, spec_count));
+        avr_speculation again{};
+        again.visited = spec_visited;
+        again.gate = spec_count;
+        abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &again));
+        ++sp.active_frames;
+      }
+      ++sp.frames_of_plan;
+      if (sp.state == S::kObserving && sp.frames_of_plan >= 1) {
+        // this frame's flags to the host (a copy kernel into pinned memory), read a few frames on
+        abi_ok(avr::launch_upload(spec_visited, sp.host_flags_dev, spec_bytes, stream_m));
+        if (sp.copied == nullptr) sp.copied = make_event(false);
+        hip_ok(hipEventRecord(sp.copied, stream_m), "hipEventRecord");
+        sp.state = S::kDeciding;
+      }
     } else {
       abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
     }

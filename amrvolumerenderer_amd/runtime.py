@@ -536,6 +536,48 @@ class Scene:
             C.c_void_p(visibility.data_ptr())))
         return visibility
 
+    def classify_plan_flagged(self, ctx: "Context", plan, slot: int, flags: torch.Tensor,
+                              gate: Optional[torch.Tensor] = None) -> None:
+        """avr_classify_plan_flagged: the classify pass of the boxes whose flag (uint8, by position
+        in the rank's layer order) is set; with a gate (int32[1]) nothing at all unless it is != 0."""
+        ctx._check_tensor(flags, torch.uint8, "flags")
+        if flags.numel() < len(self.boxes):
+            raise ValueError("flags needs one entry per local box")
+        if gate is not None:
+            ctx._check_tensor(gate, torch.int32, "gate")
+        _capi.check(_capi.lib().avr_classify_plan_flagged(
+            ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(flags.data_ptr()),
+            C.c_void_p(gate.data_ptr()) if gate is not None else None))
+
+    def march_plan_speculative(self, ctx: "Context", plan, slot: int, out: torch.Tensor,
+                               classified: Optional[torch.Tensor] = None,
+                               visited: Optional[torch.Tensor] = None,
+                               missed: Optional[torch.Tensor] = None,
+                               miss_count: Optional[torch.Tensor] = None,
+                               gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """avr_march_plan_speculative: the march that checks `classified` (the flags this frame's
+        classify pass was given), records the boxes it samples in `visited` and the ones it needs
+        but finds unclassified in `missed` / `miss_count` (uint8 per local box / int32[1])."""
+        ctx._check_tensor(out, torch.float32, "out")
+        if out.numel() < plan.send_floats:
+            raise ValueError("send buffer is too small")
+        n = len(self.boxes)
+        for name, tensor, dtype in (("classified", classified, torch.uint8), ("visited", visited, torch.uint8),
+                                    ("missed", missed, torch.uint8)):
+            if tensor is not None:
+                ctx._check_tensor(tensor, dtype, name)
+                if tensor.numel() < n:
+                    raise ValueError(f"{name} needs one entry per local box")
+        for name, tensor in (("miss_count", miss_count), ("gate", gate)):
+            if tensor is not None:
+                ctx._check_tensor(tensor, torch.int32, name)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        spec = _capi.Speculation(ptr(classified), ptr(visited), ptr(missed), ptr(miss_count), None, ptr(gate))
+        _capi.check(_capi.lib().avr_march_plan_speculative(
+            ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(out.data_ptr()),
+            C.byref(spec)))
+        return out
+
     def render_plan(self, plan, out: Optional[torch.Tensor] = None,
                     samples: Optional[torch.Tensor] = None,
                     sync_streams: bool = True) -> torch.Tensor:
@@ -849,6 +891,31 @@ class NativeRenderer:
         """avr_renderer_set_corun_balance: -1 / 1 one rank balances its two kernels by their
         durations (a bisection of ~70 frames), 0 always the full search of every candidate."""
         _capi.check(_capi.lib().avr_renderer_set_corun_balance(self._handle, int(mode)))
+
+    def set_visibility_speculation(self, mode: int = -1) -> None:
+        """avr_renderer_set_visibility_speculation: -1 / 1 (default) a frame whose plan repeats
+        classifies only the boxes the frame two before sampled, checks and, if need be, repairs
+        (exact); 0 never."""
+        _capi.check(_capi.lib().avr_renderer_set_visibility_speculation(self._handle, int(mode)))
+
+    def debug_set_speculation_threshold(self, sampled_fraction: float) -> None:
+        """avr_renderer_debug_set_speculation_threshold (include/avr_hip_debug.h): tests only."""
+        _capi.check(_capi.lib().avr_renderer_debug_set_speculation_threshold(
+            self._handle, float(sampled_fraction)))
+
+    _SPECULATION_STATES = {-1: "off", 0: "observing", 1: "deciding", 2: "speculating",
+                           3: "not worth it for this plan", 4: "suspended after a repair"}
+
+    def speculation_state(self) -> dict:
+        """avr_renderer_speculation_state."""
+        state = C.c_int(0)
+        frames, repaired = C.c_int64(0), C.c_int64(0)
+        fraction = C.c_float(0.0)
+        _capi.check(_capi.lib().avr_renderer_speculation_state(
+            self._handle, C.byref(state), C.byref(frames), C.byref(repaired), C.byref(fraction)))
+        return {"state": self._SPECULATION_STATES.get(state.value, str(state.value)),
+                "speculative_frames": int(frames.value), "repaired_frames": int(repaired.value),
+                "sampled_fraction": None if fraction.value < 0 else round(float(fraction.value), 4)}
 
     def last_frame_chunks(self) -> int:
         return int(_capi.lib().avr_renderer_last_frame_chunks(self._handle))

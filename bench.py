@@ -79,6 +79,10 @@ def parse_args():
     ap.add_argument("--occlusion-culling", type=int, default=-1,
                     help="avr_renderer_set_occlusion_culling: -1 / 0 off (the driver's default), "
                          "k >= 2: every frame in k culled chunks")
+    ap.add_argument("--no-speculation", action="store_true",
+                    help="A/B only: avr_renderer_set_visibility_speculation(0) -- every frame classifies "
+                         "every box (the driver's default speculates where a standing camera's rays "
+                         "sample at most 85 % of the boxes: the opaque regime)")
     ap.add_argument("--corun-full-search", action="store_true",
                     help="A/B only: one rank times every candidate of the co-run search (rounds 2-4) "
                          "instead of balancing the two kernels by their durations "
@@ -489,6 +493,8 @@ def run(args, state):
         renderer.native.set_occlusion_culling(args.occlusion_culling)
     if renderer.native is not None and args.corun_full_search:
         renderer.native.set_corun_balance(0)
+    if renderer.native is not None and args.no_speculation:
+        renderer.native.set_visibility_speculation(0)
     if renderer.native is not None and args.no_coordination:
         renderer.native.set_corun_coordination(0)
     if renderer.native is not None and args.classify_share >= 0:
@@ -798,6 +804,9 @@ def run(args, state):
                                   f"C++ driver's communicator failed: {renderer.native_error}"),
             "march_workgroups_per_cu": renderer.march_workgroups_per_cu,
             "corun": corun_ranks[0] if native else None,
+            # one rank, a standing camera: frames may classify only the boxes an earlier frame's
+            # rays sampled (checked by the march, repaired if wrong: results never change)
+            "visibility_speculation": renderer.native.speculation_state() if native else None,
             # N > 1: what every rank's driver holds (searched as one system: the same on all)
             "corun_ranks": corun_ranks if (native and world > 1) else None,
             "exchange": ({"rank0_send_mb": round(renderer.last_plan.send_floats * 4 / 1e6, 2),

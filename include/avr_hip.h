@@ -395,6 +395,39 @@ int avr_render_plan_culled(avr_context *ctx, const avr_scene *scene, const avr_f
                            int slot, float *send_buffer, uint64_t *samples_out, int n_chunks,
                            uint8_t *visibility);
 
+/* SPECULATIVE frames: occlusion culling from one frame to the next, exact.  With the reference's
+ * default boxTransparency = 0 (VolumeRenderer.hpp:36) most rays saturate in the first boxes they
+ * cross (VolumePainter.cpp:837 carried from box to box: the march skips a box wherever the run
+ * accumulator in front of it is opaque), so a frame reads the f64 cells of boxes no ray samples.
+ * A frame of the same plan as an earlier one may therefore classify only the boxes that earlier
+ * frame's march sampled (`visited`, recorded by avr_march_plan_speculative):
+ *   avr_classify_plan_flagged(flags = that frame's visited[])      the covered boxes only
+ *   avr_march_plan_speculative(classified = the same flags, ...)   checks every box it needs
+ * The march that needs a box the flags left out (the cells changed, say) raises missed[position]
+ * and miss_count, leaves the box out and goes on; with a less opaque accumulator it can only need
+ * MORE boxes than the true frame, so the raised flags cover everything the true frame needs, and
+ * the caller queues, unconditionally, the repair behind it on the same stream:
+ *   avr_classify_plan_flagged(flags = missed, gate = miss_count)   a small grid, idle unless *gate
+ *   avr_march_plan_speculative(classified = NULL, gate = miss_count, ...)   the whole march again
+ * Both do nothing when no flag was raised (the usual case: two launches of a few microseconds).
+ * Results equal avr_classify_plan + avr_march_plan bit for bit either way.  All arrays are device
+ * memory of plan->info.n_local_boxes entries, indexed by the position of a box among this rank's
+ * boxes in the plan's global layer order (opaque to the caller: flags one call wrote are what the
+ * next one reads); visited / missed / miss_count are cleared by the caller.
+ * host_miss_flag: NULL, or device-visible host memory that the march sets to 1 on a miss. */
+typedef struct avr_speculation {
+  const uint8_t *classified; /* != 0: classified this frame; NULL: every box is */
+  uint8_t *visited;          /* out (or NULL): 1 for every box some ray sampled */
+  uint8_t *missed;           /* out: boxes needed but not classified (NULL only if classified is) */
+  uint32_t *miss_count;      /* out: raised with every miss */
+  uint32_t *host_miss_flag;  /* out, or NULL */
+  const uint32_t *gate;      /* NULL, or: the march does nothing unless *gate != 0 */
+} avr_speculation;
+int avr_classify_plan_flagged(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                              int slot, const uint8_t *flags, const uint32_t *gate);
+int avr_march_plan_speculative(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                               int slot, float *send_buffer, const avr_speculation *speculation);
+
 /* Receiver side of composeLayered (DirectSendBase.cpp:400-446) for this rank's piece: folds
  * the runs in global order from the received buffer (recv_floats floats; with one rank the send
  * buffer itself) into out_piece[(piece_end - piece_begin) * 5]; pixels no run covers become the
@@ -717,6 +750,22 @@ int avr_renderer_set_frame_chunks(avr_renderer *renderer, int chunks);
  * not to pay on the configurations of BASELINE.json (profiles/r5_opaque/).  Never changes results. */
 int avr_renderer_set_occlusion_culling(avr_renderer *renderer, int chunks);
 int avr_renderer_last_frame_chunks(const avr_renderer *renderer); /* what the last frame took */
+/* Visibility speculation (avr_classify_plan_flagged / avr_march_plan_speculative; one rank).
+ * -1 / 1 (default): a frame whose plan the frames before it had -- a camera that stands still
+ * while the cells change, the in-situ case -- classifies only the boxes the march of the frame two
+ * before sampled, its march checks every box it needs, and a repair pass (two gated launches that
+ * do nothing as a rule) redoes the frame when the guess was wrong: results never change.  Decided
+ * per plan from its second frame's flags: taken up when at most 85 % of the rank's boxes were
+ * sampled (the reference's default boxTransparency = 0: config-4 samples 58 of 176 boxes, the
+ * classify pass takes 0.24 instead of 0.57 ms), dropped for the plan otherwise (a translucent frame
+ * pays nothing); a frame that needed a repair suspends it for 64 frames.  0: never.
+ * avr_renderer_speculation_state: state -1 off / 0 observing / 1 deciding / 2 speculating /
+ * 3 not worth it for this plan / 4 suspended after a repair; frames speculated and repaired so far;
+ * the fraction of boxes the deciding frame sampled (-1: not decided). */
+int avr_renderer_set_visibility_speculation(avr_renderer *renderer, int mode);
+int avr_renderer_speculation_state(const avr_renderer *renderer, int *state,
+                                   int64_t *speculative_frames, int64_t *repaired_frames,
+                                   float *sampled_fraction);
 int avr_renderer_set_plan_check(avr_renderer *renderer, int mode);
 /* One rank (default -1 = on): instead of timing every candidate of the co-run search, the driver
  * reads off each frame's two kernel durations which of the two is the longer one side by side and

@@ -37,6 +37,11 @@ int avr_renderer_set_corun_history(avr_renderer *renderer, int frames);
 int avr_renderer_corun_history(const avr_renderer *renderer, int16_t *candidates_out, int capacity,
                                int *frames_out);
 
+/* The fraction of a rank's boxes a plan's deciding frame may have sampled for the driver to take
+ * up visibility speculation (avr_renderer_set_visibility_speculation; default 0.85): the tests set
+ * it to 1 so that small scenes, whose rays reach nearly every box, exercise the machinery. */
+int avr_renderer_debug_set_speculation_threshold(avr_renderer *renderer, float sampled_fraction);
+
 #ifdef __cplusplus
 }
 #endif
