@@ -173,6 +173,7 @@ SIGNATURES = {
     "avr_march_plan_chunked": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "avr_render_plan_culled": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "avr_classify_plan_flagged": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "avr_classify_plan_positions": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "avr_march_plan_speculative": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_own": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -369,6 +369,10 @@ struct FrameChunks {
   // gate, does nothing at all unless *gate != 0: the repair pass), the march checks and records.
   const uint8_t* classify_flags = nullptr;
   const uint32_t* classify_gate = nullptr;
+  // ... or the positions themselves, known on the host (avr_classify_plan_positions): a launch of
+  // exactly their tiles
+  const int32_t* classify_positions = nullptr;
+  int n_classify_positions = 0;
   const avr_speculation* speculation = nullptr;
 };
 
@@ -529,20 +533,31 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
   }
   // a flagged classify pass: the local boxes in layer order as ONE list under its own prefix sum
   std::vector<uint32_t> listed_tile_begin;
-  const bool flagged = (phases & kClassify) && chunks.classify_flags != nullptr;
+  std::vector<int32_t> listed_boxes;
+  const bool positioned = (phases & kClassify) && chunks.classify_positions != nullptr;
+  const bool flagged = (phases & kClassify) && (chunks.classify_flags != nullptr || positioned);
   if (flagged) {
     require(chunks.count == 1, "a flagged classify pass is not cut into chunks");
     require(n_order == 0 || box_order != nullptr, "null box_order");
-    listed_tile_begin.reserve(static_cast<size_t>(n_order) + 1);
+    require(!(positioned && chunks.classify_flags != nullptr), "flags or positions, not both");
+    const int n_listed = positioned ? chunks.n_classify_positions : n_order;
+    require(n_listed >= 0 && n_listed <= n_order, "too many positions");
+    listed_tile_begin.reserve(static_cast<size_t>(n_listed) + 1);
+    listed_boxes.reserve(static_cast<size_t>(n_listed));
     uint32_t sum = 0;
     listed_tile_begin.push_back(0u);
-    for (int i = 0; i < n_order; ++i) {
-      require(box_order[i] >= 0 && box_order[i] < n_boxes, "box_order entry out of range");
-      const size_t b = static_cast<size_t>(box_order[i]);
+    int previous = -1;
+    for (int i = 0; i < n_listed; ++i) {
+      const int position = positioned ? chunks.classify_positions[i] : i;
+      require(position > previous && position < n_order, "positions must ascend within the layer order");
+      previous = position;
+      require(box_order[position] >= 0 && box_order[position] < n_boxes, "box_order entry out of range");
+      const size_t b = static_cast<size_t>(box_order[position]);
       sum += plan.classify_tile_begin[b + 1] - plan.classify_tile_begin[b];
       listed_tile_begin.push_back(sum);
+      listed_boxes.push_back(box_order[position]);
     }
-    bytes += listed_tile_begin.size() * sizeof(uint32_t) + static_cast<size_t>(n_order) * 4;
+    bytes += listed_tile_begin.size() * sizeof(uint32_t) + listed_boxes.size() * 4;
   }
   if ((phases & kMarch) && chunks.speculation != nullptr) bytes += sizeof(avr::MarchSpecDev);
   avr::StagingRing& staging = ctx->staging;
@@ -559,10 +574,10 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     }
     if (flagged) {
       launch.tile_begin_dev = staging.add(listed_tile_begin.data(), listed_tile_begin.size());
-      launch.box_list_dev = staging.add(box_order, static_cast<size_t>(n_order));
-      launch.n_classify_boxes = n_order;
+      launch.box_list_dev = staging.add(listed_boxes.data(), listed_boxes.size());
+      launch.n_classify_boxes = static_cast<int>(listed_boxes.size());
       launch.n_classify_tiles = listed_tile_begin.back();
-      launch.visible_in = chunks.classify_flags;
+      launch.visible_in = chunks.classify_flags;  // (null with positions: all of them)
       launch.classify_gate = chunks.classify_gate;
     }
   }
@@ -1126,7 +1141,8 @@ static int plan_phase(avr_context* ctx, int phases, const avr_scene* scene,
     require(scene != nullptr && plan != nullptr, "null argument");
     require(chunks.count == 1 || !scene->cache_classification,
             "a cached classification is not classified in chunks");
-    require(chunks.classify_flags == nullptr || !scene->cache_classification,
+    require((chunks.classify_flags == nullptr && chunks.classify_positions == nullptr) ||
+                !scene->cache_classification,
             "a cached classification is not classified by flags");
     require(static_cast<int>(scene->boxes.size()) == plan->info.n_local_boxes,
             "the scene does not hold this rank's boxes of the plan");
@@ -1199,6 +1215,18 @@ int avr_classify_plan_flagged(avr_context* ctx, const avr_scene* scene, const av
     FrameChunks chunks;
     chunks.classify_flags = flags;
     chunks.classify_gate = gate;
+    return plan_phase(ctx, kClassify, scene, plan, slot, nullptr, nullptr, chunks);
+  });
+}
+
+int avr_classify_plan_positions(avr_context* ctx, const avr_scene* scene, const avr_frame_plan* plan,
+                                int slot, const int32_t* positions, int n_positions) {
+  return guarded([&]() -> int {
+    require(positions != nullptr && n_positions >= 0, "null positions");
+    if (n_positions == 0) return AVR_OK;
+    FrameChunks chunks;
+    chunks.classify_positions = positions;
+    chunks.n_classify_positions = n_positions;
     return plan_phase(ctx, kClassify, scene, plan, slot, nullptr, nullptr, chunks);
   });
 }

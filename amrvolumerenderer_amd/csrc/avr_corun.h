@@ -136,6 +136,7 @@ struct CoRunTuner {
   int finalists[5] = {0, 0, 0, 0, 0}, n_finalists = 0, b_final_at = 0;
   float finalist_ms[5] = {0, 0, 0, 0, 0};
   static constexpr float kPlayoffWithin = 1.06f;
+  static constexpr int kPlayoffFrames = 8;       // (the play-off's reading counts twice: see below)
   bool b_playoff = false;        // the two best finalists are being timed once more
   float playoff_first_ms[2] = {0, 0};
   int b_reports = 0;
@@ -156,7 +157,7 @@ struct CoRunTuner {
   void report_durations(int frame_candidate, float classify_ms, float march_ms) {
     if (phase != kBalance || frame_candidate != candidate) return;
     const int settle = !b_final ? kBalanceSettle : (b_final_at == 0 ? kFirstFinalistSettle : kFinalistSettle);
-    const int frames = b_final ? kFinalistFrames : kBalanceStepFrames;
+    const int frames = b_playoff ? kPlayoffFrames : b_final ? kFinalistFrames : kBalanceStepFrames;
     if (++b_reports <= settle) return;
     b_classify += classify_ms;
     b_march += march_ms;
@@ -213,7 +214,8 @@ struct CoRunTuner {
         return;
       }
       if (b_playoff) {
-        chosen = (finalist_ms[0] + playoff_first_ms[0] <= finalist_ms[1] + playoff_first_ms[1]) ? 0 : 1;
+        // (eight frames against the first reading's four)
+        chosen = (2.0f * finalist_ms[0] + playoff_first_ms[0] <= 2.0f * finalist_ms[1] + playoff_first_ms[1]) ? 0 : 1;
       }
       best = candidate = finalists[chosen];
       best_beside = best;

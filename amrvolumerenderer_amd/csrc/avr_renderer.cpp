@@ -235,33 +235,35 @@ struct avr_renderer {
   hipEvent_t chunk_event[AVR_CLASSIFIED_SLOTS][AVR_MAX_FRAME_CHUNKS] = {};
   int last_chunks = 1;  // what the last frame did (avr_renderer_corun_state / diagnostics)
 
-  // ---- visibility speculation (avr_classify_plan_flagged / avr_march_plan_speculative; one rank) --
-  // A frame of the plan the frames before it had classifies only the boxes the march of the frame
-  // TWO before sampled (that march has certainly finished when the classify pass starts: the
-  // classify stream waits for its event); the march checks every box it needs against those flags
-  // and two gated launches behind it repair the frame when the guess was wrong -- results never
-  // change.  With the reference's default boxTransparency = 0 config-4's rays sample 58 of its 176
-  // boxes: the classify pass goes from 0.57 to 0.24 ms.  Decided per plan: the second frame of a
-  // plan copies its flags to the host; at most spec_worth_it of the boxes sampled -> speculate.
+  // ---- visibility speculation (avr_classify_plan_positions / avr_march_plan_speculative; one rank) --
+  // A camera that stands still (the in-situ case: the cells change, the view does not): the second
+  // frame of a plan records which boxes its march samples and copies the flags to the host; if at
+  // most spec_worth_it of the boxes were sampled, the frames that follow classify only those (a
+  // launch of exactly their tiles), their march checks every box it needs against the set, and two
+  // gated launches behind it repair the frame when the set was wrong (the cells changed) -- results
+  // never change.  A repair sends the plan back to observing, after a pause that doubles.  With the
+  // reference's default boxTransparency = 0 config-4's rays sample 58 of its 176 boxes: the classify
+  // pass goes from 0.57 to 0.19 ms and the pipelined frame from 0.64 to 0.46.
   int speculation = -1;  // avr_renderer_set_visibility_speculation: -1 = auto (one rank), 0 = never
   struct Speculating {
     enum State { kObserving, kDeciding, kActive, kRejected, kBackoff };
-    const avr_frame_plan* plan = nullptr;  // whose flags these are
+    const avr_frame_plan* plan = nullptr;  // whose set this is
     State state = kObserving;
     int seen = 0;                          // consecutive frames of `plan` (a camera that never repeats
                                            // records nothing: the recording march holds a wave less)
-    int frames_of_plan = 0;                // consecutive frames of `plan` that recorded their flags
-    int backoff = 0;                       // kBackoff: plain frames left
-    hipEvent_t copied = nullptr;           // recorded behind the deciding frame's copy to the host
-    DeviceBuffer visited[AVR_CLASSIFIED_SLOTS];  // by frame % 3: what that frame's march sampled
-    DeviceBuffer missed[AVR_CLASSIFIED_SLOTS];   // ... needed and found unclassified, then a counter
-    uint8_t* host_flags = nullptr;         // pinned: the deciding frame's flags
+    int backoff = 0, next_backoff = 16;    // kBackoff: plain frames left / after the next repair
+    hipEvent_t copied = nullptr;           // recorded behind the observing frame's copy to the host
+    std::vector<int32_t> positions;        // kActive: the sampled boxes (positions in the layer order)
+    DeviceBuffer flags;                    // ... as flags for the march, on the device
+    DeviceBuffer visited;                  // the observing frame's flags
+    DeviceBuffer missed[AVR_CLASSIFIED_SLOTS];  // by frame % 3: needed and unclassified, then a counter
+    uint8_t* host_flags = nullptr;         // pinned: the observing frame's flags
     uint8_t* host_flags_dev = nullptr;     // (its device address)
     size_t host_flags_capacity = 0;
     uint32_t* host_miss = nullptr;         // pinned, device-visible: set by a march that missed
     uint32_t* host_miss_dev = nullptr;
     long active_frames = 0, repaired_frames = 0;
-    float sampled_fraction = -1.0f;        // of the deciding frame (-1: not decided)
+    float sampled_fraction = -1.0f;        // of the observing frame (-1: not decided)
     ~Speculating() {
       if (host_flags != nullptr) (void)hipHostFree(host_flags);
       if (host_miss != nullptr) (void)hipHostFree(host_miss);
@@ -269,7 +271,6 @@ struct avr_renderer {
     }
   } spec;
   float spec_worth_it = 0.85f;  // (avr_renderer_debug_set_speculation_threshold: tests)
-  static constexpr int kSpecBackoffFrames = 64;
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
   unsigned frame = 0;
 
@@ -312,7 +313,8 @@ struct avr_renderer {
                                    &visible_flags[0], &visible_flags[1], &visible_flags[2]}) {
         buffer->ptr = nullptr;  // (hipFree waits for the device)
       }
-      for (int i = 0; i < AVR_CLASSIFIED_SLOTS; ++i) spec.visited[i].ptr = spec.missed[i].ptr = nullptr;
+      for (int i = 0; i < AVR_CLASSIFIED_SLOTS; ++i) spec.missed[i].ptr = nullptr;
+      spec.visited.ptr = spec.flags.ptr = nullptr;
       spec.host_flags = nullptr;  // (hipHostFree waits as well)
       spec.host_miss = nullptr;
       spec.copied = nullptr;
@@ -1095,8 +1097,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       visibility = static_cast<uint8_t*>(r->visible_flags[slot].reserve(
           bytes_of(static_cast<int64_t>(cull) * info.n_local_boxes, 1), drain));
     }
-    // ---- visibility speculation (one rank): this frame's flag buffers; what the frame does with
-    // them is settled below, when its layout is known
+    // ---- visibility speculation (one rank): this frame's buffers; what the frame does with them
+    // is settled below, when its layout is known
     avr_renderer::Speculating& sp = r->spec;
     bool spec_considered = !many && r->speculation != 0 && cull < 2 && !r->cache_classification &&
                            info.n_local_runs > 0 && info.n_local_boxes >= 8 && samples_out == nullptr;
@@ -1108,7 +1110,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       if (sp.plan != plan) {
         sp.plan = plan;
         sp.state = avr_renderer::Speculating::kObserving;
-        sp.seen = sp.frames_of_plan = 0;
+        sp.seen = 0;
+        sp.next_backoff = 16;
         sp.sampled_fraction = -1.0f;
       }
       ++sp.seen;
@@ -1117,11 +1120,10 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       spec_considered = false;
     }
     if (spec_considered) {
-      const void* before[2] = {sp.visited[slot].ptr, sp.missed[slot].ptr};
-      spec_visited = static_cast<uint8_t*>(sp.visited[slot].reserve(spec_bytes, drain));
+      spec_visited = static_cast<uint8_t*>(sp.visited.reserve(spec_bytes, drain));
+      (void)sp.flags.reserve(spec_bytes, drain);
       spec_missed = static_cast<uint8_t*>(sp.missed[slot].reserve(spec_bytes + 16, drain));
       spec_count = reinterpret_cast<uint32_t*>(spec_missed + spec_bytes);
-      if (before[0] != spec_visited || before[1] != spec_missed) sp.frames_of_plan = 0;  // (new buffers: no flags yet)
       if (sp.host_flags_capacity < spec_bytes) {
         drain();  // (a copy into the old block may be in flight)
         if (sp.host_flags != nullptr) (void)hipHostFree(sp.host_flags);
@@ -1134,10 +1136,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         hip_ok(hipHostGetDevicePointer(&mapped, block, 0), "hipHostGetDevicePointer");
         sp.host_flags_dev = static_cast<uint8_t*>(mapped);
         sp.host_flags_capacity = spec_bytes * 2;
-        if (sp.state == avr_renderer::Speculating::kDeciding) {
-          sp.state = avr_renderer::Speculating::kObserving;
-          sp.frames_of_plan = 0;
-        }
+        sp.state = avr_renderer::Speculating::kObserving;  // (whatever was being decided)
       }
       if (sp.host_miss == nullptr) {
         void* block = nullptr;
@@ -1360,7 +1359,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     }
     r->last_chunks = n_chunks;
     // ---- visibility speculation: what this frame does (0 nothing, 1 records the boxes its march
-    // samples, 2 classifies only what the frame two before sampled, checks, repairs)
+    // samples and copies them to the host, 2 classifies only the held set, checks, repairs)
     int spec_mode = 0;
     {
       using S = avr_renderer::Speculating;
@@ -1369,33 +1368,37 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
           *static_cast<volatile uint32_t*>(sp.host_miss) = 0;
           ++sp.repaired_frames;
           if (sp.state == S::kActive) {
+            // the set is stale (the cells changed): plain frames for a while, then look again
             sp.state = S::kBackoff;
-            sp.backoff = avr_renderer::kSpecBackoffFrames;
+            sp.backoff = sp.next_backoff;
+            sp.next_backoff = std::min(sp.next_backoff * 2, 1024);
             tuner.restart();  // (the classify pass is the whole pass again)
           }
         }
-        if (sp.state == S::kBackoff && --sp.backoff <= 0) {
-          sp.state = S::kActive;
-          tuner.restart();
-        }
-        if (sp.state == S::kDeciding && hipEventQuery(sp.copied) == hipSuccess) {
-          int sampled = 0;
-          for (int i = 0; i < info.n_local_boxes; ++i) sampled += sp.host_flags[i] != 0 ? 1 : 0;
-          sp.sampled_fraction = static_cast<float>(sampled) / static_cast<float>(std::max(info.n_local_boxes, 1));
-          if (sp.sampled_fraction <= r->spec_worth_it) {
-            sp.state = S::kActive;
-            tuner.restart();  // (a classify pass of a fraction of the boxes: another balance)
+        if (sp.state == S::kBackoff && --sp.backoff <= 0) sp.state = S::kObserving;
+        if (sp.state == S::kDeciding) {
+          if (hipEventQuery(sp.copied) == hipSuccess) {
+            sp.positions.clear();
+            for (int i = 0; i < info.n_local_boxes; ++i) {
+              if (sp.host_flags[i] != 0) sp.positions.push_back(i);
+            }
+            sp.sampled_fraction = static_cast<float>(sp.positions.size()) /
+                                  static_cast<float>(std::max(info.n_local_boxes, 1));
+            if (sp.sampled_fraction <= r->spec_worth_it && !sp.positions.empty()) {
+              // the set for the march, on the device (frames in flight may still read the old one)
+              drain();
+              hip_ok(hipMemcpy(sp.flags.ptr, sp.host_flags, spec_bytes, hipMemcpyHostToDevice),
+                     "hipMemcpy(speculation flags)");
+              sp.state = S::kActive;
+              tuner.restart();  // (a classify pass of a fraction of the boxes: another balance)
+            } else {
+              sp.state = S::kRejected;
+            }
           } else {
-            sp.state = S::kRejected;
+            (void)hipGetLastError();  // hipErrorNotReady is not an error here
           }
-        } else if (sp.state == S::kDeciding) {
-          (void)hipGetLastError();  // hipErrorNotReady is not an error here
         }
-        if (sp.state != S::kRejected) {
-          spec_mode = (sp.state == S::kActive && sp.frames_of_plan >= 2) ? 2 : 1;
-        }
-      } else if (sp.plan == plan) {
-        sp.frames_of_plan = 0;  // (a frame of the plan that records nothing breaks the chain)
+        spec_mode = sp.state == S::kActive ? 2 : sp.state == S::kObserving ? 1 : 0;
       }
     }
     void* chunk_events[AVR_MAX_FRAME_CHUNKS] = {};
@@ -1460,11 +1463,9 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       abi_ok(avr_classify_plan_chunked(classify_ctx, r->scene, plan, volume, n_chunks, chunk_events,
                                        was_idle ? 1 : 0));
     } else if (spec_mode == 2) {
-      // only the boxes the march of the frame two before sampled (it is through when this starts)
-      const int from = (volume + 1) % AVR_CLASSIFIED_SLOTS;
-      if (r->marched_pending[from]) wait_unless_done(stream_c, r->marched_event[from]);
-      abi_ok(avr_classify_plan_flagged(classify_ctx, r->scene, plan, volume,
-                                       static_cast<const uint8_t*>(sp.visited[from].ptr), nullptr));
+      // only the boxes of the held set: a launch of exactly their tiles
+      abi_ok(avr_classify_plan_positions(classify_ctx, r->scene, plan, volume, sp.positions.data(),
+                                         static_cast<int>(sp.positions.size())));
     } else {
       abi_ok(avr_classify_plan(classify_ctx, r->scene, plan, volume));
     }
@@ -1481,11 +1482,10 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(1);
     r->stage = "march";
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
-    if (spec_mode != 0) {  // (cleared while the classify pass still runs)
+    if (spec_mode == 1) {  // (cleared while the classify pass still runs)
       hip_ok(hipMemsetAsync(spec_visited, 0, spec_bytes, stream_m), "hipMemsetAsync(speculation)");
-      if (spec_mode == 2) {
-        hip_ok(hipMemsetAsync(spec_missed, 0, spec_bytes + 16, stream_m), "hipMemsetAsync(speculation)");
-      }
+    } else if (spec_mode == 2) {
+      hip_ok(hipMemsetAsync(spec_missed, 0, spec_bytes + 16, stream_m), "hipMemsetAsync(speculation)");
     }
     if (overlap && !paired && n_chunks == 1) {
       // (paired: the march follows its classify pass on the same stream; chunked: every march
@@ -1500,34 +1500,29 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     } else if (n_chunks > 1) {
       abi_ok(avr_march_plan_chunked(march_ctx, r->scene, plan, volume, send, samples_out, n_chunks,
                                     chunk_events));
-    } else if (spec_mode != 0) {
-      using S = avr_renderer::Speculating;
+    } else if (spec_mode == 1) {
+      // the observing frame: a plain frame whose march records the boxes it samples; the flags go
+      // to the host behind it (a copy kernel into pinned memory), read a few frames on
+      avr_speculation observing{};
+      observing.visited = spec_visited;
+      abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &observing));
+      abi_ok(avr::launch_upload(spec_visited, sp.host_flags_dev, spec_bytes, stream_m));
+      if (sp.copied == nullptr) sp.copied = make_event(false);
+      hip_ok(hipEventRecord(sp.copied, stream_m), "hipEventRecord");
+      sp.state = avr_renderer::Speculating::kDeciding;
+    } else if (spec_mode == 2) {
       avr_speculation first{};
-      first.visited = spec_visited;
-      if (spec_mode == 2) {
-        first.classified = static_cast<const uint8_t*>(sp.visited[(volume + 1) % AVR_CLASSIFIED_SLOTS].ptr);
-        first.missed = spec_missed;
-        first.miss_count = spec_count;
-        first.host_miss_flag = sp.host_miss_dev;
-      }
+      first.classified = static_cast<const uint8_t*>(sp.flags.ptr);
+      first.missed = spec_missed;
+      first.miss_count = spec_count;
+      first.host_miss_flag = sp.host_miss_dev;
       abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &first));
-      if (spec_mode == 2) {
-        // the repair, queued unconditionally: both launches do nothing unless the march missed
-        abi_ok(avr_classify_plan_flagged(march_ctx, r->scene, plan, volume, spec_missed, spec_count));
-        avr_speculation again{};
-        again.visited = spec_visited;
-        again.gate = spec_count;
-        abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &again));
-        ++sp.active_frames;
-      }
-      ++sp.frames_of_plan;
-      if (sp.state == S::kObserving && sp.frames_of_plan >= 1) {
-        // this frame's flags to the host (a copy kernel into pinned memory), read a few frames on
-        abi_ok(avr::launch_upload(spec_visited, sp.host_flags_dev, spec_bytes, stream_m));
-        if (sp.copied == nullptr) sp.copied = make_event(false);
-        hip_ok(hipEventRecord(sp.copied, stream_m), "hipEventRecord");
-        sp.state = S::kDeciding;
-      }
+      // the repair, queued unconditionally: both launches do nothing unless the march missed
+      abi_ok(avr_classify_plan_flagged(march_ctx, r->scene, plan, volume, spec_missed, spec_count));
+      avr_speculation again{};
+      again.gate = spec_count;
+      abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &again));
+      ++sp.active_frames;
     } else {
       abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
     }

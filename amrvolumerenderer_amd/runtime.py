@@ -549,6 +549,14 @@ class Scene:
             ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(flags.data_ptr()),
             C.c_void_p(gate.data_ptr()) if gate is not None else None))
 
+    def classify_plan_positions(self, ctx: "Context", plan, slot: int, positions) -> None:
+        """avr_classify_plan_positions: the classify pass of the boxes at these (ascending)
+        positions of the rank's layer order -- a launch of exactly their tiles."""
+        values = [int(v) for v in positions]
+        array = (C.c_int32 * max(len(values), 1))(*values)
+        _capi.check(_capi.lib().avr_classify_plan_positions(
+            ctx._handle, self._handle, plan._handle, int(slot), array, len(values)))
+
     def march_plan_speculative(self, ctx: "Context", plan, slot: int, out: torch.Tensor,
                                classified: Optional[torch.Tensor] = None,
                                visited: Optional[torch.Tensor] = None,

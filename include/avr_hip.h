@@ -97,6 +97,8 @@ const char *avr_last_error(void);
  *     late by default (avr_renderer_set_deferred_gather, avr_renderer_outputs_complete) and
  *     avr_renderer_synchronize is collective while such a gather is pending; the test hooks and
  *     diagnostics moved to avr_hip_debug.h; avr_context_set_cu_mask_pattern is gone.
+ *     (Added since, compatibly: avr_classify_plan_flagged / _positions, avr_march_plan_speculative,
+ *     avr_renderer_set_visibility_speculation, avr_renderer_speculation_state.)
  *   1: rounds 1-4. */
 #define AVR_ABI_VERSION 2
 int avr_abi_version(void);
@@ -427,6 +429,12 @@ int avr_classify_plan_flagged(avr_context *ctx, const avr_scene *scene, const av
                               int slot, const uint8_t *flags, const uint32_t *gate);
 int avr_march_plan_speculative(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
                                int slot, float *send_buffer, const avr_speculation *speculation);
+/* The flagged classify pass for a caller who has the flags on the HOST (copied from `visited` a few
+ * frames ago): positions[0 .. n_positions) ascending -- a launch of exactly those boxes' tiles
+ * (avr_classify_plan_flagged launches a workgroup per tile of every box and lets the unflagged ones
+ * return: a sixth of config-4's flagged pass).  The march is then given the same set as flags. */
+int avr_classify_plan_positions(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
+                                int slot, const int32_t *positions, int n_positions);
 
 /* Receiver side of composeLayered (DirectSendBase.cpp:400-446) for this rank's piece: folds
  * the runs in global order from the received buffer (recv_floats floats; with one rank the send

@@ -84,6 +84,17 @@ def test_speculative_frame_equals_the_plain_frame(ctx, n_ranks, policy, transpar
             assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (view, r)
             assert misses == 0 and int(missed.sum().item()) == 0, (view, r, misses)
             assert torch.equal(again, visited), (view, r)   # the same frame samples the same boxes
+            # ... and the same set held on the host: a launch of exactly those boxes' tiles
+            scene.classify_plan(ctx, other, 1)
+            listed = torch.full_like(want, float("nan"))
+            missed.zero_()
+            count = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+            scene.classify_plan_positions(ctx, plan, 1, torch.nonzero(visited.cpu()).flatten().tolist())
+            scene.march_plan_speculative(ctx, plan, 1, listed, classified=visited, missed=missed,
+                                         miss_count=count)
+            ctx.synchronize()
+            assert torch.equal(listed.view(torch.int32), want.view(torch.int32)), (view, r)
+            assert int(count.item()) == 0, (view, r)
             if int((visited == 0).sum().item()) > 0:
                 left_out = True
     if transparency == 0.0 and n_ranks == 1:   # (a rank of several folds short runs: little to hide)
@@ -148,6 +159,8 @@ def test_argument_checks(ctx):
     flags = torch.ones(n, dtype=torch.uint8, device=ctx.device)
     with pytest.raises(ValueError):
         scene.classify_plan_flagged(ctx, plan, 0, flags[:n - 1])
+    with pytest.raises(ValueError):   # positions must ascend
+        scene.classify_plan_positions(ctx, plan, 0, [1, 0])
     with pytest.raises(ValueError):   # flags to check, nowhere to report a miss
         scene.march_plan_speculative(ctx, plan, 0, out, classified=flags)
 
