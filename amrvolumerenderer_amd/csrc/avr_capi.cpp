@@ -622,6 +622,7 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
       spec.host_miss_flag = given.host_miss_flag;
       spec.gate = given.gate;
       launch.spec_dev = staging.add(&spec, 1);
+      launch.spec_is_repair = given.gate != nullptr;
     }
     launch.items_dev = staging.add(items.data(), items.size());
     launch.n_items = static_cast<uint32_t>(items.size());

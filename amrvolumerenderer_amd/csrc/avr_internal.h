@@ -252,6 +252,7 @@ struct RenderLaunch {
   const int32_t* order_dev;     // box indices in global layer order
   const int32_t* order_rects_dev;  // their conservative screen rectangles (x0, y0, x1, y1), same order
   const MarchSpecDev* spec_dev = nullptr;  // a speculative frame's bookkeeping (staged per launch)
+  bool spec_is_repair = false;             // ... of its gated second march (a kernel name of its own)
   const uint32_t* classify_gate = nullptr;  // launch_classify: the gated small-grid kernel
   const int32_t* run_end_dev;   // one-past-last position per run
   int n_order, n_runs, n_pieces;

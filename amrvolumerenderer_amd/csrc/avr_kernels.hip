@@ -482,10 +482,10 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
 // (MI355X_MICROARCH.md, "Residency"), i.e. 8 per CU only up to 80 SGPRs, 6 at 98+.
 // SPEC: the speculative frame's bookkeeping is compiled in (one vector register more: six waves per
 // SIMD instead of seven, so it is its own instantiation; never together with STATS).
-template <bool STATS, int ONLY_MODE, bool SPEC = false>
-__global__ __launch_bounds__(kBlockThreads, 6) void
-render_runs_kernel(
-    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+template <bool STATS, int ONLY_MODE, bool SPEC>
+__device__ __forceinline__ void
+render_runs_body(
+    const FrameConsts& fc, const BoxDev* __restrict__ boxes,
     const uint8_t* __restrict__ classified, const float* __restrict__ tables,
     const int n_tables, const int32_t* __restrict__ order, const int4* __restrict__ order_rects,
     const int32_t* __restrict__ run_end,
@@ -779,6 +779,36 @@ render_runs_kernel(
   }
 }
 
+#define AVR_MARCH_PARAMETERS                                                                       \
+    const FrameConsts fc, const BoxDev* __restrict__ boxes, const uint8_t* __restrict__ classified, \
+    const float* __restrict__ tables, const int n_tables, const int32_t* __restrict__ order,       \
+    const int4* __restrict__ order_rects, const int32_t* __restrict__ run_end, const int n_runs,   \
+    const int n_pieces, const RunRectDev* __restrict__ run_rects,                                  \
+    const RunBlockDev* __restrict__ run_blocks, const RunSpanDev* __restrict__ run_spans,          \
+    const int band_shift, const int tiles_x, const int tiles_y,                                    \
+    const MarchItemDev* __restrict__ items, float* __restrict__ out,                               \
+    unsigned long long* samples_out, unsigned long long* counters, const int pos_begin,            \
+    const int pos_end, const int resume, uint8_t* __restrict__ visible_out,                        \
+    const MarchSpecDev* __restrict__ spec
+#define AVR_MARCH_ARGUMENTS                                                                        \
+    fc, boxes, classified, tables, n_tables, order, order_rects, run_end, n_runs, n_pieces,        \
+    run_rects, run_blocks, run_spans, band_shift, tiles_x, tiles_y, items, out, samples_out,       \
+    counters, pos_begin, pos_end, resume, visible_out, spec
+
+template <bool STATS, int ONLY_MODE, bool SPEC = false>
+__global__ __launch_bounds__(kBlockThreads, 6) void render_runs_kernel(AVR_MARCH_PARAMETERS) {
+  render_runs_body<STATS, ONLY_MODE, SPEC>(AVR_MARCH_ARGUMENTS);
+}
+
+// The gated second march of a speculative frame under a name of its own (a profile then tells the
+// marches that ran from the repair launches that found nothing to do).
+template <int ONLY_MODE>
+__global__ __launch_bounds__(kBlockThreads, 6) void render_runs_repair_kernel(AVR_MARCH_PARAMETERS) {
+  render_runs_body<false, ONLY_MODE, true>(AVR_MARCH_ARGUMENTS);
+}
+#undef AVR_MARCH_PARAMETERS
+#undef AVR_MARCH_ARGUMENTS
+
 // Descriptor upload: pinned host block (read over PCIe through its device mapping) -> HBM.
 __global__ void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
@@ -1012,7 +1042,7 @@ __device__ __forceinline__ void classify_tile(
 
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
-    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+    const FrameConsts& fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
     const int stream_stores, const int32_t* __restrict__ box_list,
     const uint8_t* __restrict__ visible) {
@@ -1026,7 +1056,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
 // case, which must not cost the dispatch of a workgroup per tile.
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_gated_kernel(
-    const FrameConsts fc, const BoxDev* __restrict__ boxes,
+    const FrameConsts& fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
     const int32_t* __restrict__ box_list, const uint8_t* __restrict__ visible,
     const uint32_t* __restrict__ gate, const uint32_t n_tiles) {
@@ -1567,7 +1597,9 @@ int launch_march(const RenderLaunch& L, void* stream_v) {
       return AVR_ERR_INVALID_ARGUMENT;
     }
 #define AVR_LAUNCH_SPEC(ONLY)                                                                    \
-  hipLaunchKernelGGL((render_runs_kernel<false, ONLY, true>), dim3(blocks), dim3(kBlockThreads),  \
+  hipLaunchKernelGGL((L.spec_is_repair ? render_runs_repair_kernel<ONLY>                           \
+                                       : render_runs_kernel<false, ONLY, true>),                  \
+                     dim3(blocks), dim3(kBlockThreads),                                            \
                      lds_bytes, stream, L.consts, L.boxes_dev, L.classified, L.tables_dev,       \
                      L.n_tables, L.order_dev, reinterpret_cast<const int4*>(L.order_rects_dev),  \
                      L.run_end_dev, L.n_runs, L.n_pieces,                                        \

@@ -33,6 +33,9 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
             name = "render_runs_kernel"
         elif "classify_kernel" in k:
             name = "classify_kernel"
+        elif "render_runs_repair_kernel" in k or "classify_gated_kernel" in k:
+            # (a speculative frame's two repair launches: idle unless its march missed a box)
+            name = "render_runs_repair_kernel" if "render_runs" in k else "classify_gated_kernel"
         else:
             continue
         agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))

@@ -59,11 +59,13 @@ PY
   }
   run config4_translucent || exit 1
   run config4_opaque --transparency 0.0 || exit 1
+  run config4_opaque_every_box --transparency 0.0 --no-speculation || exit 1
   run config4_noise_field --field noise || exit 1
   run config4_orbit16 --orbit 16 || exit 1
   run config4_fly_through --fly-through || exit 1
   run config3_translucent --config config3 || exit 1
   run config2_translucent --config config2 || exit 1
+  run config2_opaque --config config2 --transparency 0.0 || exit 1
   run config5_translucent --config config5 --antialiasing 4 --steps 20 --warmup 3 || exit 1
 fi
 if [ "$part" = latency ]; then
