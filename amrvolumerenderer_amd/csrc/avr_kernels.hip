@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void classify_tile(
 
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
-    const FrameConsts& fc, const BoxDev* __restrict__ boxes,
+    const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
     const int stream_stores, const int32_t* __restrict__ box_list,
     const uint8_t* __restrict__ visible) {
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(kBlockThreads) void classify_kernel(
 // case, which must not cost the dispatch of a workgroup per tile.
 template <bool SIMPLE>
 __global__ __launch_bounds__(kBlockThreads) void classify_gated_kernel(
-    const FrameConsts& fc, const BoxDev* __restrict__ boxes,
+    const FrameConsts fc, const BoxDev* __restrict__ boxes,
     const uint32_t* __restrict__ tile_begin, const int n_boxes, uint8_t* __restrict__ classified,
     const int32_t* __restrict__ box_list, const uint8_t* __restrict__ visible,
     const uint32_t* __restrict__ gate, const uint32_t n_tiles) {
