@@ -135,8 +135,8 @@ struct CoRunTuner {
   bool b_final = false;          // the bracket has closed: the finalists are being timed
   int finalists[5] = {0, 0, 0, 0, 0}, n_finalists = 0, b_final_at = 0;
   float finalist_ms[5] = {0, 0, 0, 0, 0};
-  static constexpr float kPlayoffWithin = 1.06f;
-  static constexpr int kPlayoffFrames = 8;       // (the play-off's reading counts twice: see below)
+  static constexpr float kPlayoffWithin = 1.04f;
+  static constexpr int kPlayoffFrames = 4;
   bool b_playoff = false;        // the two best finalists are being timed once more
   float playoff_first_ms[2] = {0, 0};
   int b_reports = 0;
@@ -197,7 +197,7 @@ struct CoRunTuner {
         if (i != chosen && (second < 0 || finalist_ms[i] < finalist_ms[second])) second = i;
       }
       // A close call (four frames after three are good to a few per cent; the pockets beside the
-      // best reserve are 4-8 % slower): the two are timed once more, in ascending order, and the
+      // best reserve are 4-8 % slower): within 4 % the two are timed once more, in ascending order, and the
       // sums decide -- once.
       if (!b_playoff && second >= 0 && finalist_ms[second] < finalist_ms[chosen] * kPlayoffWithin) {
         b_playoff = true;
@@ -214,8 +214,7 @@ struct CoRunTuner {
         return;
       }
       if (b_playoff) {
-        // (eight frames against the first reading's four)
-        chosen = (2.0f * finalist_ms[0] + playoff_first_ms[0] <= 2.0f * finalist_ms[1] + playoff_first_ms[1]) ? 0 : 1;
+        chosen = (finalist_ms[0] + playoff_first_ms[0] <= finalist_ms[1] + playoff_first_ms[1]) ? 0 : 1;
       }
       best = candidate = finalists[chosen];
       best_beside = best;

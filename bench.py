@@ -309,7 +309,7 @@ def profiled_traffic(args, world):
     coalesced stream, so the classify kernel's reads are doubled and the march's byte gathers
     are not (MI355X_MICROARCH.md, HBM)."""
     key = workload_key(args, world)
-    if key is None:
+    if key is None or getattr(args, "no_speculation", False):   # (an A/B run: the summaries are the default driver's)
         return None, None
     summary = os.path.join(PMC_DIR, f"pmc_{key}.txt")
     path = os.path.join(ROOT, summary)

@@ -51,6 +51,8 @@ count = torch.zeros(1, dtype=torch.int32, device=ctx.device)
 scratch = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
 print("plain classify          %.4f ms" % timed(lambda: scene.classify_plan(ctx, plan, 0)))
 print("flagged classify        %.4f ms" % timed(lambda: scene.classify_plan_flagged(ctx, plan, 0, visited)))
+positions = torch.nonzero(visited.cpu()).flatten().tolist()
+print("classify, those positions %.4f ms" % timed(lambda: scene.classify_plan_positions(ctx, plan, 0, positions)))
 print("plain march             %.4f ms" % timed(lambda: scene.march_plan(ctx, plan, 0, out)))
 print("checking march          %.4f ms" % timed(lambda: scene.march_plan_speculative(
     ctx, plan, 0, out, classified=visited, visited=scratch, missed=missed, miss_count=count)))
