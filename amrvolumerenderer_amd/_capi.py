@@ -70,7 +70,8 @@ class ColormapPoint(C.Structure):
 class Speculation(C.Structure):
     """avr_speculation (include/avr_hip.h): device pointers of a speculative frame's flags."""
     _fields_ = [("classified", C.c_void_p), ("visited", C.c_void_p), ("missed", C.c_void_p),
-                ("miss_count", C.c_void_p), ("host_miss_flag", C.c_void_p), ("gate", C.c_void_p)]
+                ("miss_count", C.c_void_p), ("host_miss_flag", C.c_void_p), ("gate", C.c_void_p),
+                ("classified_host", C.c_void_p), ("dirty_workgroups", C.c_void_p)]
 
 
 class PaintParams(C.Structure):
@@ -174,6 +175,7 @@ SIGNATURES = {
     "avr_render_plan_culled": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "avr_classify_plan_flagged": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_classify_plan_positions": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "avr_march_plan_workgroups": (C.c_int, [_vp, _vp]),
     "avr_march_plan_speculative": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "avr_fold_plan": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "avr_fold_plan_own": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

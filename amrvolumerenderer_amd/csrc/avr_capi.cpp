@@ -402,6 +402,15 @@ std::vector<int> chunk_bounds(const avr::FramePlan& plan, const int32_t* box_ord
 
 // One frame's device work for a list of boxes: the classify pass and/or the march.
 // `classified` must hold plan.classified_bytes bytes; `cached` (optional) carries the host
+// Upper bound of the march's workgroups: a work item per super-tile of the screen and run, padded
+// to whole rounds of the XCDs, four workgroups each (build_march_items, avr_host.cpp).
+int64_t march_workgroups_bound(int width, int height, int n_runs) {
+  const int64_t span = avr::kTile * avr::kSuperTileSide;
+  const int64_t super_tiles = ((width + span - 1) / span) * ((height + span - 1) / span);
+  const int64_t items = (super_tiles * std::max(n_runs, 0) + avr::kXcds - 1) / avr::kXcds * avr::kXcds;
+  return items * avr::kSuperTileTiles;
+}
+
 // prologue from the classify call of a frame to its march call.
 int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
            const avr_scalar_transform& transform, const avr_paint_params& params,
@@ -559,7 +568,9 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
     }
     bytes += listed_tile_begin.size() * sizeof(uint32_t) + listed_boxes.size() * 4;
   }
-  if ((phases & kMarch) && chunks.speculation != nullptr) bytes += sizeof(avr::MarchSpecDev);
+  if ((phases & kMarch) && chunks.speculation != nullptr) {
+    bytes += sizeof(avr::MarchSpecDev) + static_cast<size_t>(n_order);
+  }
   avr::StagingRing& staging = ctx->staging;
   staging.begin(bytes, 16);
   launch.boxes_dev = staging.add(plan.boxes.data(), plan.boxes.size());
@@ -612,15 +623,28 @@ int render(avr_context* ctx, int phases, const avr_box* boxes, int n_boxes,
       require(chunks.count == 1 && samples_out == nullptr,
               "a speculative march is one launch and counts no samples");
       const avr_speculation& given = *chunks.speculation;
-      require(given.classified == nullptr || (given.missed != nullptr && given.miss_count != nullptr),
+      require(given.classified == nullptr || given.classified_host == nullptr,
+              "the flags are on the device or on the host, not both");
+      const bool checks = given.classified != nullptr || given.classified_host != nullptr;
+      require(!checks || (given.missed != nullptr && given.miss_count != nullptr),
               "a speculative march that checks flags needs somewhere to report misses");
       avr::MarchSpecDev spec{};
-      spec.classified = given.classified;
+      spec.classified = given.classified_host != nullptr
+                            ? staging.add(given.classified_host, static_cast<size_t>(n_order))
+                            : given.classified;
       spec.visited = given.visited;
       spec.missed = given.missed;
       spec.miss_count = given.miss_count;
       spec.host_miss_flag = given.host_miss_flag;
       spec.gate = given.gate;
+      // (the first pass marks, the gated pass reads: one array, a byte per workgroup of the grid)
+      spec.dirty_blocks_out = given.gate == nullptr ? given.dirty_workgroups : nullptr;
+      spec.dirty_blocks = given.gate != nullptr ? given.dirty_workgroups : nullptr;
+      if (given.dirty_workgroups != nullptr) {
+        require(static_cast<int64_t>(items.size()) * avr::kSuperTileTiles <=
+                    march_workgroups_bound(params.width, params.height, n_runs),
+                "more march workgroups than avr_march_plan_workgroups promised");
+      }
       launch.spec_dev = staging.add(&spec, 1);
       launch.spec_is_repair = given.gate != nullptr;
     }
@@ -1217,6 +1241,14 @@ int avr_classify_plan_flagged(avr_context* ctx, const avr_scene* scene, const av
     chunks.classify_flags = flags;
     chunks.classify_gate = gate;
     return plan_phase(ctx, kClassify, scene, plan, slot, nullptr, nullptr, chunks);
+  });
+}
+
+int avr_march_plan_workgroups(const avr_frame_plan* plan, int64_t* workgroups) {
+  return guarded([&]() -> int {
+    require(plan != nullptr && workgroups != nullptr, "null argument");
+    *workgroups = march_workgroups_bound(plan->params.width, plan->params.height, plan->info.n_local_runs);
+    return AVR_OK;
   });
 }
 

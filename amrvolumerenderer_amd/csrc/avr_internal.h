@@ -61,6 +61,8 @@ struct MarchSpecDev {
   uint32_t* miss_count;       // out: one per (wave, box) miss
   uint32_t* host_miss_flag;   // out, host-mapped or nullptr: set to 1 on a miss
   const uint32_t* gate;       // nullptr, or: the launch does nothing unless *gate != 0
+  uint8_t* dirty_blocks_out;  // out, or nullptr: per workgroup of the grid, 1 = it met an unclassified box
+  const uint8_t* dirty_blocks;  // gated launch: nullptr, or only these workgroups run again
 };
 
 // Frame constants (camera basis, scalar mapping); passed to kernels by value (kernarg -> SGPRs).

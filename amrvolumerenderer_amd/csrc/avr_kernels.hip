@@ -515,7 +515,13 @@ render_runs_body(
   extern __shared__ float4 lds_tables[];  // n_tables x 256 RGBA entries
   if (SPEC && spec != nullptr) {
     const uint32_t* const gate = spec->gate;
-    if (gate != nullptr && *gate == 0) return;  // (uniform over the grid)
+    if (gate != nullptr) {
+      if (*gate == 0) return;  // (uniform over the grid)
+      // the repair march redoes only the workgroups whose first pass met an unclassified box (the
+      // same grid, the same work items): every other layer pixel is final already
+      const uint8_t* const dirty = spec->dirty_blocks;
+      if (dirty != nullptr && dirty[blockIdx.x] == 0) return;
+    }
   }
 
   // ---- XCD-aware work assignment ------------------------------------------------------------
@@ -662,6 +668,7 @@ render_runs_body(
         if ((unclassified >> bit) & 1ull) {
           if (lane == 0) {
             spec->missed[position] = 1;
+            if (spec->dirty_blocks_out != nullptr) spec->dirty_blocks_out[blockIdx.x] = 1;
             atomicAdd(spec->miss_count, 1u);
             if (spec->host_miss_flag != nullptr) {
               __hip_atomic_store(spec->host_miss_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -186,7 +186,7 @@ struct avr_renderer {
     plans.clear();
     plan = nullptr;
     have_plan = false;
-    spec.plan = nullptr;  // (flags of a plan that is gone)
+    spec.forget();  // (what was sampled under the old settings)
   }
 
   DeviceBuffer send[AVR_CLASSIFIED_SLOTS], recv, piece, piece_rgb8, full_rgb8, full_image, assembled_image, small_image;
@@ -236,40 +236,62 @@ struct avr_renderer {
   int last_chunks = 1;  // what the last frame did (avr_renderer_corun_state / diagnostics)
 
   // ---- visibility speculation (avr_classify_plan_positions / avr_march_plan_speculative; one rank) --
-  // A camera that stands still (the in-situ case: the cells change, the view does not): the second
-  // frame of a plan records which boxes its march samples and copies the flags to the host; if at
-  // most spec_worth_it of the boxes were sampled, the frames that follow classify only those (a
-  // launch of exactly their tiles), their march checks every box it needs against the set, and two
-  // gated launches behind it repair the frame when the set was wrong (the cells changed) -- results
-  // never change.  A repair sends the plan back to observing, after a pause that doubles.  With the
-  // reference's default boxTransparency = 0 config-4's rays sample 58 of its 176 boxes: the classify
-  // pass goes from 0.57 to 0.19 ms and the pipelined frame from 0.64 to 0.46.
+  // With the reference's default boxTransparency = 0 the march's skip test keeps config-4's rays out
+  // of 118 of its 176 boxes, yet every frame reads their f64 cells.  The driver remembers, per BOX
+  // of the rank, the last frame whose march sampled it (observations: a march that records the boxes
+  // it samples, the flags copied to the host and read a few frames later -- by box, so they outlive
+  // the plan: a moving camera keeps what it learnt).  While at most spec_worth_it of the boxes were
+  // sampled in the last kSpecMemory frames, a frame classifies only those (a launch of exactly
+  // their tiles), its march checks every box it is about to march against the same set, and two
+  // gated launches behind it repair the frame when the set was wrong (the cells changed, the camera
+  // turned) -- results never change.  Config-4 opaque: classify pass 0.55 -> 0.18 ms, pipelined
+  // frame 0.64 -> 0.43 ms.  A translucent frame (every box sampled) is observed once and then left
+  // alone but for one observing frame in kSpecProbeEvery.
   int speculation = -1;  // avr_renderer_set_visibility_speculation: -1 = auto (one rank), 0 = never
   struct Speculating {
     enum State { kObserving, kDeciding, kActive, kRejected, kBackoff };
-    const avr_frame_plan* plan = nullptr;  // whose set this is
     State state = kObserving;
-    int seen = 0;                          // consecutive frames of `plan` (a camera that never repeats
-                                           // records nothing: the recording march holds a wave less)
-    int backoff = 0, next_backoff = 16;    // kBackoff: plain frames left / after the next repair
-    hipEvent_t copied = nullptr;           // recorded behind the observing frame's copy to the host
-    std::vector<int32_t> positions;        // kActive: the sampled boxes (positions in the layer order)
-    DeviceBuffer flags;                    // ... as flags for the march, on the device
-    DeviceBuffer visited;                  // the observing frame's flags
-    DeviceBuffer missed[AVR_CLASSIFIED_SLOTS];  // by frame % 3: needed and unclassified, then a counter
-    uint8_t* host_flags = nullptr;         // pinned: the observing frame's flags
-    uint8_t* host_flags_dev = nullptr;     // (its device address)
-    size_t host_flags_capacity = 0;
+    std::vector<int64_t> last_sampled;     // per local box: the last frame that sampled it (-1 never)
+    std::vector<int32_t> positions;        // this frame's set, as positions in its layer order
+    std::vector<uint8_t> flags;            // ... and as flags by position (staged with the march)
+    int64_t frame = 0;                     // frames this struct has seen
+    int64_t asleep_until = 0;              // kRejected / kBackoff: the next observing frame
+    int next_backoff = 64;                 // after the next run of repairs
+    int recent_repairs = 0, recent_frames = 0;
+    // observations in flight: the march's flags by POSITION, that frame's layer order, an event
+    struct Observation {
+      uint8_t* host = nullptr;             // pinned, device-visible
+      uint8_t* host_dev = nullptr;
+      size_t capacity = 0;
+      hipEvent_t copied = nullptr;
+      std::vector<int32_t> order;          // position -> local box of that frame's plan
+      int64_t frame = 0;
+      bool pending = false;
+    };
+    static constexpr int kObservations = 4;
+    Observation observations[kObservations];
+    DeviceBuffer visited[AVR_CLASSIFIED_SLOTS];  // by frame % 3: what that frame's march sampled
+    DeviceBuffer missed[AVR_CLASSIFIED_SLOTS];   // ... needed and found unclassified, then a counter
     uint32_t* host_miss = nullptr;         // pinned, device-visible: set by a march that missed
     uint32_t* host_miss_dev = nullptr;
     long active_frames = 0, repaired_frames = 0;
-    float sampled_fraction = -1.0f;        // of the observing frame (-1: not decided)
+    float sampled_fraction = -1.0f;        // of the rank's boxes, in the last kSpecMemory frames
+    void forget() {                        // (another transfer function, other boxes)
+      last_sampled.clear();
+      state = kObserving;
+      sampled_fraction = -1.0f;
+      for (Observation& o : observations) o.pending = false;  // (their flags are of the old settings)
+    }
     ~Speculating() {
-      if (host_flags != nullptr) (void)hipHostFree(host_flags);
+      for (Observation& o : observations) {
+        if (o.host != nullptr) (void)hipHostFree(o.host);
+        if (o.copied != nullptr) (void)hipEventDestroy(o.copied);
+      }
       if (host_miss != nullptr) (void)hipHostFree(host_miss);
-      if (copied != nullptr) (void)hipEventDestroy(copied);
     }
   } spec;
+  static constexpr int kSpecMemory = 24;       // frames a box stays in the set after it was last sampled
+  static constexpr int kSpecProbeEvery = 512;  // kRejected: one observing frame in so many
   float spec_worth_it = 0.85f;  // (avr_renderer_debug_set_speculation_threshold: tests)
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
   unsigned frame = 0;
@@ -313,11 +335,12 @@ struct avr_renderer {
                                    &visible_flags[0], &visible_flags[1], &visible_flags[2]}) {
         buffer->ptr = nullptr;  // (hipFree waits for the device)
       }
-      for (int i = 0; i < AVR_CLASSIFIED_SLOTS; ++i) spec.missed[i].ptr = nullptr;
-      spec.visited.ptr = spec.flags.ptr = nullptr;
-      spec.host_flags = nullptr;  // (hipHostFree waits as well)
+      for (int i = 0; i < AVR_CLASSIFIED_SLOTS; ++i) spec.visited[i].ptr = spec.missed[i].ptr = nullptr;
+      for (Speculating::Observation& o : spec.observations) {
+        o.host = nullptr;  // (hipHostFree waits as well)
+        o.copied = nullptr;
+      }
       spec.host_miss = nullptr;
-      spec.copied = nullptr;
       return;
     }
     for (avr_context* ctx : {classify, march, compose, pair_b}) {
@@ -764,7 +787,7 @@ int avr_renderer_set_visibility_speculation(avr_renderer* r, int mode) {
       r->tuner.restart();  // (the classify pass changes its length)
     }
     r->speculation = mode;
-    r->spec.plan = nullptr;  // (whatever was decided is decided again)
+    r->spec.forget();  // (whatever was decided is decided again)
     return AVR_OK;
   });
 }
@@ -774,7 +797,7 @@ int avr_renderer_debug_set_speculation_threshold(avr_renderer* r, float sampled_
     require(sampled_fraction >= 0.0f && sampled_fraction <= 1.0f, "the fraction must be in [0, 1]");
     r->drain_all();
     r->spec_worth_it = sampled_fraction;
-    r->spec.plan = nullptr;
+    r->spec.forget();
     return AVR_OK;
   });
 }
@@ -788,7 +811,7 @@ int avr_renderer_speculation_state(const avr_renderer* r, int* state, int64_t* s
   }
   if (speculative_frames != nullptr) *speculative_frames = sp.active_frames;
   if (repaired_frames != nullptr) *repaired_frames = sp.repaired_frames;
-  if (sampled_fraction != nullptr) *sampled_fraction = sp.sampled_fraction;
+  if (sampled_fraction != nullptr) *sampled_fraction = sp.sampled_fraction < 0.0f ? -1.0f : sp.sampled_fraction;
   return AVR_OK;
 }
 
@@ -1100,44 +1123,30 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     // ---- visibility speculation (one rank): this frame's buffers; what the frame does with them
     // is settled below, when its layout is known
     avr_renderer::Speculating& sp = r->spec;
-    bool spec_considered = !many && r->speculation != 0 && cull < 2 && !r->cache_classification &&
-                           info.n_local_runs > 0 && info.n_local_boxes >= 8 && samples_out == nullptr;
+    const bool spec_considered = !many && r->speculation != 0 && cull < 2 && !r->cache_classification &&
+                                 info.n_local_runs > 0 && info.n_local_boxes >= 8 && samples_out == nullptr &&
+                                 plan->local_order.size() == static_cast<size_t>(info.n_local_boxes);
     const size_t spec_bytes = (static_cast<size_t>(std::max(info.n_local_boxes, 1)) + 15) / 16 * 16;
     uint8_t* spec_visited = nullptr;
     uint8_t* spec_missed = nullptr;
     uint32_t* spec_count = nullptr;
-    if (!many && r->speculation != 0) {
-      if (sp.plan != plan) {
-        sp.plan = plan;
-        sp.state = avr_renderer::Speculating::kObserving;
-        sp.seen = 0;
-        sp.next_backoff = 16;
-        sp.sampled_fraction = -1.0f;
-      }
-      ++sp.seen;
-    }
-    if (spec_considered && (sp.seen < 2 || sp.state == avr_renderer::Speculating::kRejected)) {
-      spec_considered = false;
-    }
+    uint8_t* spec_dirty = nullptr;
+    int64_t spec_workgroups = 0;
+    size_t spec_block = 0;
+    avr_renderer::Speculating::Observation* spec_observation = nullptr;
     if (spec_considered) {
-      spec_visited = static_cast<uint8_t*>(sp.visited.reserve(spec_bytes, drain));
-      (void)sp.flags.reserve(spec_bytes, drain);
-      spec_missed = static_cast<uint8_t*>(sp.missed[slot].reserve(spec_bytes + 16, drain));
-      spec_count = reinterpret_cast<uint32_t*>(spec_missed + spec_bytes);
-      if (sp.host_flags_capacity < spec_bytes) {
-        drain();  // (a copy into the old block may be in flight)
-        if (sp.host_flags != nullptr) (void)hipHostFree(sp.host_flags);
-        sp.host_flags = nullptr;
-        sp.host_flags_capacity = 0;
-        void* block = nullptr;
-        void* mapped = nullptr;
-        hip_ok(hipHostMalloc(&block, spec_bytes * 2, hipHostMallocMapped), "hipHostMalloc(speculation flags)");
-        sp.host_flags = static_cast<uint8_t*>(block);
-        hip_ok(hipHostGetDevicePointer(&mapped, block, 0), "hipHostGetDevicePointer");
-        sp.host_flags_dev = static_cast<uint8_t*>(mapped);
-        sp.host_flags_capacity = spec_bytes * 2;
-        sp.state = avr_renderer::Speculating::kObserving;  // (whatever was being decided)
+      ++sp.frame;
+      if (sp.last_sampled.size() != static_cast<size_t>(info.n_local_boxes)) {
+        sp.last_sampled.assign(static_cast<size_t>(info.n_local_boxes), -1);
+        sp.state = avr_renderer::Speculating::kObserving;
       }
+      spec_visited = static_cast<uint8_t*>(sp.visited[slot].reserve(spec_bytes, drain));
+      // (one block per slot: the missed flags, the miss counter, a byte per march workgroup)
+      abi_ok(avr_march_plan_workgroups(plan, &spec_workgroups));
+      spec_block = spec_bytes + 16 + (static_cast<size_t>(spec_workgroups) + 15) / 16 * 16;
+      spec_missed = static_cast<uint8_t*>(sp.missed[slot].reserve(spec_block, drain));
+      spec_count = reinterpret_cast<uint32_t*>(spec_missed + spec_bytes);
+      spec_dirty = spec_missed + spec_bytes + 16;
       if (sp.host_miss == nullptr) {
         void* block = nullptr;
         void* mapped = nullptr;
@@ -1146,6 +1155,50 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
         sp.host_miss = static_cast<uint32_t*>(block);
         hip_ok(hipHostGetDevicePointer(&mapped, block, 0), "hipHostGetDevicePointer");
         sp.host_miss_dev = static_cast<uint32_t*>(mapped);
+      }
+      // the observations that have arrived, oldest first: which boxes those frames' rays sampled
+      for (int k = 0; k < avr_renderer::Speculating::kObservations; ++k) {
+        avr_renderer::Speculating::Observation* oldest = nullptr;
+        for (avr_renderer::Speculating::Observation& o : sp.observations) {
+          if (o.pending && (oldest == nullptr || o.frame < oldest->frame)) oldest = &o;
+        }
+        if (oldest == nullptr) break;
+        if (hipEventQuery(oldest->copied) != hipSuccess) {
+          (void)hipGetLastError();  // hipErrorNotReady is not an error here
+          break;
+        }
+        oldest->pending = false;
+        if (oldest->order.size() != sp.last_sampled.size()) continue;
+        for (size_t position = 0; position < oldest->order.size(); ++position) {
+          if (oldest->host[position] != 0) {
+            int64_t& last = sp.last_sampled[static_cast<size_t>(oldest->order[position])];
+            last = std::max(last, oldest->frame);
+          }
+        }
+        if (sp.state == avr_renderer::Speculating::kDeciding) sp.state = avr_renderer::Speculating::kObserving;
+        sp.sampled_fraction = -2.0f;  // (to be counted below)
+      }
+      // a free observation slot for this frame (none: the host is far ahead, this frame is not observed)
+      for (avr_renderer::Speculating::Observation& o : sp.observations) {
+        if (o.pending) continue;
+        if (o.capacity < spec_bytes) {
+          if (o.host != nullptr) (void)hipHostFree(o.host);
+          o.host = nullptr;
+          o.capacity = 0;
+          void* block = nullptr;
+          void* mapped = nullptr;
+          hip_ok(hipHostMalloc(&block, spec_bytes * 2, hipHostMallocMapped), "hipHostMalloc(speculation flags)");
+          o.host = static_cast<uint8_t*>(block);
+          hip_ok(hipHostGetDevicePointer(&mapped, block, 0), "hipHostGetDevicePointer");
+          o.host_dev = static_cast<uint8_t*>(mapped);
+          o.capacity = spec_bytes * 2;
+        }
+        if (o.copied == nullptr) {
+          // (WITH the system fence, unlike the ordering events: the host reads what the copy wrote)
+          hip_ok(hipEventCreateWithFlags(&o.copied, hipEventDisableTiming), "hipEventCreate");
+        }
+        spec_observation = &o;
+        break;
       }
     }
     float* send = static_cast<float*>(r->send[slot].reserve(bytes_of(info.send_floats, 4), drain));
@@ -1358,47 +1411,72 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
       n_chunks = std::min(std::max(r->frame_chunks, 1), std::max(info.n_local_boxes, 1));
     }
     r->last_chunks = n_chunks;
-    // ---- visibility speculation: what this frame does (0 nothing, 1 records the boxes its march
-    // samples and copies them to the host, 2 classifies only the held set, checks, repairs)
+    // ---- visibility speculation: what this frame does (0 nothing, 1 a plain frame whose march
+    // records the boxes it samples, 2 classifies only the set, checks, repairs -- and records)
     int spec_mode = 0;
     {
       using S = avr_renderer::Speculating;
       if (spec_considered && n_chunks == 1 && !paired) {
-        if (*static_cast<volatile uint32_t*>(sp.host_miss) != 0) {  // a march of an earlier frame missed
+        const bool missed_lately = *static_cast<volatile uint32_t*>(sp.host_miss) != 0;
+        if (missed_lately) {  // a march of an earlier frame missed (its repair redid that frame)
           *static_cast<volatile uint32_t*>(sp.host_miss) = 0;
           ++sp.repaired_frames;
-          if (sp.state == S::kActive) {
-            // the set is stale (the cells changed): plain frames for a while, then look again
-            sp.state = S::kBackoff;
-            sp.backoff = sp.next_backoff;
-            sp.next_backoff = std::min(sp.next_backoff * 2, 1024);
-            tuner.restart();  // (the classify pass is the whole pass again)
-          }
+          ++sp.recent_repairs;
         }
-        if (sp.state == S::kBackoff && --sp.backoff <= 0) sp.state = S::kObserving;
-        if (sp.state == S::kDeciding) {
-          if (hipEventQuery(sp.copied) == hipSuccess) {
-            sp.positions.clear();
-            for (int i = 0; i < info.n_local_boxes; ++i) {
-              if (sp.host_flags[i] != 0) sp.positions.push_back(i);
+        if (sp.state == S::kActive && ++sp.recent_frames >= 32) {
+          // repairs in more than half of the frames: the cells change what is visible faster than
+          // the observations follow (a repair redoes the tiles that met an unclassified box)
+          if (sp.recent_repairs * 2 > sp.recent_frames) {
+            sp.state = S::kBackoff;
+            sp.asleep_until = sp.frame + sp.next_backoff;
+            sp.next_backoff = std::min(sp.next_backoff * 2, 4096);
+            tuner.restart();  // (the classify pass is the whole pass again)
+          } else if (sp.recent_repairs == 0) {
+            sp.next_backoff = 64;
+          }
+          sp.recent_repairs = sp.recent_frames = 0;
+        }
+        if ((sp.state == S::kRejected || sp.state == S::kBackoff) && sp.frame >= sp.asleep_until) {
+          sp.state = S::kObserving;
+          std::fill(sp.last_sampled.begin(), sp.last_sampled.end(), int64_t{-1});  // (look afresh)
+        }
+        // this frame's set: the boxes sampled within the last kSpecMemory frames, in its layer order
+        if (sp.state == S::kObserving || sp.state == S::kActive) {
+          sp.positions.clear();
+          sp.flags.assign(spec_bytes, 0);
+          bool any_observation = false;
+          for (int position = 0; position < info.n_local_boxes; ++position) {
+            const int64_t last = sp.last_sampled[static_cast<size_t>(plan->local_order[static_cast<size_t>(position)])];
+            any_observation = any_observation || last >= 0;
+            if (last >= 0 && last + avr_renderer::kSpecMemory >= sp.frame) {
+              sp.positions.push_back(position);
+              sp.flags[static_cast<size_t>(position)] = 1;
             }
+          }
+          if (any_observation) {
             sp.sampled_fraction = static_cast<float>(sp.positions.size()) /
                                   static_cast<float>(std::max(info.n_local_boxes, 1));
-            if (sp.sampled_fraction <= r->spec_worth_it && !sp.positions.empty()) {
-              // the set for the march, on the device (frames in flight may still read the old one)
-              drain();
-              hip_ok(hipMemcpy(sp.flags.ptr, sp.host_flags, spec_bytes, hipMemcpyHostToDevice),
-                     "hipMemcpy(speculation flags)");
+            const bool worth_it = sp.sampled_fraction <= r->spec_worth_it && !sp.positions.empty();
+            if (sp.state == S::kObserving && worth_it) {
               sp.state = S::kActive;
+              sp.recent_repairs = sp.recent_frames = 0;
               tuner.restart();  // (a classify pass of a fraction of the boxes: another balance)
-            } else {
+            } else if (sp.state == S::kObserving) {
               sp.state = S::kRejected;
+              sp.asleep_until = sp.frame + avr_renderer::kSpecProbeEvery;
+            } else if (!worth_it) {  // (kActive: the rays reach nearly everything now)
+              sp.state = S::kRejected;
+              sp.asleep_until = sp.frame + avr_renderer::kSpecProbeEvery;
+              tuner.restart();
             }
-          } else {
-            (void)hipGetLastError();  // hipErrorNotReady is not an error here
           }
         }
-        spec_mode = sp.state == S::kActive ? 2 : sp.state == S::kObserving ? 1 : 0;
+        if (sp.state == S::kActive) {
+          spec_mode = 2;
+        } else if (sp.state == S::kObserving && spec_observation != nullptr) {
+          spec_mode = 1;
+          sp.state = S::kDeciding;  // (until this observation has arrived)
+        }
       }
     }
     void* chunk_events[AVR_MAX_FRAME_CHUNKS] = {};
@@ -1482,10 +1560,12 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(1);
     r->stage = "march";
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
-    if (spec_mode == 1) {  // (cleared while the classify pass still runs)
+    const bool spec_observed = spec_mode != 0 && spec_observation != nullptr;
+    if (spec_observed) {  // (cleared while the classify pass still runs)
       hip_ok(hipMemsetAsync(spec_visited, 0, spec_bytes, stream_m), "hipMemsetAsync(speculation)");
-    } else if (spec_mode == 2) {
-      hip_ok(hipMemsetAsync(spec_missed, 0, spec_bytes + 16, stream_m), "hipMemsetAsync(speculation)");
+    }
+    if (spec_mode == 2) {
+      hip_ok(hipMemsetAsync(spec_missed, 0, spec_block, stream_m), "hipMemsetAsync(speculation)");
     }
     if (overlap && !paired && n_chunks == 1) {
       // (paired: the march follows its classify pass on the same stream; chunked: every march
@@ -1500,29 +1580,36 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     } else if (n_chunks > 1) {
       abi_ok(avr_march_plan_chunked(march_ctx, r->scene, plan, volume, send, samples_out, n_chunks,
                                     chunk_events));
-    } else if (spec_mode == 1) {
-      // the observing frame: a plain frame whose march records the boxes it samples; the flags go
-      // to the host behind it (a copy kernel into pinned memory), read a few frames on
-      avr_speculation observing{};
-      observing.visited = spec_visited;
-      abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &observing));
-      abi_ok(avr::launch_upload(spec_visited, sp.host_flags_dev, spec_bytes, stream_m));
-      if (sp.copied == nullptr) sp.copied = make_event(false);
-      hip_ok(hipEventRecord(sp.copied, stream_m), "hipEventRecord");
-      sp.state = avr_renderer::Speculating::kDeciding;
-    } else if (spec_mode == 2) {
+    } else if (spec_mode != 0) {
       avr_speculation first{};
-      first.classified = static_cast<const uint8_t*>(sp.flags.ptr);
-      first.missed = spec_missed;
-      first.miss_count = spec_count;
-      first.host_miss_flag = sp.host_miss_dev;
+      first.visited = spec_observed ? spec_visited : nullptr;
+      if (spec_mode == 2) {
+        first.classified_host = sp.flags.data();
+        first.missed = spec_missed;
+        first.miss_count = spec_count;
+        first.host_miss_flag = sp.host_miss_dev;
+        first.dirty_workgroups = spec_dirty;
+      }
       abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &first));
-      // the repair, queued unconditionally: both launches do nothing unless the march missed
-      abi_ok(avr_classify_plan_flagged(march_ctx, r->scene, plan, volume, spec_missed, spec_count));
-      avr_speculation again{};
-      again.gate = spec_count;
-      abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &again));
-      ++sp.active_frames;
+      if (spec_mode == 2) {
+        // the repair, queued unconditionally: both launches do nothing unless the march missed
+        abi_ok(avr_classify_plan_flagged(march_ctx, r->scene, plan, volume, spec_missed, spec_count));
+        avr_speculation again{};
+        again.visited = first.visited;
+        again.gate = spec_count;
+        again.dirty_workgroups = spec_dirty;  // (only the workgroups that met an unclassified box)
+        abi_ok(avr_march_plan_speculative(march_ctx, r->scene, plan, volume, send, &again));
+        ++sp.active_frames;
+      }
+      if (spec_observed) {
+        // the boxes this frame's rays sampled go to the host (a copy kernel into pinned memory) and
+        // are read a few frames on, by box
+        abi_ok(avr::launch_upload(spec_visited, spec_observation->host_dev, spec_bytes, stream_m));
+        hip_ok(hipEventRecord(spec_observation->copied, stream_m), "hipEventRecord");
+        spec_observation->order = plan->local_order;
+        spec_observation->frame = sp.frame;
+        spec_observation->pending = true;
+      }
     } else {
       abi_ok(avr_march_plan(march_ctx, r->scene, plan, volume, send, samples_out));
     }

@@ -549,6 +549,13 @@ class Scene:
             ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(flags.data_ptr()),
             C.c_void_p(gate.data_ptr()) if gate is not None else None))
 
+    @staticmethod
+    def march_plan_workgroups(plan) -> int:
+        """avr_march_plan_workgroups: an upper bound of the march launch's workgroups."""
+        count = C.c_int64(0)
+        _capi.check(_capi.lib().avr_march_plan_workgroups(plan._handle, C.byref(count)))
+        return int(count.value)
+
     def classify_plan_positions(self, ctx: "Context", plan, slot: int, positions) -> None:
         """avr_classify_plan_positions: the classify pass of the boxes at these (ascending)
         positions of the rank's layer order -- a launch of exactly their tiles."""
@@ -562,7 +569,8 @@ class Scene:
                                visited: Optional[torch.Tensor] = None,
                                missed: Optional[torch.Tensor] = None,
                                miss_count: Optional[torch.Tensor] = None,
-                               gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+                               gate: Optional[torch.Tensor] = None,
+                               dirty_workgroups: Optional[torch.Tensor] = None) -> torch.Tensor:
         """avr_march_plan_speculative: the march that checks `classified` (the flags this frame's
         classify pass was given), records the boxes it samples in `visited` and the ones it needs
         but finds unclassified in `missed` / `miss_count` (uint8 per local box / int32[1])."""
@@ -573,14 +581,26 @@ class Scene:
         for name, tensor, dtype in (("classified", classified, torch.uint8), ("visited", visited, torch.uint8),
                                     ("missed", missed, torch.uint8)):
             if tensor is not None:
-                ctx._check_tensor(tensor, dtype, name)
+                if name == "classified" and not tensor.is_cuda:   # (host flags are allowed here)
+                    if tensor.dtype != dtype:
+                        raise ValueError("classified must be uint8")
+                else:
+                    ctx._check_tensor(tensor, dtype, name)
                 if tensor.numel() < n:
                     raise ValueError(f"{name} needs one entry per local box")
         for name, tensor in (("miss_count", miss_count), ("gate", gate)):
             if tensor is not None:
                 ctx._check_tensor(tensor, torch.int32, name)
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        spec = _capi.Speculation(ptr(classified), ptr(visited), ptr(missed), ptr(miss_count), None, ptr(gate))
+        host = None
+        if classified is not None and not classified.is_cuda:   # (host flags: staged with the launch)
+            host, classified = classified.contiguous(), None
+        if dirty_workgroups is not None:
+            ctx._check_tensor(dirty_workgroups, torch.uint8, "dirty_workgroups")
+            if dirty_workgroups.numel() < self.march_plan_workgroups(plan):
+                raise ValueError("dirty_workgroups is smaller than avr_march_plan_workgroups says")
+        spec = _capi.Speculation(ptr(classified), ptr(visited), ptr(missed), ptr(miss_count), None,
+                                 ptr(gate), ptr(host), ptr(dirty_workgroups))
         _capi.check(_capi.lib().avr_march_plan_speculative(
             ctx._handle, self._handle, plan._handle, int(slot), C.c_void_p(out.data_ptr()),
             C.byref(spec)))
@@ -911,8 +931,8 @@ class NativeRenderer:
         _capi.check(_capi.lib().avr_renderer_debug_set_speculation_threshold(
             self._handle, float(sampled_fraction)))
 
-    _SPECULATION_STATES = {-1: "off", 0: "observing", 1: "deciding", 2: "speculating",
-                           3: "not worth it for this plan", 4: "suspended after a repair"}
+    _SPECULATION_STATES = {-1: "off", 0: "observing", 1: "waiting for an observation",
+                           2: "speculating", 3: "not worth it", 4: "suspended after repairs"}
 
     def speculation_state(self) -> dict:
         """avr_renderer_speculation_state."""

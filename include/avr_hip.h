@@ -424,7 +424,16 @@ typedef struct avr_speculation {
   uint32_t *miss_count;      /* out: raised with every miss */
   uint32_t *host_miss_flag;  /* out, or NULL */
   const uint32_t *gate;      /* NULL, or: the march does nothing unless *gate != 0 */
+  const uint8_t *classified_host; /* instead of `classified`: the same flags in HOST memory, copied
+                                     with the launch's descriptors (a caller who decides per frame) */
+  uint8_t *dirty_workgroups; /* NULL, or device memory of avr_march_plan_workgroups(plan) bytes, cleared
+                                by the caller: the checking march marks the workgroups that met an
+                                unclassified box, the gated march (same pointer) redoes only those --
+                                every other layer pixel is final after the first pass */
 } avr_speculation;
+/* An upper bound of the workgroups of this rank's march launch of the plan: the bytes to give
+ * dirty_workgroups. */
+int avr_march_plan_workgroups(const avr_frame_plan *plan, int64_t *workgroups);
 int avr_classify_plan_flagged(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
                               int slot, const uint8_t *flags, const uint32_t *gate);
 int avr_march_plan_speculative(avr_context *ctx, const avr_scene *scene, const avr_frame_plan *plan,
@@ -758,18 +767,20 @@ int avr_renderer_set_frame_chunks(avr_renderer *renderer, int chunks);
  * not to pay on the configurations of BASELINE.json (profiles/r5_opaque/).  Never changes results. */
 int avr_renderer_set_occlusion_culling(avr_renderer *renderer, int chunks);
 int avr_renderer_last_frame_chunks(const avr_renderer *renderer); /* what the last frame took */
-/* Visibility speculation (avr_classify_plan_flagged / avr_march_plan_speculative; one rank).
- * -1 / 1 (default): a frame whose plan the frames before it had -- a camera that stands still
- * while the cells change, the in-situ case -- classifies only the boxes the march of the frame two
- * before sampled, its march checks every box it needs, and a repair pass (two gated launches that
- * do nothing as a rule) redoes the frame when the guess was wrong: results never change.  Decided
- * per plan from its second frame's flags: taken up when at most 85 % of the rank's boxes were
- * sampled (the reference's default boxTransparency = 0: config-4 samples 58 of 176 boxes, the
- * classify pass takes 0.24 instead of 0.57 ms), dropped for the plan otherwise (a translucent frame
- * pays nothing); a frame that needed a repair suspends it for 64 frames.  0: never.
- * avr_renderer_speculation_state: state -1 off / 0 observing / 1 deciding / 2 speculating /
- * 3 not worth it for this plan / 4 suspended after a repair; frames speculated and repaired so far;
- * the fraction of boxes the deciding frame sampled (-1: not decided). */
+/* Visibility speculation (avr_classify_plan_positions / avr_march_plan_speculative; one rank).
+ * -1 / 1 (default): the driver remembers, per box, the last frame whose rays sampled it (a march
+ * that records the boxes it samples, the flags read on the host a few frames later); while at most
+ * 85 % of the rank's boxes were sampled in the last 24 frames, a frame classifies only those, its
+ * march checks every box it needs, and a repair pass (two gated launches that do nothing as a
+ * rule) redoes the frame when the set was wrong -- the cells changed, the camera turned: results
+ * never change.  The reference's default boxTransparency = 0: config-4's rays sample 58 of 176
+ * boxes, the classify pass takes 0.18 instead of 0.55 ms, the frame 0.43 instead of 0.63.  A
+ * translucent frame (every box sampled) is observed once and then left alone but for one observing
+ * frame in 512; repairs in more than a quarter of the frames suspend it (64 frames, doubling).
+ * 0: never.
+ * avr_renderer_speculation_state: state -1 off / 0 observing / 1 waiting for an observation /
+ * 2 speculating / 3 not worth it (asleep) / 4 suspended after repairs; frames speculated and
+ * repaired so far; the fraction of boxes in the present set (-1: nothing observed yet). */
 int avr_renderer_set_visibility_speculation(avr_renderer *renderer, int mode);
 int avr_renderer_speculation_state(const avr_renderer *renderer, int *state,
                                    int64_t *speculative_frames, int64_t *repaired_frames,

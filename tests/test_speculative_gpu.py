@@ -32,19 +32,25 @@ def _plain(ctx, scene, plan, slot):
     return want
 
 
-def _speculative(ctx, scene, plan, slot, flags):
-    """The protocol of include/avr_hip.h: flagged classify, checking march, gated repair."""
+def _speculative(ctx, scene, plan, slot, flags, dirty=False):
+    """The protocol of include/avr_hip.h: flagged classify, checking march, gated repair (dirty:
+    the repair redoes only the workgroups that met an unclassified box)."""
     n = max(len(scene.boxes), 1)
+    marks = (torch.zeros(scene.march_plan_workgroups(plan), dtype=torch.uint8, device=ctx.device)
+             if dirty else None)
     got = torch.full((max(plan.send_floats, 1),), float("nan"), device=ctx.device)
     visited = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
     missed = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
     miss_count = torch.zeros(1, dtype=torch.int32, device=ctx.device)
     scene.classify_plan_flagged(ctx, plan, slot, flags)
     scene.march_plan_speculative(ctx, plan, slot, got, classified=flags, visited=visited,
-                                 missed=missed, miss_count=miss_count)
+                                 missed=missed, miss_count=miss_count, dirty_workgroups=marks)
     scene.classify_plan_flagged(ctx, plan, slot, missed, gate=miss_count)
-    scene.march_plan_speculative(ctx, plan, slot, got, visited=visited, gate=miss_count)
+    scene.march_plan_speculative(ctx, plan, slot, got, visited=visited, gate=miss_count,
+                                 dirty_workgroups=marks)
     ctx.synchronize()
+    if marks is not None and int(miss_count.item()) > 0:
+        assert 0 < int(marks.sum().item()) <= marks.numel()
     return got, visited, missed, int(miss_count.item())
 
 
@@ -95,14 +101,24 @@ def test_speculative_frame_equals_the_plain_frame(ctx, n_ranks, policy, transpar
             ctx.synchronize()
             assert torch.equal(listed.view(torch.int32), want.view(torch.int32)), (view, r)
             assert int(count.item()) == 0, (view, r)
+            # ... with the flags handed over in host memory (staged with the launch)
+            scene.classify_plan(ctx, other, 1)
+            scene.classify_plan_positions(ctx, plan, 1, torch.nonzero(visited.cpu()).flatten().tolist())
+            hosted = torch.full_like(want, float("nan"))
+            scene.march_plan_speculative(ctx, plan, 1, hosted, classified=visited.cpu(), missed=missed,
+                                         miss_count=count)
+            ctx.synchronize()
+            assert torch.equal(hosted.view(torch.int32), want.view(torch.int32)), (view, r)
+            assert int(count.item()) == 0, (view, r)
             if int((visited == 0).sum().item()) > 0:
                 left_out = True
     if transparency == 0.0 and n_ranks == 1:   # (a rank of several folds short runs: little to hide)
         assert left_out, "an opaque frame sampled every box"
 
 
+@pytest.mark.parametrize("dirty", [False, True])
 @pytest.mark.parametrize("guess", ["nothing", "front_only", "random"])
-def test_a_wrong_guess_is_repaired(ctx, guess):
+def test_a_wrong_guess_is_repaired(ctx, guess, dirty):
     """Flags that leave out boxes the frame needs (the cells changed since the frame they come
     from): the march raises them, the gated repair pass classifies them and marches again."""
     W, H = 170, 130
@@ -134,7 +150,7 @@ def test_a_wrong_guess_is_repaired(ctx, guess):
                           scenes.orbit_camera(9, 16), 0, 1)
         scene.classify_plan(ctx, other, 1)   # poison
         got, visited, missed, misses = _speculative(ctx, scene, plan, 1,
-                                                    torch.from_numpy(flags).to(ctx.device))
+                                                    torch.from_numpy(flags).to(ctx.device), dirty)
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (guess, transparency)
         lacking = needed & (flags == 0)
         assert (misses > 0) == bool(lacking.any()), (guess, transparency, misses)
@@ -223,7 +239,8 @@ def test_driver_speculates_on_a_standing_camera_and_repairs_after_the_cells_chan
             assert _same(frame, want_changed), f
         state = guessing.native.speculation_state()
         assert state["repaired_frames"] >= 1, state
-        assert state["state"] in ("suspended after a repair", "speculating"), state
+        # (with every box in view now the driver gives the guessing up: "not worth it")
+        assert state["state"] in ("suspended after repairs", "speculating", "not worth it"), state
     finally:
         for box, cells in zip(local, saved):
             box.values.copy_(cells)
@@ -249,7 +266,7 @@ def test_driver_leaves_translucent_frames_and_moving_cameras_alone(ctx):
     for f, frame in enumerate(frames):
         assert _same(frame, want), f
     state = guessing.native.speculation_state()
-    assert state["state"] == "not worth it for this plan" and state["speculative_frames"] == 0, state
+    assert state["state"] == "not worth it" and state["speculative_frames"] == 0, state
     # a camera that never repeats: no plan has a frame to guess from
     opaque = RenderParameters(320, 200, 0.0, 1, draw_bounds=False)
     cams = [scenes.orbit_camera(v, 12) for v in range(6)]
@@ -260,3 +277,29 @@ def test_driver_leaves_translucent_frames_and_moving_cameras_alone(ctx):
     for f in range(len(cams)):
         assert _same(got[f], want[f]), f
     assert guessing.native.speculation_state()["speculative_frames"] == 0
+
+
+def test_driver_carries_what_it_learnt_to_a_moving_camera(ctx):
+    """The memory is per box, not per plan: a camera that turns a little every frame keeps the set,
+    boxes that come into view are missed once (and repaired), then remembered."""
+    spec, local, fresh, RenderParameters = _renderer_scene(ctx)
+    p = RenderParameters(320, 200, 0.0, 1, draw_bounds=False)
+    cams = [scenes.orbit_camera(v, 240) for v in range(40)]          # 1.5 degrees per frame
+    plain = fresh(0)
+    want = [plain.render(p, c, want_image=True) for c in cams]
+    plain.synchronize()
+    guessing = fresh(-1)
+    got = [guessing.render(p, c, want_image=True) for c in cams]
+    guessing.synchronize()
+    for f in range(len(cams)):
+        assert _same(got[f], want[f]), f
+    state = guessing.native.speculation_state()
+    assert state["speculative_frames"] > 0, state
+    # ... and a jump to the other side of the volume: whatever the set lacks is repaired
+    far = [scenes.orbit_camera(v, 240) for v in (120, 121, 122, 200, 60)]
+    want = [plain.render(p, c, want_image=True) for c in far]
+    plain.synchronize()
+    for f, c in enumerate(far):
+        frame = guessing.render(p, c, want_image=True)
+        guessing.synchronize()
+        assert _same(frame, want[f]), f

@@ -60,6 +60,8 @@ PY
   run config4_translucent || exit 1
   run config4_opaque --transparency 0.0 || exit 1
   run config4_opaque_every_box --transparency 0.0 --no-speculation || exit 1
+  run config4_opaque_fly_through --transparency 0.0 --fly-through || exit 1
+  run config4_opaque_orbit16 --transparency 0.0 --orbit 16 || exit 1
   run config4_noise_field --field noise || exit 1
   run config4_orbit16 --orbit 16 || exit 1
   run config4_fly_through --fly-through || exit 1
