@@ -756,7 +756,8 @@ def run(args, state):
     # BASELINE's configurations are all of one size, so the fraction of boxes is that of the cells)
     speculation = renderer.native.speculation_state() if native else None
     classified_fraction = (speculation["sampled_fraction"]
-                           if speculation and speculation["state"] == "speculating" else 1.0)
+                           if speculation and speculation["state"] == "speculating"
+                           and speculation["sampled_fraction"] is not None else 1.0)
     roofline = {
         "bound": "hbm", "kernel": "classify_kernel + render_runs_kernel (the paint stage of one frame)",
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
