@@ -293,6 +293,7 @@ struct avr_renderer {
   static constexpr int kSpecMemory = 24;       // frames a box stays in the set after it was last sampled
   static constexpr int kSpecProbeEvery = 512;  // kRejected: one observing frame in so many
   float spec_worth_it = 0.85f;  // (avr_renderer_debug_set_speculation_threshold: tests)
+  double spec_min_saving_ms = 0.15;  // (... sets it to 0 with any threshold: small test scenes)
   bool marched_pending[AVR_CLASSIFIED_SLOTS] = {}, composed_pending[AVR_CLASSIFIED_SLOTS] = {};
   unsigned frame = 0;
 
@@ -797,6 +798,7 @@ int avr_renderer_debug_set_speculation_threshold(avr_renderer* r, float sampled_
     require(sampled_fraction >= 0.0f && sampled_fraction <= 1.0f, "the fraction must be in [0, 1]");
     r->drain_all();
     r->spec_worth_it = sampled_fraction;
+    r->spec_min_saving_ms = 0.0;
     r->spec.forget();
     return AVR_OK;
   });
@@ -1416,7 +1418,7 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     int spec_mode = 0;
     {
       using S = avr_renderer::Speculating;
-      if (spec_considered && n_chunks == 1 && !paired) {
+      if (spec_considered && n_chunks == 1) {  // (any layout: one stream or two, the protocol is the same)
         const bool missed_lately = *static_cast<volatile uint32_t*>(sp.host_miss) != 0;
         if (missed_lately) {  // a march of an earlier frame missed (its repair redid that frame)
           *static_cast<volatile uint32_t*>(sp.host_miss) = 0;
@@ -1456,7 +1458,20 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
           if (any_observation) {
             sp.sampled_fraction = static_cast<float>(sp.positions.size()) /
                                   static_cast<float>(std::max(info.n_local_boxes, 1));
-            const bool worth_it = sp.sampled_fraction <= r->spec_worth_it && !sp.positions.empty();
+            // Worth it when the part of the classify pass it removes outweighs what it adds (two
+            // gated launches and two memsets on the march's stream, ~20 us, and a march that holds a
+            // wave per SIMD less): the rank's cells at ~5 TB/s, the unsampled share of that -- at
+            // least kSpecMinSavingMs.  (config-4 opaque 0.39 ms saved: frame 0.63 -> 0.43; config-3
+            // opaque 0.14, config-2 0.06: 1-2 % SLOWER when tried, their frames are march-bound.)
+            double cell_bytes = 0.0;
+            for (size_t b = 0; b < r->all_boxes.size(); ++b) {
+              if (r->owner[b] != r->rank) continue;
+              const avr_box& box = r->all_boxes[b];
+              cell_bytes += 8.0 * box.dims[0] * box.dims[1] * box.dims[2];
+            }
+            const double saving_ms = (1.0 - sp.sampled_fraction) * cell_bytes / 5.0e9;
+            const bool worth_it = sp.sampled_fraction <= r->spec_worth_it && !sp.positions.empty() &&
+                                  saving_ms >= r->spec_min_saving_ms;
             if (sp.state == S::kObserving && worth_it) {
               sp.state = S::kActive;
               sp.recent_repairs = sp.recent_frames = 0;

@@ -770,7 +770,8 @@ int avr_renderer_last_frame_chunks(const avr_renderer *renderer); /* what the la
 /* Visibility speculation (avr_classify_plan_positions / avr_march_plan_speculative; one rank).
  * -1 / 1 (default): the driver remembers, per box, the last frame whose rays sampled it (a march
  * that records the boxes it samples, the flags read on the host a few frames later); while at most
- * 85 % of the rank's boxes were sampled in the last 24 frames, a frame classifies only those, its
+ * 85 % of the rank's boxes were sampled in the last 24 frames (and the classify work that saves is
+ * worth 0.15 ms: not the short, march-bound frames of config-2 / config-3), a frame classifies only those, its
  * march checks every box it needs, and a repair pass (two gated launches that do nothing as a
  * rule) redoes the frame when the set was wrong -- the cells changed, the camera turned: results
  * never change.  The reference's default boxTransparency = 0: config-4's rays sample 58 of 176

@@ -39,7 +39,8 @@ int avr_renderer_corun_history(const avr_renderer *renderer, int16_t *candidates
 
 /* The fraction of a rank's boxes a plan's deciding frame may have sampled for the driver to take
  * up visibility speculation (avr_renderer_set_visibility_speculation; default 0.85): the tests set
- * it to 1 so that small scenes, whose rays reach nearly every box, exercise the machinery. */
+ * it to 1 so that small scenes, whose rays reach nearly every box, exercise the machinery (the call
+ * also drops the other condition: that the classify work saved is worth at least 0.15 ms). */
 int avr_renderer_debug_set_speculation_threshold(avr_renderer *renderer, float sampled_fraction);
 
 #ifdef __cplusplus
