@@ -267,6 +267,7 @@ struct avr_renderer {
       std::vector<int32_t> order;          // position -> local box of that frame's plan
       int64_t frame = 0;
       bool pending = false;
+      bool stale = false;                  // taken under settings that are gone: ignored when it arrives
     };
     static constexpr int kObservations = 4;
     Observation observations[kObservations];
@@ -280,7 +281,7 @@ struct avr_renderer {
       last_sampled.clear();
       state = kObserving;
       sampled_fraction = -1.0f;
-      for (Observation& o : observations) o.pending = false;  // (their flags are of the old settings)
+      for (Observation& o : observations) o.stale = o.pending;  // (their flags are of the old settings)
     }
     ~Speculating() {
       for (Observation& o : observations) {
@@ -1170,14 +1171,17 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
           break;
         }
         oldest->pending = false;
-        if (oldest->order.size() != sp.last_sampled.size()) continue;
+        if (sp.state == avr_renderer::Speculating::kDeciding) sp.state = avr_renderer::Speculating::kObserving;
+        if (oldest->stale || oldest->order.size() != sp.last_sampled.size()) {
+          oldest->stale = false;
+          continue;
+        }
         for (size_t position = 0; position < oldest->order.size(); ++position) {
           if (oldest->host[position] != 0) {
             int64_t& last = sp.last_sampled[static_cast<size_t>(oldest->order[position])];
             last = std::max(last, oldest->frame);
           }
         }
-        if (sp.state == avr_renderer::Speculating::kDeciding) sp.state = avr_renderer::Speculating::kObserving;
         sp.sampled_fraction = -2.0f;  // (to be counted below)
       }
       // a free observation slot for this frame (none: the host is far ahead, this frame is not observed)

@@ -303,3 +303,22 @@ def test_driver_carries_what_it_learnt_to_a_moving_camera(ctx):
         frame = guessing.render(p, c, want_image=True)
         guessing.synchronize()
         assert _same(frame, want[f]), f
+
+
+def test_driver_forgets_what_it_learnt_when_the_transfer_function_changes(ctx):
+    """Another scalar range maps the cells to other opacities: what was sampled under the old one says
+    nothing (observations still in flight are ignored when they arrive)."""
+    spec, local, fresh, RenderParameters = _renderer_scene(ctx)
+    p = RenderParameters(320, 200, 0.0, 1, draw_bounds=False)
+    cam = scenes.orbit_camera(2, 12)
+    plain, guessing = fresh(0), fresh(-1)
+    for scalar_range in (spec.scalar_range, (0.2, 0.6), (0.0, 0.3), spec.scalar_range):
+        plain.scalar_range = scalar_range
+        guessing.scalar_range = scalar_range     # (no synchronise: frames of the old range in flight)
+        want = plain.render(p, cam, want_image=True)
+        plain.synchronize()
+        frames = [guessing.render(p, cam, want_image=True) for _ in range(9)]
+        guessing.synchronize()
+        for f, frame in enumerate(frames):
+            assert _same(frame, want), (scalar_range, f)
+    assert guessing.native.speculation_state()["speculative_frames"] > 0
