@@ -69,6 +69,7 @@ PY
   run config2_translucent --config config2 || exit 1
   run config2_opaque --config config2 --transparency 0.0 || exit 1
   run config5_translucent --config config5 --antialiasing 4 --steps 20 --warmup 3 || exit 1
+  run config5_opaque --config config5 --antialiasing 4 --transparency 0.0 --steps 20 --warmup 3 || exit 1
 fi
 if [ "$part" = latency ]; then
   : > $out/latency.txt
