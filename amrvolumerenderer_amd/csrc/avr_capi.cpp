@@ -136,7 +136,12 @@ void wait_stream(hipStream_t stream, const char* what) { wait_stream_deadline(st
 // without waiting (a block is re-used only after the copy that read it has completed).
 class StagingRing {
  public:
-  static constexpr int kSlots = 4;
+  // Nine: a speculative frame (avr_renderer.cpp) stages three batches on the march's context -- the
+  // checking march, the gated classify pass, the gated march -- whose flag buffers rotate with the
+  // frame's slot, so the batches repeat with period nine: every slot then always sees the same
+  // batch (not copied again, below), and the host may run three such frames ahead.  (With four the
+  // host waited 0.38 ms per frame here for a block of the frame before.)
+  static constexpr int kSlots = 9;
   static constexpr size_t kAlign = 256;
 
   ~StagingRing() { release(); }
