@@ -160,7 +160,19 @@ class StagingRing {
   void set_lean(bool lean) { lean_ = lean; }
 
   // Starts a batch with room for `bytes` in `items` arrays.
+  // How many batches the host may run ahead of the consumer (1 .. kSlots; default 4: what the
+  // ring was when it had four blocks -- the frame driver's feedback loops, the co-run search among
+  // them, are timed for that lead; a speculating march context takes all nine).
+  void set_ahead(int batches) { ahead_ = std::min(std::max(batches, 1), kSlots); }
+
   void begin(size_t bytes, int items) {
+    if (ahead_ < kSlots) {
+      Slot& behind = slots_[(next_ + kSlots - ahead_) % kSlots];
+      if (behind.pending) {
+        wait_event(behind.done, "hipEventQuery(staging)");
+        behind.pending = false;
+      }
+    }
     current_ = &slots_[next_];
     next_ = (next_ + 1) % kSlots;
     if (current_->done == nullptr) {
@@ -252,6 +264,7 @@ class StagingRing {
     std::vector<char> shadow;       // what the device twin holds (host copy of the last batch copied)
   };
   bool lean_ = false;
+  int ahead_ = 4;
   Slot slots_[kSlots];
   Slot* current_ = nullptr;
   int next_ = 0;
@@ -729,6 +742,7 @@ void context_set_classify_stream_stores(avr_context* ctx, bool stream) {
   ctx->classify_stream_stores = stream;
 }
 void context_set_lean_descriptors(avr_context* ctx, bool lean) { ctx->staging.set_lean(lean); }
+void context_set_descriptor_lead(avr_context* ctx, int batches) { ctx->staging.set_ahead(batches); }
 void context_set_fold_whole_grid(avr_context* ctx, bool whole) { ctx->fold_whole_grid = whole; }
 }  // namespace avr
 

@@ -135,10 +135,13 @@ struct CoRunTuner {
   bool b_final = false;          // the bracket has closed: the finalists are being timed
   int finalists[5] = {0, 0, 0, 0, 0}, n_finalists = 0, b_final_at = 0;
   float finalist_ms[5] = {0, 0, 0, 0, 0};
-  static constexpr float kPlayoffWithin = 1.04f;
+  static constexpr float kPlayoffWithin = 1.06f;
+  static constexpr float kPlayoffDecided = 0.025f;  // of the smaller sum of readings
+  static constexpr int kPlayoffReadings = 4;        // per finalist at most (the first one included)
   static constexpr int kPlayoffFrames = 4;
-  bool b_playoff = false;        // the two best finalists are being timed once more
-  float playoff_first_ms[2] = {0, 0};
+  bool b_playoff = false;        // the two best finalists are being read again
+  float playoff_sum_ms[2] = {0, 0};
+  int playoff_readings = 0;
   int b_reports = 0;
   float b_classify = 0.0f, b_march = 0.0f;
   void set_balance(bool allowed) {
@@ -196,9 +199,11 @@ struct CoRunTuner {
       for (int i = 0; i < n_finalists; ++i) {
         if (i != chosen && (second < 0 || finalist_ms[i] < finalist_ms[second])) second = i;
       }
-      // A close call (four frames after three are good to a few per cent; the pockets beside the
-      // best reserve are 4-8 % slower): within 4 % the two are timed once more, in ascending order, and the
-      // sums decide -- once.
+      // A close call (a reading of four frames after three is good to 2-3 %; the pockets beside the
+      // best reserve are 4-8 % slower, so one reading each orders the two wrongly one time in
+      // eight): within 6 % the best two are read again, in ascending order, until their means
+      // differ by 2.5 % or each has four readings -- a sequential test: clear cases cost nothing,
+      // and only the ambiguous ones the frames.
       if (!b_playoff && second >= 0 && finalist_ms[second] < finalist_ms[chosen] * kPlayoffWithin) {
         b_playoff = true;
         const int lo = std::min(chosen, second), hi = std::max(chosen, second);
@@ -207,14 +212,25 @@ struct CoRunTuner {
         n_finalists = 2;
         for (int i = 0; i < 2; ++i) {
           finalists[i] = pair[i];
-          playoff_first_ms[i] = pair_ms[i];
+          playoff_sum_ms[i] = pair_ms[i];
         }
+        playoff_readings = 1;
         b_final_at = 0;
         begin_balance_step(finalists[0]);
         return;
       }
       if (b_playoff) {
-        chosen = (finalist_ms[0] + playoff_first_ms[0] <= finalist_ms[1] + playoff_first_ms[1]) ? 0 : 1;
+        playoff_sum_ms[0] += finalist_ms[0];
+        playoff_sum_ms[1] += finalist_ms[1];
+        ++playoff_readings;
+        const float gap = std::fabs(playoff_sum_ms[0] - playoff_sum_ms[1]);
+        if (gap < kPlayoffDecided * std::min(playoff_sum_ms[0], playoff_sum_ms[1]) &&
+            playoff_readings < kPlayoffReadings) {
+          b_final_at = 0;
+          begin_balance_step(finalists[0]);
+          return;
+        }
+        chosen = playoff_sum_ms[0] <= playoff_sum_ms[1] ? 0 : 1;
       }
       best = candidate = finalists[chosen];
       best_beside = best;

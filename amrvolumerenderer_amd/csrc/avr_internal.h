@@ -434,6 +434,8 @@ void context_set_lean_descriptors(avr_context* ctx, bool lean);
 // One rank's fold normally takes one workgroup per CU (it runs beside the next frame's paint
 // kernels); `whole`: the next fold of this context takes the whole grid (nothing else is running).
 void context_set_fold_whole_grid(avr_context* ctx, bool whole);
+// How many descriptor batches the host may stage ahead of the context's stream (1 .. 9; default 4).
+void context_set_descriptor_lead(avr_context* ctx, int batches);
 // Whether the context's classify passes stream their bricklets to memory (RenderLaunch).
 void context_set_classify_stream_stores(avr_context* ctx, bool stream);
 

@@ -1583,6 +1583,8 @@ int avr_renderer_render(avr_renderer* r, const avr_render_params* render, const 
     lap(1);
     r->stage = "march";
     // ---- stream M: march into send buffer `slot` ------------------------------------------------
+    // (three batches of descriptors per speculating frame on the march's context: the whole ring)
+    avr::context_set_descriptor_lead(march_ctx, spec_mode == 2 ? 9 : 4);
     // (a speculating frame is observed -- a memset, a copy kernel and an event more on the march's
     // stream -- every time while the camera moves or a repair was needed lately: what comes into
     // view is then in the set two or three frames later; every kSpecObserveEvery-th time while the
