@@ -49,3 +49,24 @@ def device_box(ctx, cells: np.ndarray, min_corner, max_corner, level=0, owner=0)
 
 def scene_cells(spec):
     return [scenes.box_cells_numpy(spec, i) for i in range(len(spec.boxes))]
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(worker, nprocs: int, args_for_port) -> None:
+    """torch.multiprocessing.spawn with a rendezvous port probed here.  Between the probe and rank
+    0's bind the kernel may hand the port to somebody else (EADDRINUSE: seen once in some thirty
+    runs of the suite); that attempt has queued nothing yet and is made again on another port."""
+    import torch.multiprocessing as mp
+    for attempt in range(4):
+        try:
+            mp.spawn(worker, args=args_for_port(free_port()), nprocs=nprocs, join=True)
+            return
+        except Exception as error:   # (mp.ProcessRaisedException carries the rank's traceback as text)
+            if "EADDRINUSE" not in str(error) or attempt == 3:
+                raise

@@ -14,6 +14,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from helpers import spawn_ranks
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, TRANSPARENCY = 75, 43, 0.8
 
@@ -90,8 +92,7 @@ def _free_port():
                                                 (3, "block", [2, 0, 1])])
 def test_directsend_over_gloo(tmp_path, O, avr_lib, world, policy, group):
     out = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(world, _free_port(), policy, group, str(out)), nprocs=world,
-             join=True)
+    spawn_ranks(_worker, world, lambda port: (world, port, policy, group, str(out)))
     ok, ok8, runs = out.read_text().split()
     assert ok == "1", "gathered float image differs from the oracle's layered compose"
     assert ok8 == "1", "gathered RGB8 bytes differ"
@@ -149,6 +150,6 @@ def test_plan_agreement_over_the_callers_control_plane(tmp_path, avr_lib):
         name = f"/avr_control_{os.getpid()}_{world}"
         out_dir = tmp_path / str(world)
         out_dir.mkdir()
-        mp.spawn(_control_worker, args=(world, _free_port(), name, str(out_dir)), nprocs=world, join=True)
+        spawn_ranks(_control_worker, world, lambda port: (world, port, name, str(out_dir)))
         for rank in range(world):
             assert (out_dir / f"rank{rank}.txt").read_text() == "1 1 1 1", (world, rank)

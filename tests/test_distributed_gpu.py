@@ -11,6 +11,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from helpers import spawn_ranks
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H = 120, 72
@@ -75,7 +77,7 @@ def _free_port():
 @pytest.mark.parametrize("policy,antialiasing", [("morton", 1), ("round_robin", 4)])
 def test_three_ranks_on_one_gpu(tmp_path, policy, antialiasing):
     out = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(3, _free_port(), policy, antialiasing, str(out)), nprocs=3, join=True)
+    spawn_ranks(_worker, 3, lambda port: (3, port, policy, antialiasing, str(out)))
     ok, ok8 = out.read_text().split()
     assert ok == "1", "rank 0's frame differs from the oracle's 3-rank compose"
     assert ok8 == "1", "RGB8 bytes differ"
@@ -135,7 +137,7 @@ def test_rccl_collectives_with_one_rank(tmp_path):
     pieces into views, three streams, process-group stream ordering) on a one-rank "nccl" group:
     the only RCCL configuration a one-GPU box can run."""
     out = tmp_path / "result.txt"
-    mp.spawn(_rccl_worker, args=(_free_port(), str(out)), nprocs=1, join=True)
+    spawn_ranks(_rccl_worker, 1, lambda port: (port, str(out)))
     flags = out.read_text().split()
     assert flags and all(f == "1" for f in flags), flags
 
@@ -174,7 +176,7 @@ def test_two_ranks_render_a_plotfile(tmp_path):
     plot = str(tmp_path / "plt_two")
     pf.write_plotfile(plot, ["density", "noise"], levels, (0.0, 0.0, 0.0), (2.0, 2.0, 2.0), [2])
     out = str(tmp_path / "frame.ppm")
-    mp.spawn(_plotfile_worker, args=(2, _free_port(), plot, out), nprocs=2, join=True)
+    spawn_ranks(_plotfile_worker, 2, lambda port: (2, port, plot, out))
 
     W, H, scale = 80, 56, 0.5
     convex = pf.convexify([lev["boxes"] for lev in levels], [2])
@@ -358,9 +360,7 @@ def test_native_driver_across_processes(tmp_path, world, policy, antialiasing, b
     oracle's N-rank compose bit for bit."""
     out = tmp_path / "result.txt"
     name = f"/avr_test_{os.getpid()}_{world}_{antialiasing}_{int(bytes_only)}_{int(contiguous)}"
-    mp.spawn(_native_worker, args=(world, _free_port(), policy, antialiasing, name, str(out),
-                                   bytes_only, contiguous),
-             nprocs=world, join=True)
+    spawn_ranks(_native_worker, world, lambda port: (world, port, policy, antialiasing, name, str(out), bytes_only, contiguous))
     flags = out.read_text().split()
     assert len(flags) == 6 and all(f == "1" for f in flags), flags
 
@@ -449,8 +449,7 @@ def test_ranks_fail_fast_instead_of_hanging(tmp_path, mode):
       return an error naming rank, frame, stage and co-run state; the renderer is failed for good."""
     world = 3
     name = f"/avr_failfast_{os.getpid()}_{mode}"
-    mp.spawn(_failfast_worker, args=(world, _free_port(), name, mode, str(tmp_path)),
-             nprocs=world, join=True)
+    spawn_ranks(_failfast_worker, world, lambda port: (world, port, name, mode, str(tmp_path)))
     for rank in range(world):
         error, elapsed, failed, later, rounds = (tmp_path / f"rank{rank}.txt").read_text().split("\n")
         if mode == "different_plan":
@@ -528,8 +527,7 @@ def test_ranks_search_their_corun_layout_as_one_system(tmp_path):
     import json
     world, frames = 4, 400
     name = f"/avr_lockstep_{os.getpid()}"
-    mp.spawn(_lockstep_worker, args=(world, _free_port(), name, frames, str(tmp_path)),
-             nprocs=world, join=True)
+    spawn_ranks(_lockstep_worker, world, lambda port: (world, port, name, frames, str(tmp_path)))
     got = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
     assert all(g["same"] for g in got)
     assert len(got[0]["history"]) == frames
