@@ -5,14 +5,12 @@ device work (run layers -> send buffer, receiver fold) is supplied by an oracle-
 what is under test is the host logic: plan, split sizes, buffer routing, piece ownership,
 gather order."""
 import os
-import socket
 import sys
 
 import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from helpers import spawn_ranks
 
@@ -80,12 +78,6 @@ def _worker(rank, world, port, policy, group, out_path):
             assert full is None and full8 is None
     finally:
         dist.destroy_process_group()
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 @pytest.mark.parametrize("world,policy,group", [(2, "morton", None), (2, "round_robin", [1, 0]),

@@ -3,13 +3,11 @@ each owning a third of the boxes, run FrameRenderer.render with the HIP kernels 
 over gloo through host copies (RCCL cannot place two ranks on one device).  Rank 0's frame must
 be bit-identical to the oracle's 3-rank layered compose."""
 import os
-import socket
 import sys
 
 import numpy as np
 import pytest
 import torch
-import torch.multiprocessing as mp
 
 from helpers import spawn_ranks
 
@@ -66,12 +64,6 @@ def _worker(rank, world, port, policy, antialiasing, out_path):
             assert image is None and rgb8 is None
     finally:
         dist.destroy_process_group()
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 @pytest.mark.parametrize("policy,antialiasing", [("morton", 1), ("round_robin", 4)])
