@@ -322,3 +322,49 @@ def test_driver_forgets_what_it_learnt_when_the_transfer_function_changes(ctx):
         for f, frame in enumerate(frames):
             assert _same(frame, want), (scalar_range, f)
     assert guessing.native.speculation_state()["speculative_frames"] > 0
+
+
+def test_soak_random_cameras_and_changing_cells(ctx):
+    """150 frames of a guessing driver against a plain one on the same data, in bursts of five
+    queued frames: the camera stands, turns a little or jumps, and between bursts, now and then, a
+    random third of the boxes turns transparent or back -- every frame's image and bytes are the
+    plain frame's."""
+    spec, local, fresh, RenderParameters = _renderer_scene(ctx)
+    p = RenderParameters(256, 160, 0.0, 1, draw_bounds=False)
+    plain, guessing = fresh(0), fresh(-1)
+    rng = np.random.default_rng(11)
+    original = [box.values.clone() for box in local]
+    transparent = set()
+    view = 0
+    try:
+        for burst in range(30):
+            if burst % 5 == 4:      # (nothing is in flight: the bursts end synchronised)
+                for b in rng.choice(len(local), size=len(local) // 3, replace=False):
+                    if b in transparent:
+                        local[b].values.copy_(original[b])
+                        transparent.discard(b)
+                    else:
+                        local[b].values.fill_(float(spec.scalar_range[0]))
+                        transparent.add(b)
+                torch.cuda.synchronize()
+            cams = []
+            for _ in range(5):
+                move = rng.random()
+                if 0.5 <= move < 0.9:
+                    view = (view + 1) % 240                  # turns 1.5 degrees
+                elif move >= 0.9:
+                    view = int(rng.integers(0, 240))         # jumps
+                cams.append(scenes.orbit_camera(view, 240))  # (else: the camera stands)
+            want = [plain.render(p, cam, want_image=True) for cam in cams]
+            got = [guessing.render(p, cam, want_image=True) for cam in cams]
+            plain.synchronize()
+            guessing.synchronize()
+            for f in range(5):
+                assert _same(got[f], want[f]), (burst, f)
+        state = guessing.native.speculation_state()
+        assert state["speculative_frames"] > 0, state
+    finally:
+        torch.cuda.synchronize()
+        for box, cells in zip(local, original):
+            box.values.copy_(cells)
+        torch.cuda.synchronize()
