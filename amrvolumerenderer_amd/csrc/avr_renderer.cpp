@@ -70,8 +70,10 @@ struct DeviceBuffer {
   template <typename Drain>
   void* reserve(size_t bytes, Drain&& drain) {
     if (bytes > capacity) {
-      drain();
-      if (ptr != nullptr) (void)hipFree(ptr);
+      if (ptr != nullptr) {  // (a first allocation replaces nothing a frame in flight could read)
+        drain();
+        (void)hipFree(ptr);
+      }
       ptr = nullptr;
       capacity = 0;
       const size_t want = bytes + bytes / 4 + 256;
