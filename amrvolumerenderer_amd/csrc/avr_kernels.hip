@@ -34,6 +34,15 @@ namespace avr {
 namespace {
 
 constexpr int kBlockThreads = 256;  // workgroup = kTile x kTile pixels = 4 waves of 8x8
+// Samples per trip of the march's interior loop: a deep loop first (that many loads in flight per
+// wave, that many samples' registers), then the loop of four.  Eight: config-4's march alone 0.657
+// -> 0.603 ms and the pipelined frame 0.931 -> 0.874 (round 5, after the side-by-side counters showed
+// that a SIMD's wave slots bind, not its registers: profiles/r5_corun_counters/); 6: 0.618 / 0.895,
+// 10: 0.630 / 0.888, 12: 0.633 / 0.884, 16: 0.712 / 0.919, 4 (no deep loop): 0.657 / 0.931.
+// Power-of-two spacings only (every BASELINE configuration); other boxes take the loop of four.
+#ifndef AVR_MARCH_GROUP
+#define AVR_MARCH_GROUP 8
+#endif
 
 #define AVR_INF __builtin_huge_valf()
 
@@ -278,6 +287,89 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     float_pair nx2 = {box.nmin_inv[0], box.nmin_inv[0]}, ny2 = {box.nmin_inv[1], box.nmin_inv[1]},
                nz2 = {box.nmin_inv[2], box.nmin_inv[2]};
     if (MODE == kPow2Multiply) asm volatile("" : "+v"(nx2), "+v"(ny2), "+v"(nz2));
+#if AVR_MARCH_GROUP > 4
+    // kDeep (8, 12 ...) steps per trip while all of them lie below safe_end: several groups' worth
+    // of cell bytes and table entries in flight per wave.  Side by side with the classify pass a
+    // SIMD's eight wave slots bind, not its registers, and a wave's throughput is one memory round
+    // trip per trip of this loop (profiles/r5_corun_counters/): more loads per trip is what a wave
+    // can still give.  Every sample is accumulated by the same operations in the same order as
+    // below; what is left takes the loop of four, then the general loop.
+    if (MODE == kPow2Multiply) {
+      constexpr int kDeep = AVR_MARCH_GROUP;
+      static_assert(kDeep % 2 == 0, "the positions are computed two at a time");
+      for (;;) {
+        float d[kDeep];
+        d[0] = distance;
+#pragma unroll
+        for (int i = 1; i < kDeep; ++i) d[i] = d[i - 1] + step;
+        if (!(d[kDeep - 1] < safe_end)) break;
+        uint32_t off[kDeep];
+#pragma unroll
+        for (int pair = 0; pair < kDeep / 2; ++pair) {
+          const float_pair dd = {d[2 * pair], d[2 * pair + 1]};
+          const float_pair qx = __builtin_elementwise_fma(ray.ox + ray.dx * dd, ix2, nx2);
+          const float_pair qy = __builtin_elementwise_fma(ray.oy + ray.dy * dd, iy2, ny2);
+          const float_pair qz = __builtin_elementwise_fma(ray.oz + ray.dz * dd, iz2, nz2);
+          off[2 * pair] = bricklet_offset(static_cast<int>(qx.x), static_cast<int>(qy.x),
+                                          static_cast<int>(qz.x), row_pitch, plane_pitch);
+          off[2 * pair + 1] = bricklet_offset(static_cast<int>(qx.y), static_cast<int>(qy.y),
+                                              static_cast<int>(qz.y), row_pitch, plane_pitch);
+        }
+        int idx[kDeep];
+#pragma unroll
+        for (int i = 0; i < kDeep; ++i) idx[i] = cells[off[i]];
+        float4 sample[kDeep];
+#pragma unroll
+        for (int i = 0; i < kDeep; ++i) sample[i] = table[idx[i]];
+        float_pair rg = {acc_r, acc_g}, ba = {acc_b, acc_a};
+#pragma unroll
+        for (int i = 0; i < kDeep; ++i) {
+          const float w_ = sample[i].w * (1.0f - ba.y);
+          const float_pair color_ = {sample[i].x, sample[i].y};
+          const float_pair zw_ = {sample[i].z * w_, w_};
+          float_pair weighted_;
+          asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]"
+              : "=v"(weighted_)
+              : "v"(color_), "v"(zw_));
+          ba = ba + zw_;
+          rg = rg + weighted_;
+          asm volatile("" : "+v"(rg));
+        }
+        if (__builtin_amdgcn_ballot_w64(ba.y >= 1.0f) == 0) {
+          acc_r = rg.x;
+          acc_g = rg.y;
+          acc_b = ba.x;
+          acc_a = ba.y;
+          distance = d[kDeep - 1] + step;
+          if (STATS) fetches += static_cast<unsigned>(kDeep);
+        } else {
+          // some lane's ray terminates inside this trip: per-sample selects, as in the loop of four
+          // (sample k + 1 only if accumA < 1 still holds after sample k; the loop's own condition
+          // held before the first)
+          unsigned taken = 0u;
+          float next = distance;
+#pragma unroll
+          for (int i = 0; i < kDeep; ++i) {
+            const bool running_ = acc_a < 1.0f;
+            const float alpha_ = sample[i].w * (1.0f - acc_a);
+            const float r_ = acc_r + sample[i].x * alpha_;
+            const float g_ = acc_g + sample[i].y * alpha_;
+            const float b_ = acc_b + sample[i].z * alpha_;
+            const float a_ = acc_a + alpha_;
+            acc_r = running_ ? r_ : acc_r;
+            acc_g = running_ ? g_ : acc_g;
+            acc_b = running_ ? b_ : acc_b;
+            acc_a = running_ ? a_ : acc_a;
+            next = running_ ? (d[i] + step) : next;
+            taken += running_ ? 1u : 0u;
+          }
+          distance = next;
+          if (STATS) fetches += taken;
+          if (!(acc_a < 1.0f)) break;  // the reference's loop condition (:837)
+        }
+      }
+    }
+#endif
     for (;;) {
       const float d1 = distance;
       const float d2 = d1 + step;
@@ -803,14 +895,14 @@ render_runs_body(
     counters, pos_begin, pos_end, resume, visible_out, spec
 
 template <bool STATS, int ONLY_MODE, bool SPEC = false>
-__global__ __launch_bounds__(kBlockThreads, 6) void render_runs_kernel(AVR_MARCH_PARAMETERS) {
+__global__ __launch_bounds__(kBlockThreads, AVR_MARCH_GROUP >= 16 ? 3 : AVR_MARCH_GROUP >= 8 ? 4 : AVR_MARCH_GROUP >= 6 ? 5 : 6) void render_runs_kernel(AVR_MARCH_PARAMETERS) {
   render_runs_body<STATS, ONLY_MODE, SPEC>(AVR_MARCH_ARGUMENTS);
 }
 
 // The gated second march of a speculative frame under a name of its own (a profile then tells the
 // marches that ran from the repair launches that found nothing to do).
 template <int ONLY_MODE>
-__global__ __launch_bounds__(kBlockThreads, 6) void render_runs_repair_kernel(AVR_MARCH_PARAMETERS) {
+__global__ __launch_bounds__(kBlockThreads, AVR_MARCH_GROUP >= 16 ? 3 : AVR_MARCH_GROUP >= 8 ? 4 : AVR_MARCH_GROUP >= 6 ? 5 : 6) void render_runs_repair_kernel(AVR_MARCH_PARAMETERS) {
   render_runs_body<false, ONLY_MODE, true>(AVR_MARCH_ARGUMENTS);
 }
 #undef AVR_MARCH_PARAMETERS
