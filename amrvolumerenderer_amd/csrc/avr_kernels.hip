@@ -39,7 +39,8 @@ constexpr int kBlockThreads = 256;  // workgroup = kTile x kTile pixels = 4 wave
 // -> 0.603 ms and the pipelined frame 0.931 -> 0.874 (round 5, after the side-by-side counters showed
 // that a SIMD's wave slots bind, not its registers: profiles/r5_corun_counters/); 6: 0.618 / 0.895,
 // 10: 0.630 / 0.888, 12: 0.633 / 0.884, 16: 0.712 / 0.919, 4 (no deep loop): 0.657 / 0.931.
-// Power-of-two spacings only (every BASELINE configuration); other boxes take the loop of four.
+// Power-of-two spacings (every BASELINE configuration) and reciprocal ones alike; degenerate
+// spacings (the exact divide throughout) take the loop of four.
 #ifndef AVR_MARCH_GROUP
 #define AVR_MARCH_GROUP 8
 #endif
@@ -294,7 +295,7 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
     // trip per trip of this loop (profiles/r5_corun_counters/): more loads per trip is what a wave
     // can still give.  Every sample is accumulated by the same operations in the same order as
     // below; what is left takes the loop of four, then the general loop.
-    if (MODE == kPow2Multiply) {
+    if (MODE == kPow2Multiply || MODE == kReciprocal) {
       constexpr int kDeep = AVR_MARCH_GROUP;
       static_assert(kDeep % 2 == 0, "the positions are computed two at a time");
       for (;;) {
@@ -307,13 +308,25 @@ __device__ __forceinline__ Layer5 march_box(const BoxDev& box, const FrameConsts
 #pragma unroll
         for (int pair = 0; pair < kDeep / 2; ++pair) {
           const float_pair dd = {d[2 * pair], d[2 * pair + 1]};
-          const float_pair qx = __builtin_elementwise_fma(ray.ox + ray.dx * dd, ix2, nx2);
-          const float_pair qy = __builtin_elementwise_fma(ray.oy + ray.dy * dd, iy2, ny2);
-          const float_pair qz = __builtin_elementwise_fma(ray.oz + ray.dz * dd, iz2, nz2);
-          off[2 * pair] = bricklet_offset(static_cast<int>(qx.x), static_cast<int>(qy.x),
-                                          static_cast<int>(qz.x), row_pitch, plane_pitch);
-          off[2 * pair + 1] = bricklet_offset(static_cast<int>(qx.y), static_cast<int>(qy.y),
-                                              static_cast<int>(qz.y), row_pitch, plane_pitch);
+          if (MODE == kPow2Multiply) {
+            const float_pair qx = __builtin_elementwise_fma(ray.ox + ray.dx * dd, ix2, nx2);
+            const float_pair qy = __builtin_elementwise_fma(ray.oy + ray.dy * dd, iy2, ny2);
+            const float_pair qz = __builtin_elementwise_fma(ray.oz + ray.dz * dd, iz2, nz2);
+            off[2 * pair] = bricklet_offset(static_cast<int>(qx.x), static_cast<int>(qy.x),
+                                            static_cast<int>(qz.x), row_pitch, plane_pitch);
+            off[2 * pair + 1] = bricklet_offset(static_cast<int>(qx.y), static_cast<int>(qy.y),
+                                                static_cast<int>(qz.y), row_pitch, plane_pitch);
+          } else {
+            // the reference's two roundings, (pos - min) then * RN(1/d), as in the loop of four
+            const float_pair fx = (ray.ox + ray.dx * dd) - min_x;
+            const float_pair fy = (ray.oy + ray.dy * dd) - min_y;
+            const float_pair fz = (ray.oz + ray.dz * dd) - min_z;
+            const float_pair qx = fx * inv_x, qy = fy * inv_y, qz = fz * inv_z;
+            off[2 * pair] = offset_from_quotients<MODE, false, STATS>(
+                box, row_pitch, plane_pitch, qx.x, qy.x, qz.x, fx.x, fy.x, fz.x, near_hits);
+            off[2 * pair + 1] = offset_from_quotients<MODE, false, STATS>(
+                box, row_pitch, plane_pitch, qx.y, qy.y, qz.y, fx.y, fy.y, fz.y, near_hits);
+          }
         }
         int idx[kDeep];
 #pragma unroll
