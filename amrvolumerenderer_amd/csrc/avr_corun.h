@@ -137,6 +137,7 @@ struct CoRunTuner {
   float finalist_ms[5] = {0, 0, 0, 0, 0};
   static constexpr float kPlayoffWithin = 1.06f;
   static constexpr float kPlayoffDecided = 0.025f;  // of the smaller sum of readings
+  static constexpr float kPlayoffEquivalent = 0.01f;
   static constexpr int kPlayoffReadings = 4;        // per finalist at most (the first one included)
   static constexpr int kPlayoffFrames = 4;
   bool b_playoff = false;        // the two best finalists are being read again
@@ -202,7 +203,7 @@ struct CoRunTuner {
       // A close call (a reading of four frames after three is good to 2-3 %; the pockets beside the
       // best reserve are 4-8 % slower, so one reading each orders the two wrongly one time in
       // eight): within 6 % the best two are read again, in ascending order, until their means
-      // differ by 2.5 % or each has four readings -- a sequential test: clear cases cost nothing,
+      // differ by 2.5 % (or by less than 1 %: either will do) or each has four readings -- a sequential test: clear cases cost nothing,
       // and only the ambiguous ones the frames.
       if (!b_playoff && second >= 0 && finalist_ms[second] < finalist_ms[chosen] * kPlayoffWithin) {
         b_playoff = true;
@@ -223,9 +224,10 @@ struct CoRunTuner {
         playoff_sum_ms[0] += finalist_ms[0];
         playoff_sum_ms[1] += finalist_ms[1];
         ++playoff_readings;
-        const float gap = std::fabs(playoff_sum_ms[0] - playoff_sum_ms[1]);
-        if (gap < kPlayoffDecided * std::min(playoff_sum_ms[0], playoff_sum_ms[1]) &&
-            playoff_readings < kPlayoffReadings) {
+        const float gap = std::fabs(playoff_sum_ms[0] - playoff_sum_ms[1]) /
+                          std::min(playoff_sum_ms[0], playoff_sum_ms[1]);
+        // (means within 1 % after two readings each: the two are as good as each other)
+        if (gap < kPlayoffDecided && gap >= kPlayoffEquivalent && playoff_readings < kPlayoffReadings) {
           b_final_at = 0;
           begin_balance_step(finalists[0]);
           return;
