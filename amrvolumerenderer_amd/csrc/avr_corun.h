@@ -126,6 +126,7 @@ struct CoRunTuner {
   static constexpr int kFinalistFrames = 4;
   static constexpr int kFirstFinalistSettle = 6;  // (the first one follows a jump across the bracket)
   static constexpr int kBalanceSeed = 12;    // 24 KiB: where config-4's one-rank frame balances
+  static constexpr float kSeedBalanced = 0.06f;  // |classify - march| at the seed, of the longer: no bisection
   static constexpr float kBalanceMinMs = 0.35f;  // shorter frames take the full search (the paired
                                                  // layout and back to back are candidates there)
   static constexpr float kClassifyGapMs = 0.014f, kMarchGapMs = 0.028f;  // between two kernels of a stream
@@ -241,7 +242,13 @@ struct CoRunTuner {
       interrupt();
       return;
     }
-    if (classify < march) {  // the march's stream is the longer one: hold the classify pass back further
+    if (candidate == kBalanceSeed && b_lo == 0 && b_hi == kLastCandidate &&
+        std::fabs(classify - march) <= kSeedBalanced * longer) {
+      // the seed already balances the two (config-4's 24 KiB): no bisection, the five reserves
+      // around it are timed at once
+      b_lo = kBalanceSeed;
+      b_hi = kBalanceSeed + 1;
+    } else if (classify < march) {  // the march's stream is the longer one: hold the classify pass back further
       b_lo = candidate;
     } else {
       b_hi = candidate;
