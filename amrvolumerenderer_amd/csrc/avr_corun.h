@@ -161,8 +161,13 @@ struct CoRunTuner {
   // the frame was queued under; frames of an older candidate are still in flight after a change.
   void report_durations(int frame_candidate, float classify_ms, float march_ms) {
     if (phase != kBalance || frame_candidate != candidate) return;
-    const int settle = !b_final ? kBalanceSettle : (b_final_at == 0 ? kFirstFinalistSettle : kFinalistSettle);
-    const int frames = b_playoff ? kPlayoffFrames : b_final ? kFinalistFrames : kBalanceStepFrames;
+    // (the seed's reading decides whether the bisection runs at all, and the first frames of a
+    // pipeline read 10-15 % long: it gets the finalists' settling and four frames)
+    const bool seed_step = !b_final && b_lo == 0 && b_hi == kLastCandidate && candidate == kBalanceSeed;
+    const int settle = seed_step ? kFirstFinalistSettle
+                       : !b_final ? kBalanceSettle
+                                  : (b_final_at == 0 ? kFirstFinalistSettle : kFinalistSettle);
+    const int frames = b_playoff ? kPlayoffFrames : (b_final || seed_step) ? kFinalistFrames : kBalanceStepFrames;
     if (++b_reports <= settle) return;
     b_classify += classify_ms;
     b_march += march_ms;
